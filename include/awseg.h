@@ -1,0 +1,311 @@
+/*
+ * awseg.h — C ABI of libawseg_hip.so, the MI355X (gfx950) hot path of the
+ * adverse-weather segmentation robustness benchmark.
+ *
+ * The reference (REF = A-SHOJAEI/adverse-weather-semantic-segmentation-robustness-benchmark,
+ * PKG = REF/src/adverse_weather_semantic_segmentation_robustness_benchmark) is pure
+ * Python and has no FFI of its own; each entry point below names the reference
+ * function (file:line) whose arithmetic it replaces.  INTEGRATION.md shows the
+ * ctypes stub a reference maintainer would add at each of those call sites.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the parameter is documented "host";
+ *   - plain pointers and sizes only: no torch / HIP C++ types in any signature
+ *     (`awseg_stream_t` is a `hipStream_t` passed as an opaque `void*`, NULL = the
+ *     null stream);
+ *   - every call is asynchronous and stream-ordered, never allocates, never
+ *     synchronises, never throws; workspaces are caller-provided;
+ *   - return value: 0 = success; a positive value is the `hipError_t` of the failed
+ *     launch; a negative value is one of the AWSEG_E* codes below (argument check
+ *     failed on the host, nothing was launched);
+ *   - images are HWC uint8 (the loader's numpy layout, PKG/data/loader.py:206),
+ *     logits are NCHW float32 (torch default, PKG/models/model.py:214),
+ *     label / prediction maps are [B,H,W].
+ */
+#ifndef AWSEG_H
+#define AWSEG_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* awseg_stream_t;
+
+/* argument-check failures (nothing launched) */
+#define AWSEG_EINVAL   (-1) /* bad size / null pointer / unknown enum */
+#define AWSEG_ERANGE   (-2) /* a size exceeds what the kernel's indexing supports */
+#define AWSEG_EALIGN   (-3) /* pointer not aligned as documented */
+
+/* element types of label / prediction maps */
+#define AWSEG_U8   0
+#define AWSEG_I64  1
+
+/* ensemble strategies, PKG/models/model.py:443-458 */
+#define AWSEG_COMBINE_WEIGHTED  0
+#define AWSEG_COMBINE_MAXCONF   1
+#define AWSEG_COMBINE_MEAN      2
+
+/* base losses, PKG/models/model.py:548-553 */
+#define AWSEG_LOSS_CE     0
+#define AWSEG_LOSS_FOCAL  1
+
+#define AWSEG_MAX_CLASSES 32   /* per-pixel channel vectors live in registers */
+#define AWSEG_GAUSS_RADIUS 8   /* scipy gaussian_filter(sigma=2, truncate=4) -> 17 taps */
+
+int         awseg_abi_version(void);          /* bumps when a signature changes */
+const char* awseg_error_string(int code);     /* host string for any return code */
+int         awseg_device_count(void);         /* hipGetDeviceCount, 0 when no GPU */
+
+/* ------------------------------------------------------------------------- *
+ *  A13  IoUMetrics.compute_iou — confusion accumulation
+ *       replaces PKG/evaluation/metrics.py:54-71
+ * ------------------------------------------------------------------------- *
+ * counts[(t*C [mod 256 when label_wrap_u8]) + p] += 1 for every pixel with
+ * label t != ignore_index.  `counts` is int64[C*C], caller-zeroed, accumulated
+ * in place (additive across calls, images and ranks).  label_wrap_u8 = 1
+ * reproduces the reference's uint8 arithmetic of `targets * num_classes`
+ * (metrics.py:68 on a uint8 tensor wraps mod 256 before promotion); with 0 the
+ * product is exact (int64 labels).  A pixel whose flat index falls outside
+ * [0, C*C) — or whose prediction is outside [0, C) — is not counted and
+ * increments *oob (int64[1], caller-zeroed): the host raises IndexError as
+ * torch's index_add_ does.
+ */
+int awseg_confusion_accumulate(const void* pred, int pred_dtype,
+                               const void* label, int label_dtype,
+                               int64_t n, int num_classes, int ignore_index,
+                               int label_wrap_u8,
+                               int64_t* counts, int64_t* oob,
+                               awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A12  logits.argmax(dim=1)
+ *       replaces REF/scripts/evaluate.py:179, PKG/training/trainer.py:447,
+ *       PKG/evaluation/metrics.py:50-51
+ * ------------------------------------------------------------------------- *
+ * logits float32 [B,C,HW]; pred [B,HW] of pred_dtype.  First index wins on
+ * ties, NaN compares as the maximum (torch semantics).
+ */
+int awseg_argmax(const float* logits, int64_t batch, int num_classes, int64_t hw,
+                 void* pred, int pred_dtype, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A11+A12+A13  EnsembleModel combine -> /temperature -> argmax -> confusion
+ *       replaces PKG/models/model.py:443-462, REF/scripts/evaluate.py:179,
+ *       PKG/evaluation/metrics.py:54-71 in one pass over the member logits
+ * ------------------------------------------------------------------------- *
+ * seg1 (SegFormer) / seg2 (DeepLabV3+) float32 [B,C,HW].
+ * weights: device float[2] = softmax(ensemble_weights) (WEIGHTED only, else may
+ *          be NULL).  temperature: device float[1] or NULL (no scaling).
+ * Arithmetic is four separately rounded float32 operations per element
+ * ((w0*s1 + w1*s2) / T), no FMA contraction, as torch evaluates it.
+ * Optional outputs (NULL = skip): out_logits float32 [B,C,HW]; pred [B,HW].
+ * Optional fused confusion: label [B,HW] (NULL = skip), counts int64
+ * [n_slots, C*C] where slot 0 receives every image and slot 1+cond[b] the
+ * image's own weather condition (cond: device int32[B] or NULL -> slot 0 only;
+ * cond[b] < 0 -> slot 0 only).  oob as in awseg_confusion_accumulate.
+ */
+int awseg_combine_argmax_confusion(const float* seg1, const float* seg2,
+                                   int64_t batch, int num_classes, int64_t hw,
+                                   int mode, const float* weights, const float* temperature,
+                                   float* out_logits, void* pred, int pred_dtype,
+                                   const void* label, int label_dtype, int ignore_index,
+                                   int label_wrap_u8, const int32_t* cond,
+                                   int64_t* counts, int n_slots, int64_t* oob,
+                                   awseg_stream_t stream);
+
+/* Single-model variant of the above: logits -> argmax -> confusion (77 B/px). */
+int awseg_argmax_confusion(const float* logits, int64_t batch, int num_classes, int64_t hw,
+                           void* pred, int pred_dtype,
+                           const void* label, int label_dtype, int ignore_index,
+                           int label_wrap_u8, const int32_t* cond,
+                           int64_t* counts, int n_slots, int64_t* oob,
+                           awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A7  Normalize + ToTensorV2
+ *       replaces PKG/data/loader.py:195-198, 275-278
+ * ------------------------------------------------------------------------- *
+ * img uint8 HWC -> out float32 CHW, (x/255 - mean[c]) / std[c], three
+ * separately rounded float32 operations.  mean/std are host float[3].
+ */
+int awseg_normalize(const uint8_t* img, int height, int width,
+                    const float* mean_host, const float* std_host,
+                    float* out_chw, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A2  _generate_synthetic_depth
+ *       replaces PKG/data/preprocessing.py:227-248
+ * ------------------------------------------------------------------------- *
+ * depth = max(gaussian_filter((y/H)*100 + noise, sigma=2), 1.0) in float64:
+ * 17-tap separable filter, axis 0 first then axis 1, scipy 'reflect' border,
+ * scipy's symmetric summation order.  noise: float64 [H,W] (the host's
+ * np.random.normal(0,10) draw) or NULL -> N(0,10) from the in-kernel Philox
+ * stream keyed by `seed`.  taps: host double[17] = the normalised kernel.
+ * depth_out float64 [H,W].
+ */
+int awseg_synthetic_depth(const double* noise, uint64_t seed, int height, int width,
+                          const double* taps_host, double* depth_out,
+                          awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A3  _apply_fog            replaces PKG/data/preprocessing.py:113-123
+ * ------------------------------------------------------------------------- *
+ * t = exp(-beta*depth); out = trunc(clip(img/255 * t + (double)(float)A*(1-t), 0,1)*255)
+ * in float64 (img/255 is float32, A is rounded to float32 first, as numpy does).
+ * norm_out: optional fused A7 output (float32 CHW) or NULL; mean/std host float[3].
+ */
+int awseg_fog_apply(const uint8_t* img, const double* depth, int height, int width,
+                    double beta, double atmos_light,
+                    uint8_t* out, float* norm_out,
+                    const float* mean_host, const float* std_host,
+                    awseg_stream_t stream);
+
+/* A2+A3 in one kernel: depth never leaves the chip (noise tile + halo staged in LDS).
+ * noise NULL -> Philox.  depth_out optional (NULL = not written). */
+int awseg_fog_fused(const uint8_t* img, const double* noise, uint64_t seed,
+                    int height, int width, const double* taps_host,
+                    double beta, double atmos_light,
+                    uint8_t* out, float* norm_out, double* depth_out,
+                    const float* mean_host, const float* std_host,
+                    awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A6  _apply_night          replaces PKG/data/preprocessing.py:209-225
+ * ------------------------------------------------------------------------- *
+ * v = ((img/255)*f32(brightness)) * f32(gain[c])   (float32, two roundings)
+ * out = trunc(clip((double)v + noise*intensity*0.5, 0,1)*255)  (float64)
+ * noise: float64 [H,W,3] (host draw of np.random.normal(0, 5/255)) or NULL ->
+ * Philox N(0, 5/255).  gains are the reference's 0.8 / 0.85 / 1.2 (host float[3]).
+ */
+int awseg_night_apply(const uint8_t* img, const double* noise, uint64_t seed,
+                      int height, int width,
+                      double brightness, double intensity, const float* gains_host,
+                      uint8_t* out, float* norm_out,
+                      const float* mean_host, const float* std_host,
+                      awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A4  _apply_rain           replaces PKG/data/preprocessing.py:131-168
+ * ------------------------------------------------------------------------- *
+ * haze: v = v*(1-0.3I) + 0.3I*0.7 (float32); streaks: n_drops line segments
+ * (x0,y0,x1,y1,thickness) painted with colour (.8,.9,1.0); 3x3 Gaussian blur
+ * sigma 0.5, BORDER_REFLECT_101, float32; quantise.  drops: device int32[n,5]
+ * in drawing order (later drops overwrite earlier ones — same colour, so order
+ * is immaterial).  OpenCV's rasteriser is not available offline: the coverage
+ * rule is stated in oracle/awseg_oracle.c (parity unpinned).
+ */
+int awseg_rain_apply(const uint8_t* img, int height, int width,
+                     double intensity, const int32_t* drops, int n_drops,
+                     uint8_t* out, float* norm_out,
+                     const float* mean_host, const float* std_host,
+                     awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A5  _apply_snow           replaces PKG/data/preprocessing.py:176-202
+ * ------------------------------------------------------------------------- *
+ * v = clip(v + 0.2I, 0, 1); n_flakes filled discs (x,y,r) of 1.0; Gaussian
+ * blur ksize 3 or 7, sigma 1.0, BORDER_REFLECT_101, float32; quantise.
+ * flakes: device int32[n,3].
+ */
+int awseg_snow_apply(const uint8_t* img, int height, int width,
+                     double intensity, const int32_t* flakes, int n_flakes, int blur_ksize,
+                     uint8_t* out, float* norm_out,
+                     const float* mean_host, const float* std_host,
+                     awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A16  AdverseWeatherTrainer._estimate_fog_density
+ *       replaces PKG/training/trainer.py:494-511 (and its .to(device) at :321)
+ * ------------------------------------------------------------------------- *
+ * density[b] = U[0,1) * scale(cond[b]) + offset(cond[b]) generated on device
+ * (Philox; the reference draws from torch's CPU generator, so parity is in
+ * distribution only).  cond: host int32[B] (0 clean,1 fog,2 rain,3 snow,4 night).
+ */
+int awseg_fog_density_field(const int32_t* cond_host, int batch, int64_t hw, uint64_t seed,
+                            float* density, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A15  FogDensityAwareLoss  replaces PKG/models/model.py:577-587, 610, 638-642
+ * ------------------------------------------------------------------------- *
+ * Forward: per pixel ce = logsumexp(x) - x[label]; focal: (1-exp(-ce))^2 * ce;
+ * times (1 + sensitivity*density) when density != NULL.  Writes per-block
+ * partial sums (float64) into `partials` (>= awseg_loss_partials(batch*hw)
+ * doubles) and the float32 mean into loss_mean[0] via a second tiny launch.
+ * pixel_loss: optional float32 [B,HW] output.  A label outside [0,C) raises
+ * *oob (torch raises IndexError; ignore_index=-100 never occurs for uint8).
+ * Backward: grad_logits[b,c,p] = g * w_p * (softmax_c - [c==label]) * focal' / N
+ * with g = grad_scale[0] (device float, the upstream gradient of the mean).
+ */
+int64_t awseg_loss_partials(int64_t n_pixels);
+int awseg_fog_ce_forward(const float* logits, const void* label, int label_dtype,
+                         const float* density, int64_t batch, int num_classes, int64_t hw,
+                         int base_loss, float sensitivity,
+                         float* pixel_loss, double* partials, float* loss_mean,
+                         int64_t* oob, awseg_stream_t stream);
+int awseg_fog_ce_backward(const float* logits, const void* label, int label_dtype,
+                          const float* density, int64_t batch, int num_classes, int64_t hw,
+                          int base_loss, float sensitivity, const float* grad_scale,
+                          float* grad_logits, awseg_stream_t stream);
+
+/* _estimate_fog_density_from_depth, PKG/models/model.py:658-677.
+ * depth float32 [B,H,W] -> density float32 [B,H,W]; statistics (min, max, mean
+ * gradient magnitude) are global over the whole batch as in the reference.
+ * workspace: >= awseg_density_workspace(batch*h*w) bytes. */
+int64_t awseg_density_workspace(int64_t n_pixels);
+int awseg_fog_density_from_depth(const float* depth, int64_t batch, int height, int width,
+                                 float* density, void* workspace, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A8  SegFormer segmentation head, upsample fused away
+ *       replaces PKG/models/model.py:209-214 (F.interpolate x32 -> Conv3x3 ->
+ *       BatchNorm(eval) -> ReLU -> Conv1x1)
+ * ------------------------------------------------------------------------- *
+ * feat float32 [B,Cin,h,w] (stride-32 encoder output); the full-resolution
+ * [B,Cin,H,W] tensor is never materialised: because bilinear upsampling and the
+ * 3x3 convolution are both linear, conv3x3(up(f)) = sum_tap shift_tap(up(W_tap f)).
+ *   g9     float32 [B, 9, h, w, Cmid]  = per-tap 1x1 products W_tap . f, computed by the
+ *          caller with a plain GEMM (tap = ky*3+kx, channel-last)
+ *   scale/shift float32 [Cmid]: conv bias + eval-mode BatchNorm folded to y*scale+shift
+ *   w2     float32 [Cout, Cmid], b2 float32 [Cout]: the 1x1 classifier
+ * out float32 [B,Cout,H,W].  Zero padding of the 3x3 at the image border and
+ * align_corners=False source coordinates follow torch exactly.
+ */
+int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmid, int h, int w,
+                               int height, int width,
+                               const float* scale, const float* shift,
+                               const float* w2, const float* b2, int cout,
+                               float* out, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  A9  DeepLabV3+ ASPP: depthwise atrous 3x3 of all three rates in one pass
+ *       replaces the three SeparableConv2d depthwise halves of smp's ASPP
+ *       (call site PKG/models/model.py:259-265, 349)
+ * ------------------------------------------------------------------------- *
+ * x float32 NHWC [B,h,w,C]; wdw float32 [3 rates][9 taps][C]; out float32
+ * [3][B,h,w,C] (NHWC per rate) ready for the pointwise GEMMs.
+ */
+int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int channels,
+                          const float* wdw, int rate0, int rate1, int rate2,
+                          float* out, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  next #1  ConfidenceCalibration.compute_ece accumulators
+ *       replaces PKG/evaluation/metrics.py:161-194 (the per-pixel part)
+ * ------------------------------------------------------------------------- *
+ * For every pixel with label != 255: conf = max softmax prob, bin k with
+ * edges[k] < conf <= edges[k+1] (edges: device float32[n_bins+1] =
+ * torch.linspace(0,1,n_bins+1)); bins[slot][k] += {1, conf, correct} as
+ * (int64 count, float64 sum_conf, int64 sum_correct) packed in 3 x 8 bytes.
+ * Slots as in awseg_combine_argmax_confusion.
+ */
+int awseg_ece_accumulate(const float* logits, int64_t batch, int num_classes, int64_t hw,
+                         const void* label, int label_dtype, const int32_t* cond,
+                         const float* edges, int n_bins,
+                         void* bins, int n_slots, awseg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWSEG_H */

@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by IMPORTING THE REFERENCE (run in the build container only).
+
+    python tests/golden/make_golden.py            # needs /root/reference
+
+The reference cannot travel to the GPU box, so its outputs on fixed seeded inputs are
+committed here as small data fixtures; this script is how they were made.
+
+What is imported:
+  * PKG/evaluation/metrics.py  — as is                      -> A12/A13/A14, ECE
+  * PKG/data/preprocessing.py  — loaded by path with an inert, never-called `cv2`
+    module entry (cv2 is absent; fog / night / depth never touch it)   -> A2/A3/A6
+  * PKG/models/model.py        — loaded by path with inert `torchvision` /
+    `segmentation_models_pytorch` entries (absent; never called)        -> A11/A15,
+    and `SegFormerModel.forward`'s upsample+head arithmetic via the module pieces.
+Nothing that fetches weights/configs by name is constructed.
+rain / snow need the real cv2: no golden vectors exist for them (parity unpinned).
+"""
+import importlib.util
+import sys
+import types
+from pathlib import Path
+
+import numpy as np
+import torch
+
+REF = Path("/root/reference")
+PKG = REF / "src" / "adverse_weather_semantic_segmentation_robustness_benchmark"
+OUT = Path(__file__).resolve().parent
+
+
+def _load(name, path):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference():
+    sys.path.insert(0, str(REF / "src"))
+    from adverse_weather_semantic_segmentation_robustness_benchmark.evaluation import metrics
+    import transformers  # noqa: F401  (must be imported before the placeholders below)
+    for name in ("cv2", "torchvision", "torchvision.models", "segmentation_models_pytorch"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    pre = _load("ref_preprocessing", PKG / "data" / "preprocessing.py")
+    model = _load("ref_model", PKG / "models" / "model.py")
+    return metrics, pre, model
+
+
+def gen_weather(pre):
+    """fog / night / synthetic depth: (image, seed, intensity) -> u8 output, plus the fields
+    the reference drew, recovered by replaying its RNG call order."""
+    out = {}
+    tf = pre.WeatherDegradationTransforms()
+    cases = [(32, 64, 1, 0.5), (48, 80, 2, None), (17, 23, 3, 0.9), (64, 128, 4, None)]
+    for k, (h, w, seed, inten) in enumerate(cases):
+        rs = np.random.RandomState(1000 + seed)
+        img = rs.randint(0, 255, (h, w, 3), dtype=np.uint8)
+        out[f"img{k}"] = img
+        out[f"case{k}"] = np.array([h, w, seed, -1.0 if inten is None else inten], dtype=np.float64)
+        # ---- fog
+        np.random.seed(seed)
+        out[f"fog{k}"] = tf.apply_weather_effect(img, "fog", inten)
+        np.random.seed(seed)
+        noise = np.random.normal(0, 10, (h, w))
+        i_used = np.random.uniform(0.3, 0.9) if inten is None else inten
+        out[f"fog_noise{k}"] = noise
+        out[f"fog_intensity{k}"] = np.float64(i_used)
+        np.random.seed(seed)
+        out[f"depth{k}"] = tf._generate_synthetic_depth(h, w)
+        # ---- night
+        np.random.seed(seed)
+        out[f"night{k}"] = tf.apply_weather_effect(img, "night", inten)
+        np.random.seed(seed)
+        i_used = np.random.uniform(0.4, 0.8) if inten is None else inten
+        bf = 1 - i_used * np.random.uniform(0.2, 0.6)
+        nz = np.random.normal(0, 5.0 / 255.0, (h, w, 3))
+        out[f"night_intensity{k}"] = np.float64(i_used)
+        out[f"night_brightness{k}"] = np.float64(bf)
+        out[f"night_noise{k}"] = nz
+    out["n_cases"] = np.int64(len(cases))
+    # clean is the identity (preprocessing.py:78-79) and unknown types raise
+    try:
+        tf.apply_weather_effect(out["img0"], "hail")
+        out["unknown_raises"] = np.int64(0)
+    except ValueError as e:
+        out["unknown_raises"] = np.int64(1)
+        out["unknown_msg"] = np.array(str(e))
+    np.savez_compressed(OUT / "weather.npz", **out)
+
+
+def gen_metrics(metrics):
+    out = {}
+    C = 19
+    iou = metrics.IoUMetrics(C)
+    rs = np.random.RandomState(7)
+    n = 0
+    for label_dtype in ("int64", "uint8"):
+        for ignore in ("none", "some", "all"):
+            pred = rs.randint(0, C, (2, 24, 40)).astype(np.int64)
+            lab = rs.randint(0, C, (2, 24, 40))
+            if ignore == "some":
+                lab[rs.rand(*lab.shape) < 0.1] = 255
+            elif ignore == "all":
+                lab[:] = 255
+            lab = lab.astype(label_dtype)
+            res = iou.compute_iou(torch.from_numpy(pred), torch.from_numpy(lab))
+            # the confusion matrix itself, by the reference's own expressions (metrics.py:54-71)
+            p, t = torch.from_numpy(pred).view(-1), torch.from_numpy(lab).view(-1)
+            m = t != 255
+            p, t = p[m], t[m]
+            cm = torch.zeros(C * C, dtype=torch.long)
+            idx = t * C + p
+            cm.index_add_(0, idx.long(), torch.ones_like(idx))
+            out[f"pred{n}"], out[f"label{n}"] = pred, lab
+            out[f"counts{n}"] = cm.numpy()
+            out[f"miou{n}"] = np.float64(res["mean_iou"])
+            out[f"per_class{n}"] = res["per_class_iou"]
+            out[f"valid{n}"] = res["valid_classes"]
+            out[f"pixacc{n}"] = np.float64(iou.compute_pixel_accuracy(torch.from_numpy(pred), torch.from_numpy(lab)))
+            n += 1
+    out["n_cases"] = np.int64(n)
+    # 4-D logits input -> argmax path (metrics.py:50-51), incl. ties / NaN / -0.0
+    logits = rs.randn(2, C, 8, 12).astype(np.float32)
+    logits[0, 3, 0, 0] = logits[0, 7, 0, 0] = 9.0          # tie -> first
+    logits[0, 5, 0, 1] = np.nan                            # NaN is max
+    logits[0, 2, 0, 2] = np.nan; logits[0, 9, 0, 2] = np.nan
+    logits[1, :, 1, 1] = 0.0; logits[1, 4, 1, 1] = -0.0    # -0.0 == 0.0 -> index 0
+    logits[1, :, 2, 2] = -np.inf
+    out["am_logits"] = logits
+    out["am_pred"] = torch.from_numpy(logits).argmax(dim=1).numpy()
+    lab = rs.randint(0, C, (2, 8, 12)).astype(np.uint8)
+    out["am_label"] = lab
+    out["am_miou"] = np.float64(iou.compute_iou(torch.from_numpy(logits), torch.from_numpy(lab))["mean_iou"])
+    # degradation ratios (metrics.py:559-563)
+    rm = metrics.RobustnessMetrics(num_classes=C)
+    pairs = np.array([[0.5, 0.4], [0.0, 0.3], [0.2, 0.3], [0.0205, 0.0121], [1.0, 0.0]])
+    out["deg_pairs"] = pairs
+    out["deg_ratio"] = np.array([rm.compute_robustness_degradation_ratio(a, b) for a, b in pairs])
+    # ECE (metrics.py:143-226)
+    ece_logits = (rs.randn(2, C, 16, 20) * 3).astype(np.float32)
+    ece_lab = rs.randint(0, C, (2, 16, 20)); ece_lab[rs.rand(2, 16, 20) < 0.05] = 255
+    ece_lab = ece_lab.astype(np.uint8)
+    cal = metrics.ConfidenceCalibration()
+    det = cal.compute_ece(torch.from_numpy(ece_logits), torch.from_numpy(ece_lab), return_details=True)
+    out["ece_logits"], out["ece_label"] = ece_logits, ece_lab
+    out["ece"] = np.float64(det["ece"])
+    out["ece_prop"] = np.array([d["proportion"] for d in det["bin_details"]])
+    out["ece_acc"] = np.array([d["accuracy"] for d in det["bin_details"]])
+    out["ece_conf"] = np.array([d["confidence"] for d in det["bin_details"]])
+    np.savez_compressed(OUT / "metrics.npz", **out)
+
+
+def gen_model(model):
+    out = {}
+    rs = np.random.RandomState(11)
+    C = 19
+    # ---- A11 combine via EnsembleModel.forward run unbound on a stand-in (no constructor)
+    s1 = (rs.randn(2, C, 12, 20) * 2).astype(np.float32)
+    s2 = (rs.randn(2, C, 12, 20) * 2).astype(np.float32)
+    out["seg1"], out["seg2"] = s1, s2
+
+    class Member(torch.nn.Module):
+        def __init__(self, t):
+            super().__init__(); self.t = t
+        def forward(self, x):
+            return {"segmentation": self.t}
+
+    n = 0
+    for strat in ("weighted_average", "max_confidence", "mean"):
+        for ts in (True, False):
+            stand = types.SimpleNamespace(
+                segformer=Member(torch.from_numpy(s1)), deeplabv3plus=Member(torch.from_numpy(s2)),
+                ensemble_strategy=strat, temperature_scaling=ts, include_depth=False,
+                ensemble_weights=torch.tensor([0.3, -0.4]), temperature=torch.tensor([1.7]))
+            with torch.no_grad():
+                res = model.EnsembleModel.forward(stand, torch.zeros(2, 3, 12, 20))
+            out[f"combine{n}"] = res["segmentation"].numpy()
+            out[f"combine_cfg{n}"] = np.array([["weighted_average", "max_confidence", "mean"].index(strat), int(ts)])
+            n += 1
+    out["n_combine"] = np.int64(n)
+    out["ens_w"] = torch.softmax(torch.tensor([0.3, -0.4]), dim=0).numpy()
+    out["ens_t"] = np.float32(1.7)
+
+    # ---- A15 loss
+    logits = (rs.randn(2, C, 16, 24) * 2).astype(np.float32)
+    lab = rs.randint(0, C, (2, 16, 24))
+    dens = rs.rand(2, 16, 24).astype(np.float32)
+    dpred = rs.rand(2, 1, 16, 24).astype(np.float32)
+    dtgt = rs.rand(2, 16, 24).astype(np.float32)
+    out.update(loss_logits=logits, loss_label=lab.astype(np.int64), loss_density=dens, loss_dpred=dpred, loss_dtgt=dtgt)
+    n = 0
+    for base in ("cross_entropy", "focal"):
+        for ldt in (np.int64, np.uint8):
+            for variant in ("density", "from_depth", "plain", "density_depth_target"):
+                fn = model.FogDensityAwareLoss(base_loss=base)
+                preds = {"segmentation": torch.from_numpy(logits).requires_grad_(True)}
+                tg = {"label": torch.from_numpy(lab.astype(ldt))}
+                fd = None
+                if variant in ("density", "density_depth_target"):
+                    fd = torch.from_numpy(dens)
+                if variant in ("from_depth", "density_depth_target"):
+                    preds["depth"] = torch.from_numpy(dpred)
+                if variant == "density_depth_target":
+                    tg["depth"] = torch.from_numpy(dtgt)
+                r = fn(preds, tg, fd)
+                r["total_loss"].backward()
+                out[f"loss_total{n}"] = np.float32(r["total_loss"].item())
+                out[f"loss_seg{n}"] = np.float32(r["segmentation_loss"].item())
+                dl = r["depth_loss"]
+                out[f"loss_depth{n}"] = np.float32(dl.item() if isinstance(dl, torch.Tensor) else dl)
+                if ldt is np.int64:
+                    out[f"loss_grad{n}"] = preds["segmentation"].grad.numpy()
+                out[f"loss_cfg{n}"] = np.array([base, np.dtype(ldt).name, variant])
+                n += 1
+    out["n_loss"] = np.int64(n)
+    fn = model.FogDensityAwareLoss()
+    out["density_from_depth"] = fn._estimate_fog_density_from_depth(torch.from_numpy(dpred[:, 0])).numpy()
+
+    # ---- A8 head arithmetic: F.interpolate -> segmentation_head (model.py:152-158, 209-214)
+    torch.manual_seed(5)
+    cin, cmid, cout = 16, 24, 7
+    head = torch.nn.Sequential(
+        torch.nn.Conv2d(cin, cmid, kernel_size=3, padding=1), torch.nn.BatchNorm2d(cmid),
+        torch.nn.ReLU(inplace=True), torch.nn.Dropout2d(0.1), torch.nn.Conv2d(cmid, cout, kernel_size=1)).eval()
+    with torch.no_grad():
+        head[1].running_mean.uniform_(-0.5, 0.5); head[1].running_var.uniform_(0.5, 2.0)
+        head[1].weight.uniform_(0.5, 1.5); head[1].bias.uniform_(-0.3, 0.3)
+        feat = torch.randn(1, cin, 3, 5)
+        H, W = 96, 160
+        up = torch.nn.functional.interpolate(feat, size=(H, W), mode="bilinear", align_corners=False)
+        y = head(up)
+    out.update(head_feat=feat.numpy(), head_w1=head[0].weight.detach().numpy(), head_b1=head[0].bias.detach().numpy(),
+               head_bn_w=head[1].weight.detach().numpy(), head_bn_b=head[1].bias.detach().numpy(),
+               head_bn_mean=head[1].running_mean.numpy(), head_bn_var=head[1].running_var.numpy(),
+               head_bn_eps=np.float64(head[1].eps), head_w2=head[4].weight.detach().numpy().reshape(cout, cmid),
+               head_b2=head[4].bias.detach().numpy(), head_out=y.numpy(), head_size=np.array([H, W]))
+    # DepthEstimationHead (model.py:42-52) on a small feature map
+    torch.manual_seed(6)
+    dh = model.DepthEstimationHead(in_channels=8, hidden_channels=16).eval()
+    x = torch.randn(1, 8, 10, 12)
+    with torch.no_grad():
+        out["dhead_out"] = dh(x).numpy()
+    out["dhead_in"] = x.numpy()
+    for kname, v in dh.state_dict().items():
+        out["dhead_sd." + kname] = v.numpy()
+    np.savez_compressed(OUT / "model.npz", **out)
+
+
+if __name__ == "__main__":
+    metrics, pre, model = load_reference()
+    gen_weather(pre)
+    gen_metrics(metrics)
+    gen_model(model)
+    for f in sorted(OUT.glob("*.npz")):
+        print(f.name, f.stat().st_size)

@@ -1,0 +1,140 @@
+"""ctypes binding of ``libawseg_hip.so`` (the C ABI declared in ``include/awseg.h``).
+
+This is the only door between the Python host code and the HIP kernels.  There is no CPU
+fallback anywhere behind it: if the library is missing or a kernel is asked to run on
+host tensors, the call raises.  (The CPU oracle lives in ``oracle/`` and is test
+infrastructure; nothing in this package imports it.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+import torch
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "libawseg_hip.so"
+
+U8, I64 = 0, 1
+COMBINE_WEIGHTED, COMBINE_MAXCONF, COMBINE_MEAN = 0, 1, 2
+LOSS_CE, LOSS_FOCAL = 0, 1
+MAX_CLASSES = 32
+
+c_i, c_i64, c_u64, c_f, c_d, c_p = C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_void_p
+
+# numpy mirrors of the job structs in include/awseg.h (align=True == the C layout)
+FOG_JOB = np.dtype([("image", "<i4"), ("_pad", "<i4"), ("beta", "<f8"), ("atmos", "<f8"), ("seed", "<u8")], align=True)
+NIGHT_JOB = np.dtype([("image", "<i4"), ("_pad", "<i4"), ("brightness", "<f8"), ("intensity", "<f8"), ("seed", "<u8")], align=True)
+PRIM_JOB = np.dtype([("image", "<i4"), ("prim_offset", "<i4"), ("prim_count", "<i4"), ("blur_ksize", "<i4"), ("intensity", "<f8")], align=True)
+assert FOG_JOB.itemsize == 32 and NIGHT_JOB.itemsize == 32 and PRIM_JOB.itemsize == 24
+
+# name -> (restype, argtypes); every symbol include/awseg.h declares
+SIGNATURES = {
+    "awseg_abi_version": (c_i, []),
+    "awseg_error_string": (C.c_char_p, [c_i]),
+    "awseg_device_count": (c_i, []),
+    "awseg_metrics_workspace": (c_i64, [c_i64, c_i, c_i64]),
+    "awseg_confusion_accumulate": (c_i, [c_p, c_i, c_p, c_i, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "awseg_argmax": (c_i, [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p]),
+    "awseg_combine_argmax_confusion": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_i, c_i,
+                                            c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "awseg_argmax_confusion": (c_i, [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "awseg_normalize": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "awseg_synthetic_depth": (c_i, [c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "awseg_fog_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_fog_fused": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_night_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_rain_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_snow_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_fog_density_field": (c_i, [c_p, c_i, c_i64, c_u64, c_p, c_p]),
+    "awseg_loss_partials": (c_i64, [c_i64, c_i64]),
+    "awseg_fog_ce_forward": (c_i, [c_p, c_p, c_i, c_p, c_i64, c_i, c_i64, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_fog_ce_backward": (c_i, [c_p, c_p, c_i, c_p, c_i64, c_i, c_i64, c_i, c_f, c_p, c_p, c_p]),
+    "awseg_density_workspace": (c_i64, [c_i64, c_i64]),
+    "awseg_fog_density_from_depth": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    "awseg_segformer_head_fused": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "awseg_aspp_depthwise3": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "awseg_ece_accumulate": (c_i, [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
+}
+
+
+class AwsegError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    """Load libawseg_hip.so; raise (never fall back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise AwsegError(
+                f"{LIB_PATH} is missing: build it with `python -m "
+                "adverse_weather_semantic_segmentation_robustness_benchmark_amd.csrc.build` "
+                "(there is no CPU fallback for the HIP hot path)")
+        handle = C.CDLL(str(LIB_PATH))
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)          # AttributeError here == header/library drift
+            fn.restype, fn.argtypes = res, args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().awseg_error_string(rc)
+        raise AwsegError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device pointer of a CUDA tensor (None -> NULL).  Host tensors are refused."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise AwsegError("awseg kernels take device (HIP) tensors only; got a CPU tensor — no CPU fallback exists")
+    if not t.is_contiguous():
+        raise AwsegError("awseg kernels take contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def host(a: np.ndarray):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def label_dtype(t: torch.Tensor) -> int:
+    if t.dtype == torch.uint8:
+        return U8
+    if t.dtype == torch.int64:
+        return I64
+    raise AwsegError(f"label/prediction maps must be uint8 or int64, got {t.dtype}")
+
+
+def jobs_to_device(arr: np.ndarray, device) -> torch.Tensor:
+    """Structured numpy job array -> uint8 device tensor (stream-ordered copy)."""
+    raw = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy())
+    return raw.to(device, non_blocking=True)
+
+
+class Workspace:
+    """Grow-only per-device scratch buffers handed to the C ABI (which never allocates)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, device, nbytes: int, tag: str = "ws") -> torch.Tensor:
+        key = (str(device), tag)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf
+
+
+workspace = Workspace()

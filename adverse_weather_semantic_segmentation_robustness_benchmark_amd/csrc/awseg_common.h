@@ -1,0 +1,91 @@
+// awseg_common.h — shared device/host helpers for libawseg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/awseg.h"
+
+#define AWSEG_API extern "C" __attribute__((visibility("default")))
+
+#define AWSEG_WAVE 64
+#define AWSEG_CUS 256
+
+// Launch check: kernels are enqueued asynchronously, so only launch-time errors surface here.
+#define AWSEG_LAUNCH_CHECK()                                  \
+    do {                                                      \
+        hipError_t e__ = hipGetLastError();                   \
+        if (e__ != hipSuccess) return (int)e__;               \
+    } while (0)
+
+static inline hipStream_t awseg_s(awseg_stream_t s) { return (hipStream_t)s; }
+
+// Memory-bound grids: cap at 8 resident 256-thread blocks per CU and grid-stride the rest
+// (cdna_hip_programming.md Guideline 11).
+static inline int awseg_grid_1d(int64_t work_items, int per_block, int max_blocks = AWSEG_CUS * 8)
+{
+    int64_t b = (work_items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+// 64-lane wavefront reductions (shuffle tree, no LDS).
+__device__ __forceinline__ double awseg_wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float awseg_wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_down(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float awseg_wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+    return v;
+}
+
+// label load for the two dtypes the reference produces (uint8 from the loader, int64 in its tests)
+template <int DT> __device__ __forceinline__ int64_t awseg_ld_label(const void* p, int64_t i)
+{
+    if (DT == AWSEG_U8) return (int64_t)((const uint8_t*)p)[i];
+    return ((const int64_t*)p)[i];
+}
+
+// Philox4x32-10 counter-based generator (throughput-mode noise; parity mode takes host draws).
+struct awseg_philox {
+    uint32_t c[4];
+    __device__ __forceinline__ static void round(uint32_t* c, uint32_t k0, uint32_t k1)
+    {
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
+        uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
+        uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    }
+    __device__ __forceinline__ static void gen(uint64_t seed, uint64_t ctr, uint32_t stream, uint32_t out[4])
+    {
+        uint32_t c[4] = { (uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0x9E3779B9u };
+        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            round(c, k0, k1);
+            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+        }
+        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+    }
+};
+// two uint32 -> one N(0,1) pair (Box-Muller, float32; distribution-only parity)
+__device__ __forceinline__ void awseg_box_muller(uint32_t a, uint32_t b, float& n0, float& n1)
+{
+    float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    float r = sqrtf(-2.0f * __logf(u1));
+    float s, c;
+    __sincosf(6.28318530717958647692f * u2, &s, &c);
+    n0 = r * c; n1 = r * s;
+}
+__device__ __forceinline__ float awseg_u01(uint32_t a) { return (float)(a >> 8) * (1.0f / 16777216.0f); }

@@ -1,0 +1,68 @@
+"""Build libawseg_hip.so for gfx950 with hipcc (in-tree; the .so travels to the GPU box).
+
+    python -m adverse_weather_semantic_segmentation_robustness_benchmark_amd.csrc.build
+
+-ffp-contract=off is load-bearing: the parity kernels must round once per operation exactly
+as numpy / torch evaluate the reference expressions.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+CSRC = Path(__file__).resolve().parent
+PKG = CSRC.parent
+LIB = PKG / "libawseg_hip.so"
+SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip"]
+ARCH = "gfx950"
+
+
+def hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", shutil.which("hipcc")):
+        if cand and Path(cand).exists():
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libawseg_hip.so)")
+
+
+def _flags():
+    return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+            "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+
+
+def needs_build() -> bool:
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "awseg_common.h", PKG.parent / "include" / "awseg.h"]
+    return any(d.stat().st_mtime > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    if not force and not needs_build():
+        return LIB
+    cc = hipcc()
+    objdir = CSRC / "build"
+    objdir.mkdir(exist_ok=True)
+
+    def compile_one(src):
+        obj = objdir / (Path(src).stem + ".o")
+        cmd = [cc, *_flags(), "-c", str(CSRC / src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    tmp = LIB.with_suffix(".so.tmp")
+    subprocess.check_call([cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs)])
+    os.replace(tmp, LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,265 @@
+// loss.hip — A15 FogDensityAwareLoss kernels (PKG/models/model.py:577-617, 638-642, 658-677).
+//
+// Forward and backward are single passes over the NCHW logits: each lane owns 4 consecutive
+// pixels, walks the C channel planes with 16-byte loads, keeps the C x 4 logits in registers
+// (C <= 32), and derives max / sum-exp / log-softmax there.  81 B/px read forward, +76 B/px
+// written backward.  The mean is reduced wave -> block in float64 and finished
+// by a one-block launch, so the loss value is independent of grid shape and launch order.
+#include "awseg_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxC = AWSEG_MAX_CLASSES;
+
+__device__ __forceinline__ double block_sum(double v, double* s_red)
+{
+    v = awseg_wave_sum(v);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) s_red[wid] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) for (int i = 0; i < kThreads / 64; ++i) t += s_red[i];
+    return t;   // valid in thread 0
+}
+
+template <int VEC, int LDT, bool BWD>
+__global__ __launch_bounds__(kThreads)
+void fog_ce_kernel(const float* __restrict__ logits, const void* __restrict__ label, const float* __restrict__ density,
+                   int C, int64_t hw, int focal, float sens, float* __restrict__ pixel_loss,
+                   double* __restrict__ partials, const float* __restrict__ grad_scale, double inv_n,
+                   float* __restrict__ grad, int64_t* __restrict__ oob)
+{
+    __shared__ double s_red[kThreads / 64];
+    const int64_t img = blockIdx.y;
+    const float* x = logits + img * C * hw;
+    float* gx = BWD ? grad + img * C * hw : nullptr;
+    const float g = BWD ? grad_scale[0] : 0.f;
+    double acc = 0.0;
+    const int64_t nvec = hw / VEC;
+    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = v * VEC;
+        float r[kMaxC][VEC];
+#pragma unroll
+        for (int c = 0; c < kMaxC; ++c) {
+            if (c < C) {
+                if constexpr (VEC == 4) {
+                    float4 t = *reinterpret_cast<const float4*>(x + (int64_t)c * hw + p);
+                    r[c][0] = t.x; r[c][1] = t.y; r[c][2] = t.z; r[c][3] = t.w;
+                } else {
+                    r[c][0] = x[(int64_t)c * hw + p];
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) {
+            int64_t t = awseg_ld_label<LDT>(label, img * hw + p + k);
+            const bool bad = (t < 0 || t >= C);
+            if (bad) { if (!BWD) atomicAdd((unsigned long long*)oob, 1ull); t = 0; }
+            float m = r[0][k];
+#pragma unroll
+            for (int c = 1; c < kMaxC; ++c) if (c < C) m = fmaxf(m, r[c][k]);
+            float sum = 0.f, xt = 0.f;
+#pragma unroll
+            for (int c = 0; c < kMaxC; ++c) if (c < C) { sum += expf(r[c][k] - m); if (c == (int)t) xt = r[c][k]; }
+            float lse = logf(sum);
+            float ce = -((xt - m) - lse);                           // F.cross_entropy(reduction='none')
+            float w = 1.0f;
+            if (density) w = 1.0f + sens * density[img * hw + p + k];   // model.py:586
+            if (!BWD) {
+                if (focal) { float pt = expf(-ce); float q = 1.f - pt; ce = (q * q) * ce; }   // :639-640
+                ce = ce * w;                                        // :587
+                if (bad) ce = 0.f;
+                if (pixel_loss) pixel_loss[img * hw + p + k] = ce;
+                acc += (double)ce;
+            } else {
+                float kf = 1.f;
+                if (focal) { float pt = expf(-ce); float q = 1.f - pt; kf = q * q + 2.f * ce * pt * q; }
+                float coef = (float)((double)g * inv_n) * w * kf;
+                if (bad) coef = 0.f;
+                float inv = 1.0f / sum;
+#pragma unroll
+                for (int c = 0; c < kMaxC; ++c) if (c < C) {
+                    float sm = expf(r[c][k] - m) * inv;
+                    r[c][k] = coef * (sm - (c == (int)t ? 1.f : 0.f));
+                }
+            }
+        }
+        if (BWD) {
+#pragma unroll
+            for (int c = 0; c < kMaxC; ++c) if (c < C) {
+                if constexpr (VEC == 4) *reinterpret_cast<float4*>(gx + (int64_t)c * hw + p) = make_float4(r[c][0], r[c][1], r[c][2], r[c][3]);
+                else gx[(int64_t)c * hw + p] = r[c][0];
+            }
+        }
+    }
+    if (!BWD) {
+        double t = block_sum(acc, s_red);
+        if (threadIdx.x == 0) partials[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = t;
+    }
+}
+
+__global__ __launch_bounds__(kThreads)
+void loss_finish_kernel(const double* __restrict__ partials, int n, double inv_n, float* __restrict__ loss_mean)
+{
+    __shared__ double s_red[kThreads / 64];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += kThreads) a += partials[i];
+    double t = block_sum(a, s_red);
+    if (threadIdx.x == 0) loss_mean[0] = (float)(t * inv_n);
+}
+
+// ------------------------------------------------------------- density from depth (:658-677)
+struct dstats { float mn, mx; double gsum; };
+
+__device__ __forceinline__ float grad_mag(const float* __restrict__ d, int y, int x, int H, int W)
+{
+    // |forward difference| with the last column/row replicated (F.pad mode='replicate'), :664-671
+    int xx = x < W - 1 ? x : (W > 1 ? W - 2 : 0);
+    int yy = y < H - 1 ? y : (H > 1 ? H - 2 : 0);
+    float gx = W > 1 ? fabsf(d[(int64_t)y * W + xx + 1] - d[(int64_t)y * W + xx]) : 0.f;
+    float gy = H > 1 ? fabsf(d[(int64_t)(yy + 1) * W + x] - d[(int64_t)yy * W + x]) : 0.f;
+    float a = gx * gx, c = gy * gy;
+    float s = a + c; s = s + 1e-8f;
+    return sqrtf(s);
+}
+
+__global__ __launch_bounds__(kThreads)
+void density_stats_kernel(const float* __restrict__ depth, int H, int W, dstats* __restrict__ partial)
+{
+    __shared__ float s_mn[4], s_mx[4];
+    __shared__ double s_red[4];
+    const int64_t hw = (int64_t)H * W;
+    const float* d = depth + (int64_t)blockIdx.y * hw;
+    float mn = INFINITY, mx = -INFINITY; double gs = 0.0;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < hw; p += (int64_t)gridDim.x * kThreads) {
+        int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+        float v = d[p];
+        mn = fminf(mn, v); mx = fmaxf(mx, v);
+        gs += (double)grad_mag(d, y, x, H, W);
+    }
+    mn = awseg_wave_min(mn); mx = awseg_wave_max(mx);
+    const int wid = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) { s_mn[wid] = mn; s_mx[wid] = mx; }
+    double t = block_sum(gs, s_red);
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { s_mn[0] = fminf(s_mn[0], s_mn[i]); s_mx[0] = fmaxf(s_mx[0], s_mx[i]); }
+        dstats o; o.mn = s_mn[0]; o.mx = s_mx[0]; o.gsum = t;
+        partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = o;
+    }
+}
+
+__global__ void density_stats_finish_kernel(const dstats* __restrict__ partial, int n, double inv_n, float* __restrict__ stats)
+{
+    // single wave: n is at most a few thousand
+    float mn = INFINITY, mx = -INFINITY; double gs = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) { mn = fminf(mn, partial[i].mn); mx = fmaxf(mx, partial[i].mx); gs += partial[i].gsum; }
+    mn = awseg_wave_min(mn); mx = awseg_wave_max(mx); gs = awseg_wave_sum(gs);
+    if (threadIdx.x == 0) { stats[0] = mn; stats[1] = mx; stats[2] = (float)(gs * inv_n); }
+}
+
+__global__ __launch_bounds__(kThreads)
+void density_apply_kernel(const float* __restrict__ depth, int H, int W, const float* __restrict__ stats,
+                          float* __restrict__ out)
+{
+    const int64_t hw = (int64_t)H * W;
+    const float* d = depth + (int64_t)blockIdx.y * hw;
+    float* o = out + (int64_t)blockIdx.y * hw;
+    const float mn = stats[0], mx = stats[1], mean = stats[2];
+    float den = mx - mn; den = den + 1e-8f;                        // :658
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < hw; p += (int64_t)gridDim.x * kThreads) {
+        int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+        float dn = (d[p] - mn) / den;
+        float f = dn * 0.7f;                                       // :661
+        float e = grad_mag(d, y, x, H, W) > mean ? 0.3f : 0.0f;    // :674
+        f = f - e;
+        o[p] = f < 0.f ? 0.f : (f > 1.f ? 1.f : f);                // :677
+    }
+}
+
+int loss_bpi(int64_t hw, int64_t batch)
+{
+    int64_t want = (hw + kThreads - 1) / kThreads;
+    int64_t cap = (AWSEG_CUS * 8 + batch - 1) / (batch < 1 ? 1 : batch);
+    if (want > cap) want = cap;
+    return (int)(want < 1 ? 1 : want);
+}
+
+}  // namespace
+
+AWSEG_API int64_t awseg_loss_partials(int64_t batch, int64_t hw) { return (int64_t)loss_bpi(hw, batch) * (batch < 1 ? 1 : batch); }
+
+template <bool BWD>
+static int fog_ce_launch(const float* logits, const void* label, int ldt, const float* density, int64_t batch, int C,
+                         int64_t hw, int base_loss, float sens, float* pixel_loss, double* partials,
+                         const float* grad_scale, float* grad, int64_t* oob, hipStream_t s)
+{
+    if (!logits || !label || batch < 1 || hw < 1 || C < 1 || C > kMaxC) return AWSEG_EINVAL;
+    if (batch > 65535) return AWSEG_ERANGE;
+    if (ldt != AWSEG_U8 && ldt != AWSEG_I64) return AWSEG_EINVAL;
+    if (base_loss != AWSEG_LOSS_CE && base_loss != AWSEG_LOSS_FOCAL) return AWSEG_EINVAL;
+    const bool vec4 = (hw % 4 == 0) && (((uintptr_t)logits & 15) == 0) && (!BWD || ((uintptr_t)grad & 15) == 0);
+    const int bpi = loss_bpi(hw, batch);
+    dim3 grid(bpi, (unsigned)batch);
+    const double inv_n = 1.0 / ((double)batch * (double)hw);
+#define AWSEG_CE(V, L) hipLaunchKernelGGL((fog_ce_kernel<V, L, BWD>), grid, dim3(kThreads), 0, s, logits, label, density, C, hw, \
+                                          base_loss, sens, pixel_loss, partials, grad_scale, inv_n, grad, oob)
+    if (vec4) { if (ldt == AWSEG_U8) AWSEG_CE(4, AWSEG_U8); else AWSEG_CE(4, AWSEG_I64); }
+    else { if (ldt == AWSEG_U8) AWSEG_CE(1, AWSEG_U8); else AWSEG_CE(1, AWSEG_I64); }
+#undef AWSEG_CE
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
+AWSEG_API int awseg_fog_ce_forward(const float* logits, const void* label, int label_dtype, const float* density,
+                                   int64_t batch, int num_classes, int64_t hw, int base_loss, float sensitivity,
+                                   float* pixel_loss, double* partials, float* loss_mean, int64_t* oob,
+                                   awseg_stream_t stream)
+{
+    if (!partials || !loss_mean || !oob) return AWSEG_EINVAL;
+    hipStream_t s = awseg_s(stream);
+    int rc = fog_ce_launch<false>(logits, label, label_dtype, density, batch, num_classes, hw, base_loss, sensitivity,
+                                  pixel_loss, partials, nullptr, nullptr, oob, s);
+    if (rc) return rc;
+    const int n = loss_bpi(hw, batch) * (int)batch;
+    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kThreads), 0, s, partials, n, 1.0 / ((double)batch * (double)hw), loss_mean);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_fog_ce_backward(const float* logits, const void* label, int label_dtype, const float* density,
+                                    int64_t batch, int num_classes, int64_t hw, int base_loss, float sensitivity,
+                                    const float* grad_scale, float* grad_logits, awseg_stream_t stream)
+{
+    if (!grad_scale || !grad_logits) return AWSEG_EINVAL;
+    return fog_ce_launch<true>(logits, label, label_dtype, density, batch, num_classes, hw, base_loss, sensitivity,
+                               nullptr, nullptr, grad_scale, grad_logits, nullptr, awseg_s(stream));
+}
+
+AWSEG_API int64_t awseg_density_workspace(int64_t batch, int64_t hw)
+{
+    return (int64_t)loss_bpi(hw, batch) * (batch < 1 ? 1 : batch) * (int64_t)sizeof(dstats) + 64;
+}
+
+AWSEG_API int awseg_fog_density_from_depth(const float* depth, int64_t batch, int height, int width, float* density,
+                                           void* workspace, awseg_stream_t stream)
+{
+    if (!depth || !density || !workspace || batch < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (batch > 65535) return AWSEG_ERANGE;
+    if ((uintptr_t)workspace & 15) return AWSEG_EALIGN;
+    hipStream_t s = awseg_s(stream);
+    const int64_t hw = (int64_t)height * width;
+    const int bpi = loss_bpi(hw, batch);
+    const int n = bpi * (int)batch;
+    float* stats = (float*)workspace;                              // 3 floats in the first 64 bytes
+    dstats* partial = (dstats*)((char*)workspace + 64);
+    dim3 grid(bpi, (unsigned)batch);
+    hipLaunchKernelGGL(density_stats_kernel, grid, dim3(kThreads), 0, s, depth, height, width, partial);
+    AWSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(density_stats_finish_kernel, dim3(1), dim3(64), 0, s, (const dstats*)partial, n,
+                       1.0 / ((double)batch * (double)hw), stats);
+    AWSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(density_apply_kernel, grid, dim3(kThreads), 0, s, depth, height, width, (const float*)stats, density);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

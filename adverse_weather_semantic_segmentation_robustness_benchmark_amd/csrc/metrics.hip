@@ -1,0 +1,471 @@
+// metrics.hip — A11/A12/A13 (+ECE) kernels: ensemble combine -> /T -> argmax -> confusion.
+//
+// Reference arithmetic (PKG = adverse_weather_semantic_segmentation_robustness_benchmark):
+//   combine      PKG/models/model.py:443-462
+//   argmax       REF/scripts/evaluate.py:179
+//   confusion    PKG/evaluation/metrics.py:54-71   (incl. the uint8 `targets*C` wrap)
+//   ECE bins     PKG/evaluation/metrics.py:161-194
+//
+// All of these are HBM-bound scans: 153-229 B/px for the fused kernel, 2 B/px
+// for confusion-from-predictions.  Layout is torch's NCHW: a pixel's C logits sit HW floats
+// apart, so each lane owns 4 consecutive pixels and walks the channels with 16-byte loads
+// (64 lanes x 16 B = one 1 KiB wave access per channel plane).  Confusion counts go to a
+// per-block LDS histogram (ds_add_u32), are written once per block as uint32 partials and
+// folded into the caller's int64 counters by a tiny second launch — no same-address global
+// atomics on the streaming path, and the result is order-independent (integers).
+#include "awseg_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kMaxBins = AWSEG_MAX_CLASSES * AWSEG_MAX_CLASSES;
+
+__device__ __forceinline__ bool is_nan(float v) { return v != v; }
+
+// torch argmax update rule: take v when v > best, or v is NaN and best is not.
+__device__ __forceinline__ void amax_step(float v, int c, float& best, int& bi)
+{
+    if (!(v <= best) && !is_nan(best)) { best = v; bi = c; }
+}
+
+template <int LDT>
+__device__ __forceinline__ void hist_add(uint32_t* hist, const void* label, int64_t li, int pred,
+                                         int C, int ignore_index, int wrap, int64_t* oob)
+{
+    int64_t t = awseg_ld_label<LDT>(label, li);
+    if (t == ignore_index) return;
+    int64_t base = wrap ? (int64_t)(uint8_t)(t * C) : t * (int64_t)C;
+    int64_t idx = base + pred;
+    if (idx < 0 || idx >= (int64_t)C * C || pred < 0 || pred >= C) {
+        atomicAdd((unsigned long long*)oob, 1ull);
+        return;
+    }
+    atomicAdd(&hist[idx], 1u);
+}
+
+template <int PDT> __device__ __forceinline__ void st_pred(void* pred, int64_t i, int v)
+{
+    if (PDT == AWSEG_U8) ((uint8_t*)pred)[i] = (uint8_t)v;
+    else ((int64_t*)pred)[i] = (int64_t)v;
+}
+
+// ---------------------------------------------------------------------------------------
+// Fused kernel.  MODE: 0 weighted, 1 max-confidence, 2 mean, 3 single model (seg2 unused).
+// VEC: pixels per lane per step (4 -> float4 path, 1 -> scalar fallback for odd shapes).
+// grid = (blocks_per_image, B); block b of image y writes partial[(y*gridDim.x + b)][C*C].
+// ---------------------------------------------------------------------------------------
+template <int MODE, int VEC, int LDT, int PDT>
+__global__ __launch_bounds__(kThreads)
+void combine_argmax_confusion_kernel(const float* __restrict__ seg1, const float* __restrict__ seg2,
+                                     int C, int64_t hw,
+                                     const float* __restrict__ weights, const float* __restrict__ temperature,
+                                     float* __restrict__ out_logits, void* __restrict__ pred,
+                                     const void* __restrict__ label, int ignore_index, int wrap,
+                                     uint32_t* __restrict__ partial, int64_t* __restrict__ oob)
+{
+    __shared__ uint32_t hist[kMaxBins];
+    const int bins = C * C;
+    const bool do_hist = (label != nullptr);
+    if (do_hist) {
+        for (int i = threadIdx.x; i < bins; i += kThreads) hist[i] = 0u;
+        __syncthreads();
+    }
+    const int64_t img = blockIdx.y;
+    const float* a = seg1 + img * C * hw;
+    const float* d = (MODE == 3) ? nullptr : seg2 + img * C * hw;
+    float* o = out_logits ? out_logits + img * C * hw : nullptr;
+
+    float w0 = 0.f, w1 = 0.f, T = 1.f;
+    const bool has_t = (temperature != nullptr);
+    if (MODE == 0) { w0 = weights[0]; w1 = weights[1]; }
+    if (has_t) T = temperature[0];
+
+    const int64_t nvec = hw / VEC;
+    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = v * VEC;
+        float best[VEC];
+        int bi[VEC];
+        float use[VEC];
+        if (MODE == 1) {
+            // max softmax probability of each member = 1 / sum(exp(x - max)); compare (model.py:449-453)
+            float m1[VEC], m2[VEC], s1[VEC], s2[VEC];
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) { m1[k] = -INFINITY; m2[k] = -INFINITY; s1[k] = 0.f; s2[k] = 0.f; }
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    m1[k] = fmaxf(m1[k], a[(int64_t)c * hw + p + k]);
+                    m2[k] = fmaxf(m2[k], d[(int64_t)c * hw + p + k]);
+                }
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) {
+                    s1[k] += expf(a[(int64_t)c * hw + p + k] - m1[k]);
+                    s2[k] += expf(d[(int64_t)c * hw + p + k] - m2[k]);
+                }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) use[k] = (1.0f / s1[k] > 1.0f / s2[k]) ? 1.f : 0.f;
+        }
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            float x[VEC], y[VEC], r[VEC];
+            if constexpr (VEC == 4) {
+                float4 xv = *reinterpret_cast<const float4*>(a + (int64_t)c * hw + p);
+                x[0] = xv.x; x[1] = xv.y; x[2] = xv.z; x[3] = xv.w;
+                if (MODE != 3) {
+                    float4 yv = *reinterpret_cast<const float4*>(d + (int64_t)c * hw + p);
+                    y[0] = yv.x; y[1] = yv.y; y[2] = yv.z; y[3] = yv.w;
+                }
+            } else {
+                x[0] = a[(int64_t)c * hw + p];
+                if (MODE != 3) y[0] = d[(int64_t)c * hw + p];
+            }
+#pragma unroll
+            for (int k = 0; k < VEC; ++k) {
+                // four separately rounded float32 operations (built with -ffp-contract=off)
+                if (MODE == 0) { float u = w0 * x[k]; float t = w1 * y[k]; r[k] = u + t; }
+                else if (MODE == 1) { float u = use[k] * x[k]; float t = (1.f - use[k]) * y[k]; r[k] = u + t; }
+                else if (MODE == 2) { float u = x[k] + y[k]; r[k] = u / 2.f; }
+                else r[k] = x[k];
+                if (MODE != 3 && has_t) r[k] = r[k] / T;
+                if (c == 0) { best[k] = r[k]; bi[k] = 0; }
+                else amax_step(r[k], c, best[k], bi[k]);
+            }
+            if (o) {
+                if constexpr (VEC == 4) *reinterpret_cast<float4*>(o + (int64_t)c * hw + p) = make_float4(r[0], r[1], r[2], r[3]);
+                else o[(int64_t)c * hw + p] = r[0];
+            }
+        }
+        if (pred) {
+            if constexpr (VEC == 4 && PDT == AWSEG_U8) {
+                uint32_t pk = (uint32_t)bi[0] | ((uint32_t)bi[1] << 8) | ((uint32_t)bi[2] << 16) | ((uint32_t)bi[3] << 24);
+                *reinterpret_cast<uint32_t*>((uint8_t*)pred + img * hw + p) = pk;
+            } else {
+#pragma unroll
+                for (int k = 0; k < VEC; ++k) st_pred<PDT>(pred, img * hw + p + k, bi[k]);
+            }
+        }
+        if (do_hist) {
+#pragma unroll
+            for (int k = 0; k < VEC; ++k)
+                hist_add<LDT>(hist, label, img * hw + p + k, bi[k], C, ignore_index, wrap, oob);
+        }
+    }
+    if (do_hist) {
+        __syncthreads();
+        uint32_t* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * bins;
+        for (int i = threadIdx.x; i < bins; i += kThreads) dst[i] = hist[i];
+    }
+}
+
+// One block per image: fold that image's block partials into slot 0 and slot 1+cond[img].
+__global__ __launch_bounds__(kThreads)
+void fold_partials_kernel(const uint32_t* __restrict__ partial, int blocks_per_image, int bins,
+                          const int32_t* __restrict__ cond, int n_slots, int64_t* __restrict__ counts)
+{
+    const int img = blockIdx.x;
+    const uint32_t* src = partial + (int64_t)img * blocks_per_image * bins;
+    int slot = -1;
+    if (cond) { int c = cond[img]; if (c >= 0 && c + 1 < n_slots) slot = c + 1; }
+    for (int k = threadIdx.x; k < bins; k += kThreads) {
+        unsigned long long s = 0;
+        for (int b = 0; b < blocks_per_image; ++b) s += src[(int64_t)b * bins + k];
+        if (s) {
+            atomicAdd((unsigned long long*)&counts[k], s);
+            if (slot > 0) atomicAdd((unsigned long long*)&counts[(int64_t)slot * bins + k], s);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// confusion from predictions (2 B/px at u8/u8): 16 pixels per lane, runs of equal index are
+// merged in registers before touching LDS (segmentation maps are piecewise constant, so the
+// common case is one ds_add per 16 pixels; random maps degrade to one per pixel).
+// ---------------------------------------------------------------------------------------
+template <int PDT, int LDT>
+__global__ __launch_bounds__(kThreads)
+void confusion_kernel(const void* __restrict__ pred, const void* __restrict__ label, int64_t n, int C,
+                      int ignore_index, int wrap, uint32_t* __restrict__ partial, int64_t* __restrict__ oob)
+{
+    __shared__ uint32_t hist[kMaxBins];
+    const int bins = C * C;
+    for (int i = threadIdx.x; i < bins; i += kThreads) hist[i] = 0u;
+    __syncthreads();
+    constexpr int PER = 16;
+    const int64_t nchunk = (n + PER - 1) / PER;
+    for (int64_t ch = (int64_t)blockIdx.x * kThreads + threadIdx.x; ch < nchunk; ch += (int64_t)gridDim.x * kThreads) {
+        const int64_t base = ch * PER;
+        int64_t pv[PER], lv[PER];
+        if (base + PER <= n) {
+            if (PDT == AWSEG_U8) {
+                uint4 q = *reinterpret_cast<const uint4*>((const uint8_t*)pred + base);
+                uint32_t w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+                for (int k = 0; k < PER; ++k) pv[k] = (w[k >> 2] >> ((k & 3) * 8)) & 0xFF;
+            } else {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) pv[k] = ((const int64_t*)pred)[base + k];
+            }
+            if (LDT == AWSEG_U8) {
+                uint4 q = *reinterpret_cast<const uint4*>((const uint8_t*)label + base);
+                uint32_t w[4] = { q.x, q.y, q.z, q.w };
+#pragma unroll
+                for (int k = 0; k < PER; ++k) lv[k] = (w[k >> 2] >> ((k & 3) * 8)) & 0xFF;
+            } else {
+#pragma unroll
+                for (int k = 0; k < PER; ++k) lv[k] = ((const int64_t*)label)[base + k];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < PER; ++k) {
+                bool in = base + k < n;
+                pv[k] = in ? (PDT == AWSEG_U8 ? (int64_t)((const uint8_t*)pred)[base + k] : ((const int64_t*)pred)[base + k]) : 0;
+                lv[k] = in ? awseg_ld_label<LDT>(label, base + k) : (int64_t)ignore_index;
+            }
+        }
+        int64_t run_idx = -1; uint32_t run = 0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            if (lv[k] == ignore_index) continue;
+            int64_t b = wrap ? (int64_t)(uint8_t)(lv[k] * C) : lv[k] * (int64_t)C;
+            int64_t idx = b + pv[k];
+            if (idx < 0 || idx >= bins || pv[k] < 0 || pv[k] >= C) { atomicAdd((unsigned long long*)oob, 1ull); continue; }
+            if (idx == run_idx) { ++run; }
+            else { if (run) atomicAdd(&hist[run_idx], run); run_idx = idx; run = 1; }
+        }
+        if (run) atomicAdd(&hist[run_idx], run);
+    }
+    __syncthreads();
+    uint32_t* dst = partial + (int64_t)blockIdx.x * bins;
+    for (int i = threadIdx.x; i < bins; i += kThreads) dst[i] = hist[i];
+}
+
+// ---------------------------------------------------------------------------------------
+// ECE accumulators: per block LDS bins {count u32, correct u32, sum_conf f32-in-f64 partial}.
+// Block partials: [nblk][n_bins] x {uint32 cnt, uint32 correct, double sum_conf}.
+// ---------------------------------------------------------------------------------------
+struct ece_cell { uint32_t cnt; uint32_t correct; double sum_conf; };
+
+template <int LDT>
+__global__ __launch_bounds__(kThreads)
+void ece_kernel(const float* __restrict__ logits, int C, int64_t hw, const void* __restrict__ label,
+                const float* __restrict__ edges, int n_bins, ece_cell* __restrict__ partial)
+{
+    __shared__ uint32_t s_cnt[64], s_cor[64];
+    __shared__ double s_sum[64];
+    __shared__ float s_edges[65];
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0.0; }
+    for (int i = threadIdx.x; i <= n_bins; i += kThreads) s_edges[i] = edges[i];
+    __syncthreads();
+    const int64_t img = blockIdx.y;
+    const float* x = logits + img * C * hw;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < hw; p += (int64_t)gridDim.x * kThreads) {
+        int64_t t = awseg_ld_label<LDT>(label, img * hw + p);
+        if (t == 255) continue;                       // metrics.py:170 hard-codes 255
+        float m = x[p]; int bi = 0;
+        for (int c = 1; c < C; ++c) { float v = x[(int64_t)c * hw + p]; if (v > m) { m = v; bi = c; } }
+        float s = 0.f;
+        for (int c = 0; c < C; ++c) s += expf(x[(int64_t)c * hw + p] - m);
+        float conf = 1.0f / s;
+        // bins are (lo, hi] on a float32 linspace (metrics.py:179-188); linear scan keeps the
+        // reference's comparison semantics exactly.
+        for (int k = 0; k < n_bins; ++k)
+            if (conf > s_edges[k] && conf <= s_edges[k + 1]) {
+                atomicAdd(&s_cnt[k], 1u);
+                if (bi == t) atomicAdd(&s_cor[k], 1u);
+                atomicAdd(&s_sum[k], (double)conf);
+                break;
+            }
+    }
+    __syncthreads();
+    ece_cell* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_bins;
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = s_sum[i]; }
+}
+
+// bins out: per slot, n_bins x {int64 count, double sum_conf, int64 sum_correct}
+struct ece_out { long long cnt; double sum_conf; long long correct; };
+
+__global__ void ece_fold_kernel(const ece_cell* __restrict__ partial, int blocks_per_image, int n_bins,
+                                const int32_t* __restrict__ cond, int n_slots, ece_out* __restrict__ bins)
+{
+    const int img = blockIdx.x;
+    const int k = threadIdx.x;
+    if (k >= n_bins) return;
+    const ece_cell* src = partial + (int64_t)img * blocks_per_image * n_bins;
+    unsigned long long cnt = 0, cor = 0; double sum = 0.0;
+    for (int b = 0; b < blocks_per_image; ++b) { cnt += src[b * n_bins + k].cnt; cor += src[b * n_bins + k].correct; sum += src[b * n_bins + k].sum_conf; }
+    int slot = -1;
+    if (cond) { int c = cond[img]; if (c >= 0 && c + 1 < n_slots) slot = c + 1; }
+    if (cnt) {
+        atomicAdd((unsigned long long*)&bins[k].cnt, cnt);
+        atomicAdd((unsigned long long*)&bins[k].correct, cor);
+        atomicAdd(&bins[k].sum_conf, sum);
+        if (slot > 0) {
+            ece_out* b = bins + (int64_t)slot * n_bins;
+            atomicAdd((unsigned long long*)&b[k].cnt, cnt);
+            atomicAdd((unsigned long long*)&b[k].correct, cor);
+            atomicAdd(&b[k].sum_conf, sum);
+        }
+    }
+}
+
+int blocks_per_image(int64_t hw, int64_t batch, int vec)
+{
+    // enough blocks to fill 256 CUs x 8 resident blocks across the whole batch, grid-stride beyond
+    int64_t want = (hw / vec + kThreads - 1) / kThreads;
+    int64_t cap = (AWSEG_CUS * 8 + batch - 1) / batch;
+    if (cap < 1) cap = 1;
+    if (want > cap) want = cap;
+    if (want < 1) want = 1;
+    return (int)want;
+}
+
+template <int MODE, int VEC>
+int launch_fused(const float* seg1, const float* seg2, int64_t batch, int C, int64_t hw,
+                 const float* weights, const float* temperature, float* out_logits, void* pred, int pdt,
+                 const void* label, int ldt, int ignore_index, int wrap, uint32_t* partial, int64_t* oob,
+                 int bpi, hipStream_t s)
+{
+    dim3 grid(bpi, (unsigned)batch), block(kThreads);
+#define AWSEG_FUSED(L, P) \
+    hipLaunchKernelGGL((combine_argmax_confusion_kernel<MODE, VEC, L, P>), grid, block, 0, s, seg1, seg2, C, hw, \
+                       weights, temperature, out_logits, pred, label, ignore_index, wrap, partial, oob)
+    if (ldt == AWSEG_U8 && pdt == AWSEG_U8) AWSEG_FUSED(AWSEG_U8, AWSEG_U8);
+    else if (ldt == AWSEG_U8) AWSEG_FUSED(AWSEG_U8, AWSEG_I64);
+    else if (pdt == AWSEG_U8) AWSEG_FUSED(AWSEG_I64, AWSEG_U8);
+    else AWSEG_FUSED(AWSEG_I64, AWSEG_I64);
+#undef AWSEG_FUSED
+    return 0;
+}
+
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+AWSEG_API int64_t awseg_metrics_workspace(int64_t batch, int num_classes, int64_t hw)
+{
+    // uint32 partials: one C*C histogram per block; also covers the ECE partials (24 B x 64 bins)
+    int64_t bpi = blocks_per_image(hw, batch < 1 ? 1 : batch, 1);
+    int64_t per_block = (int64_t)num_classes * num_classes * 4;
+    if (per_block < 64 * 24) per_block = 64 * 24;
+    return bpi * (batch < 1 ? 1 : batch) * per_block;
+}
+
+static int fused_impl(int mode, const float* seg1, const float* seg2, int64_t batch, int C, int64_t hw,
+                      const float* weights, const float* temperature, float* out_logits, void* pred, int pdt,
+                      const void* label, int ldt, int ignore_index, int wrap, const int32_t* cond,
+                      int64_t* counts, int n_slots, int64_t* oob, void* workspace, hipStream_t s)
+{
+    if (!seg1 || batch < 1 || hw < 1 || C < 1 || C > AWSEG_MAX_CLASSES) return AWSEG_EINVAL;
+    if (mode != 3 && !seg2) return AWSEG_EINVAL;
+    if (mode == 0 && !weights) return AWSEG_EINVAL;
+    if (batch > 65535) return AWSEG_ERANGE;
+    if ((pdt != AWSEG_U8 && pdt != AWSEG_I64) || (ldt != AWSEG_U8 && ldt != AWSEG_I64)) return AWSEG_EINVAL;
+    if (label && (!counts || !oob || !workspace || n_slots < 1)) return AWSEG_EINVAL;
+    const bool vec4 = (hw % 4 == 0) && aligned16(seg1) && (mode == 3 || aligned16(seg2)) &&
+                      (!out_logits || aligned16(out_logits)) && (!pred || pdt != AWSEG_U8 || ((uintptr_t)pred & 3) == 0);
+    const int bpi = blocks_per_image(hw, batch, 1);   // same count the workspace query assumed
+    uint32_t* partial = (uint32_t*)workspace;
+#define AWSEG_MODE(M)                                                                                           \
+    (vec4 ? launch_fused<M, 4>(seg1, seg2, batch, C, hw, weights, temperature, out_logits, pred, pdt, label,    \
+                               ldt, ignore_index, wrap, partial, oob, bpi, s)                                   \
+          : launch_fused<M, 1>(seg1, seg2, batch, C, hw, weights, temperature, out_logits, pred, pdt, label,    \
+                               ldt, ignore_index, wrap, partial, oob, bpi, s))
+    switch (mode) {
+        case 0: AWSEG_MODE(0); break;
+        case 1: AWSEG_MODE(1); break;
+        case 2: AWSEG_MODE(2); break;
+        case 3: AWSEG_MODE(3); break;
+        default: return AWSEG_EINVAL;
+    }
+#undef AWSEG_MODE
+    AWSEG_LAUNCH_CHECK();
+    if (label) {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)batch), dim3(kThreads), 0, s, partial, bpi, C * C, cond,
+                           n_slots, counts);
+        AWSEG_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+AWSEG_API int awseg_combine_argmax_confusion(const float* seg1, const float* seg2, int64_t batch, int num_classes,
+                                             int64_t hw, int mode, const float* weights, const float* temperature,
+                                             float* out_logits, void* pred, int pred_dtype, const void* label,
+                                             int label_dtype, int ignore_index, int label_wrap_u8,
+                                             const int32_t* cond, int64_t* counts, int n_slots, int64_t* oob,
+                                             void* workspace, awseg_stream_t stream)
+{
+    if (mode < 0 || mode > 2) return AWSEG_EINVAL;
+    return fused_impl(mode, seg1, seg2, batch, num_classes, hw, weights, temperature, out_logits, pred, pred_dtype,
+                      label, label_dtype, ignore_index, label_wrap_u8, cond, counts, n_slots, oob, workspace,
+                      awseg_s(stream));
+}
+
+AWSEG_API int awseg_argmax_confusion(const float* logits, int64_t batch, int num_classes, int64_t hw, void* pred,
+                                     int pred_dtype, const void* label, int label_dtype, int ignore_index,
+                                     int label_wrap_u8, const int32_t* cond, int64_t* counts, int n_slots,
+                                     int64_t* oob, void* workspace, awseg_stream_t stream)
+{
+    return fused_impl(3, logits, nullptr, batch, num_classes, hw, nullptr, nullptr, nullptr, pred, pred_dtype, label,
+                      label_dtype, ignore_index, label_wrap_u8, cond, counts, n_slots, oob, workspace, awseg_s(stream));
+}
+
+AWSEG_API int awseg_argmax(const float* logits, int64_t batch, int num_classes, int64_t hw, void* pred, int pred_dtype,
+                           awseg_stream_t stream)
+{
+    if (!pred) return AWSEG_EINVAL;
+    return fused_impl(3, logits, nullptr, batch, num_classes, hw, nullptr, nullptr, nullptr, pred, pred_dtype, nullptr,
+                      AWSEG_U8, 255, 0, nullptr, nullptr, 0, nullptr, nullptr, awseg_s(stream));
+}
+
+AWSEG_API int awseg_confusion_accumulate(const void* pred, int pred_dtype, const void* label, int label_dtype,
+                                         int64_t n, int num_classes, int ignore_index, int label_wrap_u8,
+                                         int64_t* counts, int64_t* oob, void* workspace, awseg_stream_t stream)
+{
+    if (!pred || !label || !counts || !oob || !workspace || n < 0) return AWSEG_EINVAL;
+    if (num_classes < 1 || num_classes > AWSEG_MAX_CLASSES) return AWSEG_EINVAL;
+    if (n == 0) return 0;
+    hipStream_t s = awseg_s(stream);
+    // same block count as the workspace query: blocks_per_image(n, 1, 1)
+    const int nblk = blocks_per_image(n, 1, 1);
+    uint32_t* partial = (uint32_t*)workspace;
+    const bool al = aligned16(pred) && aligned16(label);
+    (void)al;  // unaligned byte maps still work: the uint4 path requires 16-B alignment
+    if ((pred_dtype == AWSEG_U8 && !aligned16(pred)) || (label_dtype == AWSEG_U8 && !aligned16(label))) return AWSEG_EALIGN;
+    dim3 grid(nblk), block(kThreads);
+#define AWSEG_CONF(P, L) \
+    hipLaunchKernelGGL((confusion_kernel<P, L>), grid, block, 0, s, pred, label, n, num_classes, ignore_index, label_wrap_u8, partial, oob)
+    if (pred_dtype == AWSEG_U8 && label_dtype == AWSEG_U8) AWSEG_CONF(AWSEG_U8, AWSEG_U8);
+    else if (pred_dtype == AWSEG_U8 && label_dtype == AWSEG_I64) AWSEG_CONF(AWSEG_U8, AWSEG_I64);
+    else if (pred_dtype == AWSEG_I64 && label_dtype == AWSEG_U8) AWSEG_CONF(AWSEG_I64, AWSEG_U8);
+    else if (pred_dtype == AWSEG_I64 && label_dtype == AWSEG_I64) AWSEG_CONF(AWSEG_I64, AWSEG_I64);
+    else return AWSEG_EINVAL;
+#undef AWSEG_CONF
+    AWSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(kThreads), 0, s, partial, nblk, num_classes * num_classes,
+                       (const int32_t*)nullptr, 1, counts);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_ece_accumulate(const float* logits, int64_t batch, int num_classes, int64_t hw, const void* label,
+                                   int label_dtype, const int32_t* cond, const float* edges, int n_bins, void* bins,
+                                   int n_slots, void* workspace, awseg_stream_t stream)
+{
+    if (!logits || !label || !edges || !bins || !workspace) return AWSEG_EINVAL;
+    if (n_bins < 1 || n_bins > 64 || n_slots < 1 || batch < 1 || batch > 65535 || hw < 1) return AWSEG_EINVAL;
+    if (num_classes < 1 || num_classes > AWSEG_MAX_CLASSES) return AWSEG_EINVAL;
+    hipStream_t s = awseg_s(stream);
+    const int bpi = blocks_per_image(hw, batch, 1);
+    dim3 grid(bpi, (unsigned)batch), block(kThreads);
+    if (label_dtype == AWSEG_U8)
+        hipLaunchKernelGGL((ece_kernel<AWSEG_U8>), grid, block, 0, s, logits, num_classes, hw, label, edges, n_bins, (ece_cell*)workspace);
+    else if (label_dtype == AWSEG_I64)
+        hipLaunchKernelGGL((ece_kernel<AWSEG_I64>), grid, block, 0, s, logits, num_classes, hw, label, edges, n_bins, (ece_cell*)workspace);
+    else return AWSEG_EINVAL;
+    AWSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ece_fold_kernel, dim3((unsigned)batch), dim3(64), 0, s, (const ece_cell*)workspace, bpi, n_bins, cond,
+                       n_slots, (ece_out*)bins);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

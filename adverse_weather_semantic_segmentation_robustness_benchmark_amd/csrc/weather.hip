@@ -1,0 +1,756 @@
+// weather.hip — A1-A7 kernels: synthetic weather corruption of uint8 HWC frames.
+//
+// Reference arithmetic (PKG/data/preprocessing.py): fog :113-123 + depth :235-246,
+// night :209-225, rain :131-168, snow :176-202; normalise PKG/data/loader.py:195-198.
+//
+// Every kernel is batched: `imgs` is the whole [B,H,W,3] uint8 batch, a device array of
+// per-image jobs says which frames get this effect and with which parameters, and
+// blockIdx.z walks the jobs — one launch covers every frame of a batch that drew the same
+// weather condition, so a launch moves tens of MB instead of one 6 MB frame.
+// All arithmetic follows the reference's dtype ladder exactly (float32 where numpy stays in
+// float32, float64 where numpy promotes) and the file is built with -ffp-contract=off.
+#include "awseg_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+struct norm_consts { float mean[3]; float std[3]; };
+
+__device__ __forceinline__ uint8_t quant_f64(double v)
+{
+    // (np.clip(v,0,1)*255).astype(np.uint8)
+    double c = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+    return (uint8_t)(int)(c * 255.0);
+}
+__device__ __forceinline__ uint8_t quant_f32(float v)
+{
+    float c = v < 0.f ? 0.f : (v > 1.f ? 1.f : v);
+    return (uint8_t)(int)(c * 255.0f);
+}
+__device__ __forceinline__ float norm1(uint8_t q, float mean, float std)
+{
+    float v = (float)q / 255.0f;
+    float d = v - mean;
+    return d / std;
+}
+
+// scipy 'reflect' (d c b a | a b c d | d c b a)
+__device__ __forceinline__ int reflect_sym(int i, int n)
+{
+    if (n == 1) return 0;
+    int period = 2 * n;
+    i %= period; if (i < 0) i += period;
+    return i < n ? i : period - 1 - i;
+}
+// OpenCV BORDER_REFLECT_101 (gfedcb|abcdefgh|gfedcba)
+__device__ __forceinline__ int reflect_101(int i, int n)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) { if (i < 0) i = -i; else i = 2 * n - 2 - i; }
+    return i;
+}
+
+// ------------------------------------------------------------------------------------ A7
+// 4 pixels per lane: 12 B in (3 dwords), three float4 out (one per channel plane).
+__global__ __launch_bounds__(kThreads)
+void normalize_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const int32_t* __restrict__ sel,
+                      norm_consts nc, float* __restrict__ out)
+{
+    const int64_t img = sel ? sel[blockIdx.y] : blockIdx.y;
+    const uint8_t* src = imgs + img * hw * 3;
+    float* dst = out + img * hw * 3;
+    const int64_t nquad = hw / 4;
+    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(src + q * 12);
+        uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+        uint8_t b[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { b[k] = (w0 >> (8 * k)) & 0xFF; b[4 + k] = (w1 >> (8 * k)) & 0xFF; b[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float4 v = make_float4(norm1(b[c], nc.mean[c], nc.std[c]), norm1(b[3 + c], nc.mean[c], nc.std[c]),
+                                   norm1(b[6 + c], nc.mean[c], nc.std[c]), norm1(b[9 + c], nc.mean[c], nc.std[c]));
+            *reinterpret_cast<float4*>(dst + (int64_t)c * hw + q * 4) = v;
+        }
+    }
+    // tail pixels (hw % 4)
+    if (blockIdx.x == 0) {
+        for (int64_t p = nquad * 4 + threadIdx.x; p < hw; p += kThreads)
+            for (int c = 0; c < 3; ++c) dst[(int64_t)c * hw + p] = norm1(src[p * 3 + c], nc.mean[c], nc.std[c]);
+    }
+}
+
+// ------------------------------------------------------------------------- A2 + A3 (fog)
+// Tile TW x TH outputs; the 17-tap separable float64 Gaussian needs an 8-pixel halo, staged
+// in LDS.  Pass order and summation order are scipy's (axis 0 first; centre tap, then the
+// symmetric pairs from the outermost inwards), which is what makes depth bit-identical.
+constexpr int FR = AWSEG_GAUSS_RADIUS;       // 8
+constexpr int FTW = 64, FTH = 32;
+constexpr int FIW = FTW + 2 * FR;            // 80 staged columns
+constexpr int FIH = FTH + 2 * FR;            // 48 staged rows
+
+struct gauss_taps { double w[2 * FR + 1]; };
+
+template <bool PHILOX>
+__device__ __forceinline__ double fog_noise_at(const double* __restrict__ noise, uint64_t seed, int gy, int gx, int W)
+{
+    if (!PHILOX) return noise[(int64_t)gy * W + gx];
+    uint32_t r[4];
+    uint64_t e = (uint64_t)gy * (uint64_t)W + (uint64_t)gx;
+    awseg_philox::gen(seed, e, 0x0F06u, r);
+    float n0, n1;
+    awseg_box_muller(r[0], r[1], n0, n1);
+    return (double)n0 * 10.0;                 // N(0, 10), preprocessing.py:239
+}
+
+// MODE 0: depth only (writes depth_out); MODE 1: fused depth + fog.
+template <bool PHILOX, int MODE>
+__global__ __launch_bounds__(kThreads)
+void fog_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_fog_job* __restrict__ jobs,
+                const double* __restrict__ noise_all, gauss_taps taps,
+                uint8_t* __restrict__ out, float* __restrict__ norm_out, double* __restrict__ depth_out,
+                norm_consts nc)
+{
+    __shared__ double s_in[FIH * FIW];        // 30 KB
+    __shared__ double s_v[FTH * FIW];         // 20 KB
+    const awseg_fog_job job = jobs[blockIdx.z];
+    const int64_t hw = (int64_t)H * W;
+    const double* noise = PHILOX ? nullptr : noise_all + (int64_t)blockIdx.z * hw;
+    const int x0 = blockIdx.x * FTW, y0 = blockIdx.y * FTH;
+
+    // phase 1: depth_base + noise for the tile and its halo (scipy reflect at the image border)
+    for (int i = threadIdx.x; i < FIH * FIW; i += kThreads) {
+        int ty = i / FIW, tx = i - ty * FIW;
+        int gy = reflect_sym(y0 - FR + ty, H), gx = reflect_sym(x0 - FR + tx, W);
+        double base = ((double)gy / (double)H) * 100.0;           // preprocessing.py:236
+        s_in[i] = base + fog_noise_at<PHILOX>(noise, job.seed, gy, gx, W);
+    }
+    __syncthreads();
+    // phase 2: axis-0 pass for rows of the tile, all staged columns
+    for (int i = threadIdx.x; i < FTH * FIW; i += kThreads) {
+        int ty = i / FIW, tx = i - ty * FIW;
+        const double* c = s_in + (ty + FR) * FIW + tx;
+        double o = c[0] * taps.w[FR];
+#pragma unroll
+        for (int j = -FR; j < 0; ++j) { double s = c[j * FIW] + c[-j * FIW]; double m = s * taps.w[FR + j]; o = o + m; }
+        s_v[i] = o;
+    }
+    __syncthreads();
+    // phase 3: axis-1 pass, 4 horizontally adjacent outputs per lane (window of 20 LDS reads),
+    // then transmission / blend / quantise on the same 4 pixels (12 B in, 12 B out).
+    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
+    uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
+    float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
+    double* ddst = depth_out ? depth_out + (int64_t)blockIdx.z * hw : nullptr;
+    const double A32 = (double)(float)job.atmos;                   // A*ones_like(f32 image), :118
+    for (int q = threadIdx.x; q < FTH * (FTW / 4); q += kThreads) {
+        int ty = q / (FTW / 4), tq = q - ty * (FTW / 4);
+        int gy = y0 + ty, gx = x0 + tq * 4;
+        if (gy >= H || gx >= W) continue;
+        double win[4 + 2 * FR];
+        const double* row = s_v + ty * FIW + tq * 4;
+#pragma unroll
+        for (int k = 0; k < 4 + 2 * FR; ++k) win[k] = row[k];
+        double depth[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double o = win[k + FR] * taps.w[FR];
+#pragma unroll
+            for (int j = -FR; j < 0; ++j) { double s = win[k + FR + j] + win[k + FR - j]; double m = s * taps.w[FR + j]; o = o + m; }
+            depth[k] = o > 1.0 ? o : 1.0;                          // np.maximum(depth, 1.0), :246
+        }
+        const int nvalid = (W - gx) < 4 ? (W - gx) : 4;
+        const int64_t p = (int64_t)gy * W + gx;
+        if (ddst) for (int k = 0; k < nvalid; ++k) ddst[p + k] = depth[k];
+        if (MODE == 0) continue;
+        uint8_t px[12], res[12];
+        if (nvalid == 4 && ((p * 3) & 3) == 0) {
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
+            uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { px[k] = (w0 >> (8 * k)) & 0xFF; px[4 + k] = (w1 >> (8 * k)) & 0xFF; px[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+        } else {
+            for (int k = 0; k < nvalid * 3; ++k) px[k] = src[p * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            double t = exp(-job.beta * depth[k]);                  // :117
+            double omt = 1.0 - t;
+            double hazeterm = A32 * omt;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v = (float)px[k * 3 + c] / 255.0f;           // :81
+                double a = (double)v * t;
+                res[k * 3 + c] = quant_f64(a + hazeterm);          // :120-123
+            }
+        }
+        if (dst) {
+            if (nvalid == 4 && ((p * 3) & 3) == 0) {
+                uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    d4[w] = (uint32_t)res[4 * w] | ((uint32_t)res[4 * w + 1] << 8) | ((uint32_t)res[4 * w + 2] << 16) | ((uint32_t)res[4 * w + 3] << 24);
+            } else {
+                for (int k = 0; k < nvalid * 3; ++k) dst[p * 3 + k] = res[k];
+            }
+        }
+        if (ndst) {
+            for (int c = 0; c < 3; ++c)
+                for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = norm1(res[k * 3 + c], nc.mean[c], nc.std[c]);
+        }
+    }
+}
+
+// fog from a caller-provided depth map (the two-step form of the reference).
+__global__ __launch_bounds__(kThreads)
+void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_fog_job* __restrict__ jobs,
+                      const double* __restrict__ depth_all, uint8_t* __restrict__ out, float* __restrict__ norm_out,
+                      norm_consts nc)
+{
+    const awseg_fog_job job = jobs[blockIdx.y];
+    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
+    const double* depth = depth_all + (int64_t)blockIdx.y * hw;
+    uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
+    float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
+    const double A32 = (double)(float)job.atmos;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < hw; p += (int64_t)gridDim.x * kThreads) {
+        double t = exp(-job.beta * depth[p]);
+        double omt = 1.0 - t;
+        double hz = A32 * omt;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (float)src[p * 3 + c] / 255.0f;
+            double a = (double)v * t;
+            uint8_t q = quant_f64(a + hz);
+            if (dst) dst[p * 3 + c] = q;
+            if (ndst) ndst[(int64_t)c * hw + p] = norm1(q, nc.mean[c], nc.std[c]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------ A6 night
+template <bool PHILOX>
+__global__ __launch_bounds__(kThreads)
+void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_night_job* __restrict__ jobs,
+                  const double* __restrict__ noise_all, float g0, float g1, float g2,
+                  uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
+{
+    const awseg_night_job job = jobs[blockIdx.y];
+    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
+    const double* noise = PHILOX ? nullptr : noise_all + (int64_t)blockIdx.y * hw * 3;
+    uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
+    float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
+    const float bf = (float)job.brightness;                       // Python float x f32 array -> f32, :213
+    const float gains[3] = { g0, g1, g2 };
+    const double sigma = 5.0 / 255.0;                             // :222
+    const int64_t nquad = (hw + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = q * 4;
+        const int nvalid = (hw - p) < 4 ? (int)(hw - p) : 4;
+        uint8_t px[12], res[12];
+        if (nvalid == 4) {
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
+            uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { px[k] = (w0 >> (8 * k)) & 0xFF; px[4 + k] = (w1 >> (8 * k)) & 0xFF; px[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+        } else {
+            for (int k = 0; k < nvalid * 3; ++k) px[k] = src[p * 3 + k];
+        }
+        double nz[12];
+        if (PHILOX) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t r[4]; float a, b, c, d;
+                awseg_philox::gen(job.seed, (uint64_t)(p + k), 0x0A17u, r);
+                awseg_box_muller(r[0], r[1], a, b);
+                awseg_box_muller(r[2], r[3], c, d);
+                nz[k * 3] = (double)a * sigma; nz[k * 3 + 1] = (double)b * sigma; nz[k * 3 + 2] = (double)c * sigma;
+            }
+        } else if (nvalid == 4) {
+            const double2* n2 = reinterpret_cast<const double2*>(noise + p * 3);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { double2 t = n2[k]; nz[2 * k] = t.x; nz[2 * k + 1] = t.y; }
+        } else {
+            for (int k = 0; k < nvalid * 3; ++k) nz[k] = noise[p * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            float v = (float)px[k] / 255.0f;
+            v = v * bf;
+            v = v * gains[k % 3];                                  // :217-219
+            double n = nz[k] * job.intensity;
+            n = n * 0.5;                                           // :223
+            res[k] = quant_f64((double)v + n);
+        }
+        if (dst) {
+            if (nvalid == 4) {
+                uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    d4[w] = (uint32_t)res[4 * w] | ((uint32_t)res[4 * w + 1] << 8) | ((uint32_t)res[4 * w + 2] << 16) | ((uint32_t)res[4 * w + 3] << 24);
+            } else {
+                for (int k = 0; k < nvalid * 3; ++k) dst[p * 3 + k] = res[k];
+            }
+        }
+        if (ndst) {
+            if (nvalid == 4 && (hw & 3) == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
+                        make_float4(norm1(res[c], nc.mean[c], nc.std[c]), norm1(res[3 + c], nc.mean[c], nc.std[c]),
+                                    norm1(res[6 + c], nc.mean[c], nc.std[c]), norm1(res[9 + c], nc.mean[c], nc.std[c]));
+            } else {
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = norm1(res[k * 3 + c], nc.mean[c], nc.std[c]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- rasteriser (A4 / A5)
+// Integer restatement of OpenCV's drawing primitives (PARITY UNPINNED, see the oracle header).
+// Primitives are rasterised by one lane each into an LDS coverage mask that covers the
+// tile + blur halo, clipped to the image.
+struct tile_mask {
+    uint8_t* m; int x0, y0, w, h;   // rect origin / size in image coordinates
+    int W, H;                       // image size (OpenCV clips to the image first)
+};
+__device__ __forceinline__ void m_hline(const tile_mask& k, int y, int xa, int xb)
+{
+    if (y < 0 || y >= k.H) return;
+    if (xa < 0) xa = 0;
+    if (xb >= k.W) xb = k.W - 1;
+    int ry = y - k.y0;
+    if (ry < 0 || ry >= k.h) return;
+    int a = xa - k.x0, b = xb - k.x0;
+    if (a < 0) a = 0;
+    if (b >= k.w) b = k.w - 1;
+    for (int x = a; x <= b; ++x) k.m[ry * k.w + x] = 1;
+}
+__device__ __forceinline__ void m_point(const tile_mask& k, int x, int y)
+{
+    if (x < 0 || x >= k.W || y < 0 || y >= k.H) return;
+    int rx = x - k.x0, ry = y - k.y0;
+    if (rx < 0 || rx >= k.w || ry < 0 || ry >= k.h) return;
+    k.m[ry * k.w + rx] = 1;
+}
+__device__ void m_line_thin(const tile_mask& k, int x0, int y0, int x1, int y1)
+{
+    if (x1 < x0) { int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
+    int dx = x1 - x0, dy = y1 - y0, sy = dy < 0 ? -1 : 1;
+    if (dy < 0) dy = -dy;
+    if (dx >= dy) {
+        if (dx == 0) { m_point(k, x0, y0); return; }
+        for (int i = 0; i <= dx; ++i) m_point(k, x0 + i, y0 + sy * (int)((2LL * dy * i + dx - 1) / (2LL * dx)));
+    } else {
+        for (int i = 0; i <= dy; ++i) m_point(k, x0 + (int)((2LL * dx * i + dy - 1) / (2LL * dy)), y0 + sy * i);
+    }
+}
+__device__ void m_disc(const tile_mask& k, int cx, int cy, int r)
+{
+    int err = 0, dx = r, dy = 0, plus = 1, minus = (r << 1) - 1;
+    while (dx >= dy) {
+        m_hline(k, cy - dy, cx - dx, cx + dx);
+        m_hline(k, cy + dy, cx - dx, cx + dx);
+        m_hline(k, cy - dx, cx - dy, cx + dy);
+        m_hline(k, cy + dx, cx - dy, cx + dy);
+        dy++;
+        err += plus; plus += 2;
+        int mask = (err <= 0) - 1;
+        err -= minus & mask;
+        dx += mask;
+        minus -= mask & 2;
+    }
+}
+constexpr int XY_SHIFT = 16;
+constexpr int XY_ONE = 1 << XY_SHIFT;
+__device__ void m_line2(const tile_mask& k, int64_t x1, int64_t y1, int64_t x2, int64_t y2)
+{
+    int64_t dx = x2 - x1, dy = y2 - y1;
+    int64_t ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+    m_point(k, (int)((x2 + (XY_ONE >> 1)) >> XY_SHIFT), (int)((y2 + (XY_ONE >> 1)) >> XY_SHIFT));
+    if (ax > ay) {
+        if (dx < 0) { int64_t t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dy = -dy; }
+        int64_t y_step = (dy * XY_ONE) / (ax | 1);
+        int ecount = (int)((x2 - x1) >> XY_SHIFT);
+        x1 += XY_ONE >> 1; y1 += XY_ONE >> 1;
+        int64_t x = x1 >> XY_SHIFT;
+        while (ecount >= 0) { m_point(k, (int)x, (int)(y1 >> XY_SHIFT)); x++; y1 += y_step; ecount--; }
+    } else {
+        if (dy < 0) { int64_t t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dx = -dx; }
+        int64_t x_step = (dx * XY_ONE) / (ay | 1);
+        int ecount = (int)((y2 - y1) >> XY_SHIFT);
+        x1 += XY_ONE >> 1; y1 += XY_ONE >> 1;
+        int64_t y = y1 >> XY_SHIFT;
+        while (ecount >= 0) { m_point(k, (int)(x1 >> XY_SHIFT), (int)y); y++; x1 += x_step; ecount--; }
+    }
+}
+__device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int64_t* vy)
+{
+    const int npts = 4;
+    const int64_t delta = XY_ONE >> 1;
+    int e_idx[2], e_di[2], e_ye[2];
+    int64_t e_x[2], e_dx[2];
+    int imin = 0, edges = npts;
+    int64_t xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+    int64_t px = vx[npts - 1], py = vy[npts - 1];
+    for (int i = 0; i < npts; ++i) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        if (vy[i] > ymax) ymax = vy[i];
+        if (vx[i] > xmax) xmax = vx[i];
+        if (vx[i] < xmin) xmin = vx[i];
+        m_line2(k, px, py, vx[i], vy[i]);
+        px = vx[i]; py = vy[i];
+    }
+    xmin = (xmin + delta) >> XY_SHIFT; xmax = (xmax + delta) >> XY_SHIFT;
+    ymin = (ymin + delta) >> XY_SHIFT; ymax = (ymax + delta) >> XY_SHIFT;
+    if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= k.W || (int)ymin >= k.H) return;
+    if (ymax > k.H - 1) ymax = k.H - 1;
+    int y = (int)ymin;
+    e_idx[0] = e_idx[1] = imin; e_ye[0] = e_ye[1] = y;
+    e_di[0] = 1; e_di[1] = npts - 1;
+    e_x[0] = e_x[1] = -XY_ONE; e_dx[0] = e_dx[1] = 0;
+    do {
+        for (int i = 0; i < 2; ++i) {
+            if (y >= e_ye[i]) {
+                int idx0 = e_idx[i], di = e_di[i];
+                int idx = idx0 + di; if (idx >= npts) idx -= npts;
+                for (; edges-- > 0;) {
+                    int ty = (int)((vy[idx] + delta) >> XY_SHIFT);
+                    if (ty > y) {
+                        int64_t xs = vx[idx0], xe = vx[idx];
+                        e_ye[i] = ty;
+                        e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
+                        e_x[i] = xs;
+                        e_idx[i] = idx;
+                        break;
+                    }
+                    idx0 = idx; idx += di; if (idx >= npts) idx -= npts;
+                }
+            }
+        }
+        if (edges < 0) break;
+        if (y >= 0) {
+            int left = 0, right = 1;
+            if (e_x[0] > e_x[1]) { left = 1; right = 0; }
+            int xx1 = (int)((e_x[left] + (XY_ONE >> 1)) >> XY_SHIFT);
+            int xx2 = (int)((e_x[right] + (XY_ONE >> 1)) >> XY_SHIFT);
+            if (xx2 >= 0 && xx1 < k.W) m_hline(k, y, xx1, xx2);
+        }
+        e_x[0] += e_dx[0];
+        e_x[1] += e_dx[1];
+    } while (++y <= (int)ymax);
+}
+__device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1, int thickness)
+{
+    int64_t p0x = (int64_t)x0 << XY_SHIFT, p0y = (int64_t)y0 << XY_SHIFT;
+    int64_t p1x = (int64_t)x1 << XY_SHIFT, p1y = (int64_t)y1 << XY_SHIFT;
+    const double INV = 1.0 / XY_ONE;
+    double dx = (double)(p0x - p1x) * INV, dy = (double)(p1y - p0y) * INV;
+    double r = dx * dx + dy * dy;
+    int odd = thickness & 1;
+    int64_t th = (int64_t)thickness << (XY_SHIFT - 1);
+    if (fabs(r) > 2.220446049250313e-16) {
+        r = ((double)th + odd * XY_ONE * 0.5) / sqrt(r);
+        int64_t dpx = (int64_t)rint(dy * r), dpy = (int64_t)rint(dx * r);
+        int64_t vx[4] = { p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx };
+        int64_t vy[4] = { p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy };
+        m_fill_convex4(k, vx, vy);
+    }
+    int rad = (int)((th + (XY_ONE >> 1)) >> XY_SHIFT);
+    m_disc(k, x0, y0, rad);
+    m_disc(k, x1, y1, rad);
+}
+
+// ---------------------------------------------------------------------- A4 rain / A5 snow
+// Tile BTW x BTH, halo R (1 for 3x3, 3 for 7x7).  Stage the float32 pre-blur image (haze /
+// brightness applied, primitives painted) in LDS, then OpenCV's separable blur: row pass over
+// every staged row, column pass over the tile.  Symmetric form k[c]*s0 + sum k[c+j]*(s[-j]+s[j]).
+constexpr int BTW = 64, BTH = 16, BRMAX = 3;
+constexpr int BSW = BTW + 2 * BRMAX, BSH = BTH + 2 * BRMAX;
+
+struct blur_taps { float k[2 * BRMAX + 1]; int r; };
+
+template <bool SNOW>
+__global__ __launch_bounds__(kThreads)
+void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_prim_job* __restrict__ jobs,
+                   const int32_t* __restrict__ prims, blur_taps bt3, blur_taps bt7,
+                   uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
+{
+    __shared__ float s_src[BSH * BSW * 3];     // 22 x 70 x 3 floats = 18.5 KB
+    __shared__ float s_row[BSH * BTW * 3];     // 22 x 64 x 3 floats = 16.9 KB
+    __shared__ uint8_t s_mask[BSH * BSW];
+    const awseg_prim_job job = jobs[blockIdx.z];
+    const blur_taps bt = (SNOW && job.blur_ksize == 7) ? bt7 : bt3;
+    const int R = bt.r;
+    const int64_t hw = (int64_t)H * W;
+    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
+    const int x0 = blockIdx.x * BTW, y0 = blockIdx.y * BTH;
+    const int sw = BTW + 2 * R, sh = BTH + 2 * R;
+
+    // coverage mask over the part of tile+halo that lies inside the image
+    tile_mask mk;
+    mk.m = s_mask; mk.W = W; mk.H = H;
+    mk.x0 = x0 - R < 0 ? 0 : x0 - R;
+    mk.y0 = y0 - R < 0 ? 0 : y0 - R;
+    int xe = x0 + BTW + R > W ? W : x0 + BTW + R, ye = y0 + BTH + R > H ? H : y0 + BTH + R;
+    mk.w = xe - mk.x0; mk.h = ye - mk.y0;
+    for (int i = threadIdx.x; i < mk.w * mk.h; i += kThreads) s_mask[i] = 0;
+    __syncthreads();
+    const int32_t* pl = prims + (int64_t)job.prim_offset * (SNOW ? 3 : 5);
+    for (int i = threadIdx.x; i < job.prim_count; i += kThreads) {
+        if (SNOW) {
+            int cx = pl[i * 3], cy = pl[i * 3 + 1], r = pl[i * 3 + 2];
+            if (cx + r < mk.x0 || cx - r >= xe || cy + r < mk.y0 || cy - r >= ye) continue;
+            m_disc(mk, cx, cy, r);
+        } else {
+            int ax = pl[i * 5], ay = pl[i * 5 + 1], bx = pl[i * 5 + 2], by = pl[i * 5 + 3], th = pl[i * 5 + 4];
+            int mg = th <= 1 ? 0 : th + 2;
+            int lx = (ax < bx ? ax : bx) - mg, hx = (ax > bx ? ax : bx) + mg;
+            int ly = (ay < by ? ay : by) - mg, hy = (ay > by ? ay : by) + mg;
+            if (hx < mk.x0 || lx >= xe || hy < mk.y0 || ly >= ye) continue;
+            if (th <= 1) m_line_thin(mk, ax, ay, bx, by);
+            else m_line_thick(mk, ax, ay, bx, by, th);
+        }
+    }
+    __syncthreads();
+    // pre-blur image: haze (:134-135) or brightness boost + clip (:179-180), then paint
+    float pm, pa;
+    if (SNOW) { pm = 1.f; pa = (float)(job.intensity * 0.2); }
+    else { double haze = job.intensity * 0.3; pm = (float)(1.0 - haze); pa = (float)(haze * 0.7); }
+    const float col[3] = { SNOW ? 1.0f : 0.8f, SNOW ? 1.0f : 0.9f, 1.0f };
+    for (int i = threadIdx.x; i < sh * sw; i += kThreads) {
+        int ty = i / sw, tx = i - ty * sw;
+        int gy = reflect_101(y0 - R + ty, H), gx = reflect_101(x0 - R + tx, W);
+        bool inrect = (gy >= mk.y0 && gy < ye && gx >= mk.x0 && gx < xe);
+        bool cov = inrect && s_mask[(gy - mk.y0) * mk.w + (gx - mk.x0)];
+        const uint8_t* px = src + ((int64_t)gy * W + gx) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = (float)px[c] / 255.0f;
+            if (SNOW) { v = v + pa; v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+            else { v = v * pm; v = v + pa; }
+            s_src[(ty * BSW + tx) * 3 + c] = cov ? col[c] : v;
+        }
+    }
+    __syncthreads();
+    // row pass
+    for (int i = threadIdx.x; i < sh * BTW * 3; i += kThreads) {
+        int c = i % 3, t = i / 3;
+        int ty = t / BTW, tx = t - ty * BTW;
+        const float* s = s_src + (ty * BSW + tx + R) * 3 + c;
+        float acc = bt.k[R] * s[0];
+        for (int j = 1; j <= R; ++j) { float ab = s[-3 * j] + s[3 * j]; float m = bt.k[R + j] * ab; acc = acc + m; }
+        s_row[(ty * BTW + tx) * 3 + c] = acc;
+    }
+    __syncthreads();
+    // column pass + quantise
+    uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
+    float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
+    for (int i = threadIdx.x; i < BTH * BTW * 3; i += kThreads) {
+        int c = i % 3, t = i / 3;
+        int ty = t / BTW, tx = t - ty * BTW;
+        int gy = y0 + ty, gx = x0 + tx;
+        if (gy >= H || gx >= W) continue;
+        const float* s = s_row + ((ty + R) * BTW + tx) * 3 + c;
+        float acc = bt.k[R] * s[0];
+        for (int j = 1; j <= R; ++j) { float ab = s[-3 * BTW * j] + s[3 * BTW * j]; float m = bt.k[R + j] * ab; acc = acc + m; }
+        uint8_t q = quant_f32(acc);
+        int64_t p = (int64_t)gy * W + gx;
+        if (dst) dst[p * 3 + c] = q;
+        if (ndst) ndst[(int64_t)c * hw + p] = norm1(q, nc.mean[c], nc.std[c]);
+    }
+}
+
+// -------------------------------------------------------------------------------- A16
+__global__ __launch_bounds__(kThreads)
+void density_field_kernel(int64_t hw, uint64_t seed, const float* __restrict__ scale_off, float* __restrict__ density)
+{
+    const int64_t img = blockIdx.y;
+    const float sc = scale_off[img * 2], of = scale_off[img * 2 + 1];
+    float* dst = density + img * hw;
+    const int64_t nquad = (hw + 3) / 4;
+    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
+        uint32_t r[4];
+        awseg_philox::gen(seed, (uint64_t)(img * nquad + q), 0x0DE5u, r);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int64_t p = q * 4 + k;
+            if (p < hw) { float u = awseg_u01(r[k]); float v = u * sc; dst[p] = v + of; }   // torch.rand*a + b, trainer.py:503-509
+        }
+    }
+}
+
+norm_consts make_nc(const float* mean, const float* std)
+{
+    norm_consts nc;
+    for (int c = 0; c < 3; ++c) { nc.mean[c] = mean ? mean[c] : 0.f; nc.std[c] = std ? std[c] : 1.f; }
+    return nc;
+}
+
+// cv::getGaussianKernel(ksize, sigma > 0, CV_32F)
+blur_taps make_blur(int ksize, double sigma)
+{
+    blur_taps b; b.r = ksize / 2;
+    double t[2 * BRMAX + 1], sum = 0.0, s2 = -0.5 / (sigma * sigma);
+    for (int i = 0; i < ksize; ++i) { double x = i - (ksize - 1) * 0.5; t[i] = exp(s2 * x * x); sum += t[i]; }
+    sum = 1.0 / sum;
+    for (int i = 0; i < 2 * BRMAX + 1; ++i) b.k[i] = 0.f;
+    for (int i = 0; i < ksize; ++i) b.k[i] = (float)(t[i] * sum);
+    return b;
+}
+
+int grid_for(int64_t items, int64_t jobs)
+{
+    int64_t want = (items + kThreads - 1) / kThreads;
+    int64_t cap = (AWSEG_CUS * 8 + jobs - 1) / (jobs < 1 ? 1 : jobs);
+    if (want > cap) want = cap;
+    return (int)(want < 1 ? 1 : want);
+}
+
+}  // namespace
+
+AWSEG_API int awseg_normalize(const uint8_t* imgs, int64_t batch, int height, int width, const int32_t* sel, int n_sel,
+                              const float* mean_host, const float* std_host, float* out, awseg_stream_t stream)
+{
+    if (!imgs || !out || !mean_host || !std_host || height < 1 || width < 1 || batch < 1) return AWSEG_EINVAL;
+    const int64_t hw = (int64_t)height * width;
+    const int64_t n = sel ? n_sel : batch;
+    if (n < 1) return 0;
+    if (n > 65535) return AWSEG_ERANGE;
+    if (((uintptr_t)imgs & 3) || ((uintptr_t)out & 15) || ((hw * 3) & 3)) {
+        if ((hw & 3) != 0) return AWSEG_EALIGN;      // the 4-pixel path needs hw % 4 == 0 for per-image bases
+    }
+    if ((hw & 3) != 0) return AWSEG_EALIGN;
+    dim3 grid(grid_for(hw / 4, n), (unsigned)n);
+    hipLaunchKernelGGL(normalize_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, sel, make_nc(mean_host, std_host), out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int fog_common(int mode, const uint8_t* imgs, int H, int W, const awseg_fog_job* jobs, int n_jobs,
+                      const double* noise, const double* taps_host, uint8_t* out, float* norm_out, double* depth_out,
+                      const float* mean_host, const float* std_host, hipStream_t s)
+{
+    if (!jobs || !taps_host || H < 1 || W < 1 || n_jobs < 0) return AWSEG_EINVAL;
+    if (mode == 1 && !imgs) return AWSEG_EINVAL;
+    if (mode == 0 && !depth_out) return AWSEG_EINVAL;
+    if (n_jobs == 0) return 0;
+    if (n_jobs > 65535) return AWSEG_ERANGE;
+    gauss_taps t;
+    for (int i = 0; i < 2 * FR + 1; ++i) t.w[i] = taps_host[i];
+    dim3 grid((W + FTW - 1) / FTW, (H + FTH - 1) / FTH, n_jobs);
+    if (grid.y > 65535) return AWSEG_ERANGE;
+    norm_consts nc = make_nc(mean_host, std_host);
+#define AWSEG_FOG(P, M) hipLaunchKernelGGL((fog_kernel<P, M>), grid, dim3(kThreads), 0, s, imgs, H, W, jobs, noise, t, out, norm_out, depth_out, nc)
+    if (noise) { if (mode) AWSEG_FOG(false, 1); else AWSEG_FOG(false, 0); }
+    else { if (mode) AWSEG_FOG(true, 1); else AWSEG_FOG(true, 0); }
+#undef AWSEG_FOG
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_synthetic_depth(int height, int width, const awseg_fog_job* jobs, int n_jobs, const double* noise,
+                                    const double* taps_host, double* depth_out, awseg_stream_t stream)
+{
+    return fog_common(0, nullptr, height, width, jobs, n_jobs, noise, taps_host, nullptr, nullptr, depth_out, nullptr,
+                      nullptr, awseg_s(stream));
+}
+
+AWSEG_API int awseg_fog_fused(const uint8_t* imgs, int height, int width, const awseg_fog_job* jobs, int n_jobs,
+                              const double* noise, const double* taps_host, uint8_t* out, float* norm_out,
+                              double* depth_out, const float* mean_host, const float* std_host, awseg_stream_t stream)
+{
+    if (!out && !norm_out) return AWSEG_EINVAL;
+    if (norm_out && (!mean_host || !std_host)) return AWSEG_EINVAL;
+    return fog_common(1, imgs, height, width, jobs, n_jobs, noise, taps_host, out, norm_out, depth_out, mean_host,
+                      std_host, awseg_s(stream));
+}
+
+AWSEG_API int awseg_fog_apply(const uint8_t* imgs, int height, int width, const awseg_fog_job* jobs, int n_jobs,
+                              const double* depth, uint8_t* out, float* norm_out, const float* mean_host,
+                              const float* std_host, awseg_stream_t stream)
+{
+    if (!imgs || !jobs || !depth || (!out && !norm_out) || height < 1 || width < 1 || n_jobs < 0) return AWSEG_EINVAL;
+    if (norm_out && (!mean_host || !std_host)) return AWSEG_EINVAL;
+    if (n_jobs == 0) return 0;
+    if (n_jobs > 65535) return AWSEG_ERANGE;
+    const int64_t hw = (int64_t)height * width;
+    dim3 grid(grid_for(hw, n_jobs), n_jobs);
+    hipLaunchKernelGGL(fog_apply_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, jobs, depth, out, norm_out,
+                       make_nc(mean_host, std_host));
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_night_apply(const uint8_t* imgs, int height, int width, const awseg_night_job* jobs, int n_jobs,
+                                const double* noise, const float* gains_host, uint8_t* out, float* norm_out,
+                                const float* mean_host, const float* std_host, awseg_stream_t stream)
+{
+    if (!imgs || !jobs || !gains_host || (!out && !norm_out) || height < 1 || width < 1 || n_jobs < 0) return AWSEG_EINVAL;
+    if (norm_out && (!mean_host || !std_host)) return AWSEG_EINVAL;
+    if (n_jobs == 0) return 0;
+    if (n_jobs > 65535) return AWSEG_ERANGE;
+    const int64_t hw = (int64_t)height * width;
+    if ((hw * 3) & 3) return AWSEG_EALIGN;           // per-image bases must stay 4-byte aligned
+    if (((uintptr_t)imgs & 3) || (out && ((uintptr_t)out & 3)) || (noise && ((uintptr_t)noise & 15))) return AWSEG_EALIGN;
+    dim3 grid(grid_for((hw + 3) / 4, n_jobs), n_jobs);
+    norm_consts nc = make_nc(mean_host, std_host);
+    if (noise)
+        hipLaunchKernelGGL((night_kernel<false>), grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, jobs, noise,
+                           gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc);
+    else
+        hipLaunchKernelGGL((night_kernel<true>), grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, jobs, noise,
+                           gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+static int streak_common(bool snow, const uint8_t* imgs, int H, int W, const awseg_prim_job* jobs, int n_jobs,
+                         const int32_t* prims, uint8_t* out, float* norm_out, const float* mean_host,
+                         const float* std_host, hipStream_t s)
+{
+    if (!imgs || !jobs || (!out && !norm_out) || H < 1 || W < 1 || n_jobs < 0) return AWSEG_EINVAL;
+    if (norm_out && (!mean_host || !std_host)) return AWSEG_EINVAL;
+    if (n_jobs == 0) return 0;
+    if (n_jobs > 65535) return AWSEG_ERANGE;
+    if (out == imgs) return AWSEG_EINVAL;            // the blur reads neighbours: not in-place safe
+    dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, n_jobs);
+    if (grid.y > 65535) return AWSEG_ERANGE;
+    norm_consts nc = make_nc(mean_host, std_host);
+    if (snow) {
+        hipLaunchKernelGGL((streak_kernel<true>), grid, dim3(kThreads), 0, s, imgs, H, W, jobs, prims, make_blur(3, 1.0),
+                           make_blur(7, 1.0), out, norm_out, nc);
+    } else {
+        blur_taps b = make_blur(3, 0.5);
+        hipLaunchKernelGGL((streak_kernel<false>), grid, dim3(kThreads), 0, s, imgs, H, W, jobs, prims, b, b, out, norm_out, nc);
+    }
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_rain_apply(const uint8_t* imgs, int height, int width, const awseg_prim_job* jobs, int n_jobs,
+                               const int32_t* drops, uint8_t* out, float* norm_out, const float* mean_host,
+                               const float* std_host, awseg_stream_t stream)
+{
+    return streak_common(false, imgs, height, width, jobs, n_jobs, drops, out, norm_out, mean_host, std_host, awseg_s(stream));
+}
+
+AWSEG_API int awseg_snow_apply(const uint8_t* imgs, int height, int width, const awseg_prim_job* jobs, int n_jobs,
+                               const int32_t* flakes, uint8_t* out, float* norm_out, const float* mean_host,
+                               const float* std_host, awseg_stream_t stream)
+{
+    return streak_common(true, imgs, height, width, jobs, n_jobs, flakes, out, norm_out, mean_host, std_host, awseg_s(stream));
+}
+
+AWSEG_API int awseg_fog_density_field(const float* scale_offset, int batch, int64_t hw, uint64_t seed, float* density,
+                                      awseg_stream_t stream)
+{
+    if (!scale_offset || !density || batch < 1 || hw < 1) return AWSEG_EINVAL;
+    if (batch > 65535) return AWSEG_ERANGE;
+    dim3 grid(grid_for((hw + 3) / 4, batch), batch);
+    hipLaunchKernelGGL(density_field_kernel, grid, dim3(kThreads), 0, awseg_s(stream), hw, seed, scale_offset, density);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

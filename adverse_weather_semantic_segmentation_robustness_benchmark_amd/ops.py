@@ -1,0 +1,328 @@
+"""Functional host wrappers over the C ABI (``include/awseg.h``) for torch device tensors.
+
+Each function cites the reference function it replaces (PKG = the reference package
+``adverse_weather_semantic_segmentation_robustness_benchmark``).  All of them launch on the
+current torch stream, never synchronise, and raise if handed CPU tensors.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as N
+
+IMAGENET_MEAN = np.array([0.485, 0.456, 0.406], dtype=np.float32)   # PKG/data/loader.py:196
+IMAGENET_STD = np.array([0.229, 0.224, 0.225], dtype=np.float32)
+NIGHT_GAINS = np.array([0.8, 0.85, 1.2], dtype=np.float32)          # PKG/data/preprocessing.py:55
+CONDITIONS = ("clean", "fog", "rain", "snow", "night")               # PKG/evaluation/metrics.py:491
+
+
+def gaussian_taps(sigma: float = 2.0, truncate: float = 4.0) -> np.ndarray:
+    """The 17 float64 weights scipy.ndimage.gaussian_filter(sigma=2) uses
+    (PKG/data/preprocessing.py:243): same numpy expressions as scipy's _gaussian_kernel1d."""
+    radius = int(truncate * float(sigma) + 0.5)
+    x = np.arange(-radius, radius + 1)
+    phi = np.exp(-0.5 / (sigma * sigma) * x ** 2)
+    return phi / phi.sum()
+
+
+_TAPS = gaussian_taps()
+
+
+def _mean_std(mean, std):
+    m = np.ascontiguousarray(IMAGENET_MEAN if mean is None else mean, dtype=np.float32)
+    s = np.ascontiguousarray(IMAGENET_STD if std is None else std, dtype=np.float32)
+    return m, s
+
+
+# ----------------------------------------------------------------------------- metrics
+def new_counts(num_classes: int, device, n_slots: int = 1) -> torch.Tensor:
+    return torch.zeros(n_slots, num_classes * num_classes, dtype=torch.int64, device=device)
+
+
+def confusion_accumulate(pred: torch.Tensor, label: torch.Tensor, num_classes: int, counts: torch.Tensor,
+                         oob: torch.Tensor, ignore_index: int = 255, wrap_u8: Optional[bool] = None) -> None:
+    """PKG/evaluation/metrics.py:54-71.  `wrap_u8` defaults to the reference's behaviour: on
+    for uint8 label tensors (their `targets*C` wraps mod 256), off for int64."""
+    pred, label = pred.contiguous().view(-1), label.contiguous().view(-1)
+    if wrap_u8 is None:
+        wrap_u8 = label.dtype == torch.uint8
+    n = pred.numel()
+    ws = N.workspace.get(pred.device, N.lib().awseg_metrics_workspace(1, num_classes, n))
+    N.check(N.lib().awseg_confusion_accumulate(N.ptr(pred), N.label_dtype(pred), N.ptr(label), N.label_dtype(label), n,
+                                               num_classes, ignore_index, int(wrap_u8), N.ptr(counts), N.ptr(oob),
+                                               N.ptr(ws), N.stream()), "awseg_confusion_accumulate")
+
+
+def argmax(logits: torch.Tensor, out_dtype=torch.int64) -> torch.Tensor:
+    """logits.argmax(dim=1), REF/scripts/evaluate.py:179."""
+    logits = logits.contiguous()
+    b, c = logits.shape[0], logits.shape[1]
+    hw = logits[0, 0].numel()
+    pred = torch.empty((b,) + tuple(logits.shape[2:]), dtype=out_dtype, device=logits.device)
+    N.check(N.lib().awseg_argmax(N.ptr(logits), b, c, hw, N.ptr(pred), N.label_dtype(pred), N.stream()), "awseg_argmax")
+    return pred
+
+
+def combine_argmax_confusion(seg1: torch.Tensor, seg2: Optional[torch.Tensor], mode: int,
+                             weights: Optional[torch.Tensor] = None, temperature: Optional[torch.Tensor] = None,
+                             want_logits: bool = True, want_pred: bool = False, pred_dtype=torch.int64,
+                             label: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None,
+                             oob: Optional[torch.Tensor] = None, cond: Optional[torch.Tensor] = None,
+                             ignore_index: int = 255, wrap_u8: Optional[bool] = None):
+    """PKG/models/model.py:443-462 (+ argmax evaluate.py:179, + confusion metrics.py:54-71).
+    seg2 None -> single-model argmax(+confusion)."""
+    seg1 = seg1.contiguous()
+    b, c = seg1.shape[0], seg1.shape[1]
+    hw = seg1[0, 0].numel()
+    out = torch.empty_like(seg1) if (want_logits and seg2 is not None) else None
+    pred = torch.empty((b,) + tuple(seg1.shape[2:]), dtype=pred_dtype, device=seg1.device) if want_pred else None
+    ws = None
+    ldt = N.U8
+    if label is not None:
+        label = label.contiguous()
+        ldt = N.label_dtype(label)
+        if wrap_u8 is None:
+            wrap_u8 = label.dtype == torch.uint8
+        ws = N.workspace.get(seg1.device, N.lib().awseg_metrics_workspace(b, c, hw))
+    n_slots = 0 if counts is None else counts.shape[0]
+    pdt = N.label_dtype(pred) if pred is not None else N.U8
+    if seg2 is None:
+        rc = N.lib().awseg_argmax_confusion(N.ptr(seg1), b, c, hw, N.ptr(pred), pdt, N.ptr(label), ldt, ignore_index,
+                                            int(bool(wrap_u8)), N.ptr(cond), N.ptr(counts), n_slots, N.ptr(oob),
+                                            N.ptr(ws), N.stream())
+        N.check(rc, "awseg_argmax_confusion")
+        return seg1, pred
+    seg2 = seg2.contiguous()
+    rc = N.lib().awseg_combine_argmax_confusion(N.ptr(seg1), N.ptr(seg2), b, c, hw, mode, N.ptr(weights),
+                                                N.ptr(temperature), N.ptr(out), N.ptr(pred), pdt, N.ptr(label), ldt,
+                                                ignore_index, int(bool(wrap_u8)), N.ptr(cond), N.ptr(counts), n_slots,
+                                                N.ptr(oob), N.ptr(ws), N.stream())
+    N.check(rc, "awseg_combine_argmax_confusion")
+    return out, pred
+
+
+ECE_BIN_DTYPE = np.dtype([("count", "<i8"), ("sum_conf", "<f8"), ("sum_correct", "<i8")])
+
+
+def new_ece_bins(n_bins: int, device, n_slots: int = 1) -> torch.Tensor:
+    return torch.zeros(n_slots, n_bins, 3, dtype=torch.int64, device=device)   # 24 B / bin, raw
+
+
+def ece_accumulate(logits: torch.Tensor, label: torch.Tensor, bins: torch.Tensor, edges: torch.Tensor,
+                   cond: Optional[torch.Tensor] = None) -> None:
+    """PKG/evaluation/metrics.py:161-194, per-pixel part, accumulated on device."""
+    logits, label = logits.contiguous(), label.contiguous()
+    b, c = logits.shape[0], logits.shape[1]
+    hw = logits[0, 0].numel()
+    ws = N.workspace.get(logits.device, N.lib().awseg_metrics_workspace(b, c, hw))
+    N.check(N.lib().awseg_ece_accumulate(N.ptr(logits), b, c, hw, N.ptr(label), N.label_dtype(label), N.ptr(cond),
+                                         N.ptr(edges), bins.shape[1], N.ptr(bins), bins.shape[0], N.ptr(ws), N.stream()),
+            "awseg_ece_accumulate")
+
+
+def ece_bins_to_numpy(bins: torch.Tensor) -> np.ndarray:
+    return bins.cpu().numpy().view(np.uint8).reshape(bins.shape[0], bins.shape[1], 24).view(ECE_BIN_DTYPE)[..., 0]
+
+
+# ----------------------------------------------------------------------------- A7
+def normalize(imgs: torch.Tensor, out: Optional[torch.Tensor] = None, sel: Optional[torch.Tensor] = None,
+              mean=None, std=None) -> torch.Tensor:
+    """PKG/data/loader.py:195-198: uint8 [B,H,W,3] -> float32 [B,3,H,W]."""
+    imgs = imgs.contiguous()
+    b, h, w, _ = imgs.shape
+    if out is None:
+        out = torch.empty(b, 3, h, w, dtype=torch.float32, device=imgs.device)
+    m, s = _mean_std(mean, std)
+    N.check(N.lib().awseg_normalize(N.ptr(imgs), b, h, w, N.ptr(sel), 0 if sel is None else sel.numel(), N.host(m),
+                                    N.host(s), N.ptr(out), N.stream()), "awseg_normalize")
+    return out
+
+
+# ----------------------------------------------------------------------------- weather
+def _jobs(dtype, n):
+    return np.zeros(n, dtype=dtype)
+
+
+def fog_jobs(images: Sequence[int], intensities: Sequence[float], seeds: Optional[Sequence[int]] = None) -> np.ndarray:
+    """beta / A from intensity exactly as PKG/data/preprocessing.py:110-114 (Python float math)."""
+    j = _jobs(N.FOG_JOB, len(images))
+    for k, (im, inten) in enumerate(zip(images, intensities)):
+        inten = float(inten)
+        j[k]["image"] = im
+        j[k]["beta"] = 0.005 + inten * (0.05 - 0.005)
+        j[k]["atmos"] = 0.7 + inten * (1.0 - 0.7)
+        j[k]["seed"] = 0 if seeds is None else int(seeds[k]) & 0xFFFFFFFFFFFFFFFF
+    return j
+
+
+def night_jobs(images, brightness, intensities, seeds=None) -> np.ndarray:
+    j = _jobs(N.NIGHT_JOB, len(images))
+    for k in range(len(images)):
+        j[k]["image"] = images[k]
+        j[k]["brightness"] = float(brightness[k])
+        j[k]["intensity"] = float(intensities[k])
+        j[k]["seed"] = 0 if seeds is None else int(seeds[k]) & 0xFFFFFFFFFFFFFFFF
+    return j
+
+
+def prim_jobs(images, intensities, prim_lists, ksizes=None):
+    """-> (jobs, concatenated int32 primitive array)."""
+    j = _jobs(N.PRIM_JOB, len(images))
+    off = 0
+    for k in range(len(images)):
+        j[k]["image"] = images[k]
+        j[k]["prim_offset"] = off
+        j[k]["prim_count"] = len(prim_lists[k])
+        j[k]["blur_ksize"] = 3 if ksizes is None else int(ksizes[k])
+        j[k]["intensity"] = float(intensities[k])
+        off += len(prim_lists[k])
+    width = prim_lists[0].shape[1] if len(prim_lists) and prim_lists[0].ndim == 2 else 1
+    prims = np.concatenate([np.asarray(p, dtype=np.int32).reshape(-1, width) for p in prim_lists], axis=0) \
+        if len(prim_lists) else np.zeros((0, width), np.int32)
+    if prims.shape[0] == 0:
+        prims = np.zeros((1, max(width, 1)), np.int32)
+    return j, np.ascontiguousarray(prims)
+
+
+def synthetic_depth(h: int, w: int, jobs: np.ndarray, device, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """PKG/data/preprocessing.py:227-248 -> float64 [n_jobs,H,W]."""
+    jd = N.jobs_to_device(jobs, device)
+    out = torch.empty(len(jobs), h, w, dtype=torch.float64, device=device)
+    N.check(N.lib().awseg_synthetic_depth(h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out), N.stream()),
+            "awseg_synthetic_depth")
+    return out
+
+
+def fog(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = None, depth: Optional[torch.Tensor] = None,
+        out: Optional[torch.Tensor] = None, norm_out: Optional[torch.Tensor] = None, depth_out: Optional[torch.Tensor] = None,
+        mean=None, std=None) -> None:
+    """_apply_fog (PKG/data/preprocessing.py:94-123).  depth given -> two-step form; else fused
+    depth+fog with `noise` (parity mode) or in-kernel Philox (noise None)."""
+    imgs = imgs.contiguous()
+    _, h, w, _ = imgs.shape
+    jd = N.jobs_to_device(jobs, imgs.device)
+    m, s = _mean_std(mean, std)
+    if depth is not None:
+        N.check(N.lib().awseg_fog_apply(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(depth.contiguous()), N.ptr(out),
+                                        N.ptr(norm_out), N.host(m), N.host(s), N.stream()), "awseg_fog_apply")
+    else:
+        N.check(N.lib().awseg_fog_fused(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out),
+                                        N.ptr(norm_out), N.ptr(depth_out), N.host(m), N.host(s), N.stream()),
+                "awseg_fog_fused")
+
+
+def night(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = None, out=None, norm_out=None,
+          mean=None, std=None) -> None:
+    """_apply_night (PKG/data/preprocessing.py:204-225)."""
+    imgs = imgs.contiguous()
+    _, h, w, _ = imgs.shape
+    jd = N.jobs_to_device(jobs, imgs.device)
+    m, s = _mean_std(mean, std)
+    N.check(N.lib().awseg_night_apply(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(NIGHT_GAINS), N.ptr(out),
+                                      N.ptr(norm_out), N.host(m), N.host(s), N.stream()), "awseg_night_apply")
+
+
+def rain(imgs: torch.Tensor, jobs: np.ndarray, drops: np.ndarray, out=None, norm_out=None, mean=None, std=None) -> None:
+    """_apply_rain (PKG/data/preprocessing.py:125-168)."""
+    imgs = imgs.contiguous()
+    _, h, w, _ = imgs.shape
+    jd = N.jobs_to_device(jobs, imgs.device)
+    pd = torch.from_numpy(np.ascontiguousarray(drops, dtype=np.int32)).to(imgs.device, non_blocking=True)
+    m, s = _mean_std(mean, std)
+    N.check(N.lib().awseg_rain_apply(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
+                                     N.host(m), N.host(s), N.stream()), "awseg_rain_apply")
+
+
+def snow(imgs: torch.Tensor, jobs: np.ndarray, flakes: np.ndarray, out=None, norm_out=None, mean=None, std=None) -> None:
+    """_apply_snow (PKG/data/preprocessing.py:170-202)."""
+    imgs = imgs.contiguous()
+    _, h, w, _ = imgs.shape
+    jd = N.jobs_to_device(jobs, imgs.device)
+    pd = torch.from_numpy(np.ascontiguousarray(flakes, dtype=np.int32)).to(imgs.device, non_blocking=True)
+    m, s = _mean_std(mean, std)
+    N.check(N.lib().awseg_snow_apply(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
+                                     N.host(m), N.host(s), N.stream()), "awseg_snow_apply")
+
+
+_DENSITY_TABLE = {"fog": (0.5, 0.5), "rain": (0.3, 0.2), "snow": (0.3, 0.2)}   # trainer.py:501-509, else (0.1, 0)
+
+
+def fog_density_field(conditions: Sequence[str], h: int, w: int, device, seed: int) -> torch.Tensor:
+    """AdverseWeatherTrainer._estimate_fog_density (PKG/training/trainer.py:480-511) on device."""
+    so = np.array([_DENSITY_TABLE.get(str(c), (0.1, 0.0)) for c in conditions], dtype=np.float32)
+    sod = torch.from_numpy(so).to(device, non_blocking=True)
+    out = torch.empty(len(conditions), h, w, dtype=torch.float32, device=device)
+    N.check(N.lib().awseg_fog_density_field(N.ptr(sod), len(conditions), h * w, seed & 0xFFFFFFFFFFFFFFFF, N.ptr(out),
+                                            N.stream()), "awseg_fog_density_field")
+    return out
+
+
+# ----------------------------------------------------------------------------- loss
+def fog_ce_forward(logits: torch.Tensor, label: torch.Tensor, density: Optional[torch.Tensor], focal: bool,
+                   sensitivity: float, oob: torch.Tensor, want_pixel: bool = False):
+    """FogDensityAwareLoss seg term, PKG/models/model.py:577-587 + mean :610 -> float32[1]."""
+    logits, label = logits.contiguous(), label.contiguous()
+    b, c = logits.shape[0], logits.shape[1]
+    hw = logits[0, 0].numel()
+    n_part = N.lib().awseg_loss_partials(b, hw)
+    partials = N.workspace.get(logits.device, n_part * 8, "loss").view(torch.float64)
+    mean = torch.empty(1, dtype=torch.float32, device=logits.device)
+    pix = torch.empty((b,) + tuple(logits.shape[2:]), dtype=torch.float32, device=logits.device) if want_pixel else None
+    dens = None if density is None else density.contiguous()
+    N.check(N.lib().awseg_fog_ce_forward(N.ptr(logits), N.ptr(label), N.label_dtype(label), N.ptr(dens), b, c, hw,
+                                         N.LOSS_FOCAL if focal else N.LOSS_CE, float(sensitivity), N.ptr(pix),
+                                         N.ptr(partials), N.ptr(mean), N.ptr(oob), N.stream()), "awseg_fog_ce_forward")
+    return mean, pix
+
+
+def fog_ce_backward(logits, label, density, focal: bool, sensitivity: float, grad_scale: torch.Tensor) -> torch.Tensor:
+    logits, label = logits.contiguous(), label.contiguous()
+    b, c = logits.shape[0], logits.shape[1]
+    hw = logits[0, 0].numel()
+    grad = torch.empty_like(logits)
+    dens = None if density is None else density.contiguous()
+    gs = grad_scale.to(torch.float32).reshape(1).contiguous()
+    N.check(N.lib().awseg_fog_ce_backward(N.ptr(logits), N.ptr(label), N.label_dtype(label), N.ptr(dens), b, c, hw,
+                                          N.LOSS_FOCAL if focal else N.LOSS_CE, float(sensitivity), N.ptr(gs), N.ptr(grad),
+                                          N.stream()), "awseg_fog_ce_backward")
+    return grad
+
+
+def fog_density_from_depth(depth: torch.Tensor) -> torch.Tensor:
+    """FogDensityAwareLoss._estimate_fog_density_from_depth, PKG/models/model.py:644-677."""
+    depth = depth.contiguous().float()
+    b, h, w = depth.shape
+    ws = N.workspace.get(depth.device, N.lib().awseg_density_workspace(b, h * w), "density")
+    out = torch.empty_like(depth)
+    N.check(N.lib().awseg_fog_density_from_depth(N.ptr(depth), b, h, w, N.ptr(out), N.ptr(ws), N.stream()),
+            "awseg_fog_density_from_depth")
+    return out
+
+
+# ----------------------------------------------------------------------------- heads
+def segformer_head_fused(g9: torch.Tensor, scale, shift, w2, b2, height: int, width: int) -> torch.Tensor:
+    """Upsample-free SegFormer head (PKG/models/model.py:209-214).  g9 [B,h,w,9,Cmid]."""
+    g9 = g9.contiguous()
+    b, h, w, nine, cmid = g9.shape
+    assert nine == 9
+    cout = w2.shape[0]
+    out = torch.empty(b, cout, height, width, dtype=torch.float32, device=g9.device)
+    N.check(N.lib().awseg_segformer_head_fused(N.ptr(g9), b, cmid, h, w, height, width, N.ptr(scale.contiguous()),
+                                               N.ptr(shift.contiguous()), N.ptr(w2.contiguous()), N.ptr(b2.contiguous()),
+                                               cout, N.ptr(out), N.stream()), "awseg_segformer_head_fused")
+    return out
+
+
+def aspp_depthwise3(x_nhwc: torch.Tensor, wdw: torch.Tensor, rates) -> torch.Tensor:
+    """Depthwise halves of smp's three ASPPSeparableConv branches in one pass.
+    x [B,h,w,C] NHWC, wdw [3,9,C] -> [3,B,h,w,C]."""
+    x = x_nhwc.contiguous()
+    b, h, w, c = x.shape
+    out = torch.empty(3, b, h, w, c, dtype=torch.float32, device=x.device)
+    N.check(N.lib().awseg_aspp_depthwise3(N.ptr(x), b, h, w, c, N.ptr(wdw.contiguous()), int(rates[0]), int(rates[1]),
+                                          int(rates[2]), N.ptr(out), N.stream()), "awseg_aspp_depthwise3")
+    return out

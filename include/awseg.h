@@ -58,6 +58,31 @@ int         awseg_abi_version(void);          /* bumps when a signature changes 
 const char* awseg_error_string(int code);     /* host string for any return code */
 int         awseg_device_count(void);         /* hipGetDeviceCount, 0 when no GPU */
 
+/* Per-image jobs of the batched weather kernels.  `image` indexes the [B,H,W,3] batch for
+ * both input and output; the job's own position j indexes the per-job arrays (noise,
+ * depth_out).  Plain C layout (numpy dtype with align=True reproduces it). */
+typedef struct awseg_fog_job {
+    int32_t  image; int32_t _pad;
+    double   beta;            /* preprocessing.py:113 */
+    double   atmos;           /* preprocessing.py:114, rounded to float32 inside the kernel */
+    uint64_t seed;            /* Philox key, used only when noise == NULL */
+} awseg_fog_job;
+
+typedef struct awseg_night_job {
+    int32_t  image; int32_t _pad;
+    double   brightness;      /* 1 - I*U(.2,.6), preprocessing.py:212 */
+    double   intensity;       /* preprocessing.py:207 */
+    uint64_t seed;
+} awseg_night_job;
+
+typedef struct awseg_prim_job {
+    int32_t  image;
+    int32_t  prim_offset;     /* first primitive of this image in the shared primitive array */
+    int32_t  prim_count;
+    int32_t  blur_ksize;      /* snow: 3 or 7 (preprocessing.py:197); rain: ignored (3) */
+    double   intensity;
+} awseg_prim_job;
+
 /* ------------------------------------------------------------------------- *
  *  A13  IoUMetrics.compute_iou — confusion accumulation
  *       replaces PKG/evaluation/metrics.py:54-71
@@ -70,14 +95,17 @@ int         awseg_device_count(void);         /* hipGetDeviceCount, 0 when no GP
  * product is exact (int64 labels).  A pixel whose flat index falls outside
  * [0, C*C) — or whose prediction is outside [0, C) — is not counted and
  * increments *oob (int64[1], caller-zeroed): the host raises IndexError as
- * torch's index_add_ does.
+ * torch's index_add_ does.  uint8 maps must be 16-byte aligned.
+ * workspace: >= awseg_metrics_workspace(1, C, n) bytes (per-block partial
+ * histograms; contents are scratch).
  */
+int64_t awseg_metrics_workspace(int64_t batch, int num_classes, int64_t hw);
 int awseg_confusion_accumulate(const void* pred, int pred_dtype,
                                const void* label, int label_dtype,
                                int64_t n, int num_classes, int ignore_index,
                                int label_wrap_u8,
                                int64_t* counts, int64_t* oob,
-                               awseg_stream_t stream);
+                               void* workspace, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A12  logits.argmax(dim=1)
@@ -105,6 +133,7 @@ int awseg_argmax(const float* logits, int64_t batch, int num_classes, int64_t hw
  * [n_slots, C*C] where slot 0 receives every image and slot 1+cond[b] the
  * image's own weather condition (cond: device int32[B] or NULL -> slot 0 only;
  * cond[b] < 0 -> slot 0 only).  oob as in awseg_confusion_accumulate.
+ * workspace: >= awseg_metrics_workspace(B, C, HW) bytes when label != NULL.
  */
 int awseg_combine_argmax_confusion(const float* seg1, const float* seg2,
                                    int64_t batch, int num_classes, int64_t hw,
@@ -113,7 +142,7 @@ int awseg_combine_argmax_confusion(const float* seg1, const float* seg2,
                                    const void* label, int label_dtype, int ignore_index,
                                    int label_wrap_u8, const int32_t* cond,
                                    int64_t* counts, int n_slots, int64_t* oob,
-                                   awseg_stream_t stream);
+                                   void* workspace, awseg_stream_t stream);
 
 /* Single-model variant of the above: logits -> argmax -> confusion (77 B/px). */
 int awseg_argmax_confusion(const float* logits, int64_t batch, int num_classes, int64_t hw,
@@ -121,18 +150,21 @@ int awseg_argmax_confusion(const float* logits, int64_t batch, int num_classes, 
                            const void* label, int label_dtype, int ignore_index,
                            int label_wrap_u8, const int32_t* cond,
                            int64_t* counts, int n_slots, int64_t* oob,
-                           awseg_stream_t stream);
+                           void* workspace, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A7  Normalize + ToTensorV2
  *       replaces PKG/data/loader.py:195-198, 275-278
  * ------------------------------------------------------------------------- *
- * img uint8 HWC -> out float32 CHW, (x/255 - mean[c]) / std[c], three
- * separately rounded float32 operations.  mean/std are host float[3].
+ * imgs uint8 [B,H,W,3] -> out float32 [B,3,H,W], (x/255 - mean[c]) / std[c],
+ * three separately rounded float32 operations.  sel: device int32[n_sel] image
+ * indices to convert, or NULL for all B.  mean/std are host float[3].
+ * H*W must be a multiple of 4.
  */
-int awseg_normalize(const uint8_t* img, int height, int width,
+int awseg_normalize(const uint8_t* imgs, int64_t batch, int height, int width,
+                    const int32_t* sel, int n_sel,
                     const float* mean_host, const float* std_host,
-                    float* out_chw, awseg_stream_t stream);
+                    float* out, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A2  _generate_synthetic_depth
@@ -140,33 +172,35 @@ int awseg_normalize(const uint8_t* img, int height, int width,
  * ------------------------------------------------------------------------- *
  * depth = max(gaussian_filter((y/H)*100 + noise, sigma=2), 1.0) in float64:
  * 17-tap separable filter, axis 0 first then axis 1, scipy 'reflect' border,
- * scipy's symmetric summation order.  noise: float64 [H,W] (the host's
- * np.random.normal(0,10) draw) or NULL -> N(0,10) from the in-kernel Philox
- * stream keyed by `seed`.  taps: host double[17] = the normalised kernel.
- * depth_out float64 [H,W].
+ * scipy's symmetric summation order.  noise: float64 [n_jobs,H,W] (the host's
+ * np.random.normal(0,10) draws) or NULL -> N(0,10) from the in-kernel Philox
+ * stream keyed by jobs[j].seed.  taps: host double[17] = the normalised kernel.
+ * depth_out float64 [n_jobs,H,W].
  */
-int awseg_synthetic_depth(const double* noise, uint64_t seed, int height, int width,
-                          const double* taps_host, double* depth_out,
-                          awseg_stream_t stream);
+int awseg_synthetic_depth(int height, int width,
+                          const awseg_fog_job* jobs, int n_jobs,
+                          const double* noise, const double* taps_host,
+                          double* depth_out, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A3  _apply_fog            replaces PKG/data/preprocessing.py:113-123
  * ------------------------------------------------------------------------- *
  * t = exp(-beta*depth); out = trunc(clip(img/255 * t + (double)(float)A*(1-t), 0,1)*255)
  * in float64 (img/255 is float32, A is rounded to float32 first, as numpy does).
- * norm_out: optional fused A7 output (float32 CHW) or NULL; mean/std host float[3].
+ * depth float64 [n_jobs,H,W].  out: uint8 [B,H,W,3] or NULL; norm_out: fused A7
+ * output float32 [B,3,H,W] or NULL (at least one of the two).
  */
-int awseg_fog_apply(const uint8_t* img, const double* depth, int height, int width,
-                    double beta, double atmos_light,
+int awseg_fog_apply(const uint8_t* imgs, int height, int width,
+                    const awseg_fog_job* jobs, int n_jobs, const double* depth,
                     uint8_t* out, float* norm_out,
                     const float* mean_host, const float* std_host,
                     awseg_stream_t stream);
 
 /* A2+A3 in one kernel: depth never leaves the chip (noise tile + halo staged in LDS).
- * noise NULL -> Philox.  depth_out optional (NULL = not written). */
-int awseg_fog_fused(const uint8_t* img, const double* noise, uint64_t seed,
-                    int height, int width, const double* taps_host,
-                    double beta, double atmos_light,
+ * noise NULL -> Philox.  depth_out optional float64 [n_jobs,H,W] (NULL = not written). */
+int awseg_fog_fused(const uint8_t* imgs, int height, int width,
+                    const awseg_fog_job* jobs, int n_jobs,
+                    const double* noise, const double* taps_host,
                     uint8_t* out, float* norm_out, double* depth_out,
                     const float* mean_host, const float* std_host,
                     awseg_stream_t stream);
@@ -176,12 +210,13 @@ int awseg_fog_fused(const uint8_t* img, const double* noise, uint64_t seed,
  * ------------------------------------------------------------------------- *
  * v = ((img/255)*f32(brightness)) * f32(gain[c])   (float32, two roundings)
  * out = trunc(clip((double)v + noise*intensity*0.5, 0,1)*255)  (float64)
- * noise: float64 [H,W,3] (host draw of np.random.normal(0, 5/255)) or NULL ->
- * Philox N(0, 5/255).  gains are the reference's 0.8 / 0.85 / 1.2 (host float[3]).
+ * noise: float64 [n_jobs,H,W,3] (host draws of np.random.normal(0, 5/255)) or
+ * NULL -> Philox N(0, 5/255).  gains are the reference's 0.8 / 0.85 / 1.2
+ * (host float[3]).  H*W*3 must be a multiple of 4.
  */
-int awseg_night_apply(const uint8_t* img, const double* noise, uint64_t seed,
-                      int height, int width,
-                      double brightness, double intensity, const float* gains_host,
+int awseg_night_apply(const uint8_t* imgs, int height, int width,
+                      const awseg_night_job* jobs, int n_jobs,
+                      const double* noise, const float* gains_host,
                       uint8_t* out, float* norm_out,
                       const float* mean_host, const float* std_host,
                       awseg_stream_t stream);
@@ -189,15 +224,15 @@ int awseg_night_apply(const uint8_t* img, const double* noise, uint64_t seed,
 /* ------------------------------------------------------------------------- *
  *  A4  _apply_rain           replaces PKG/data/preprocessing.py:131-168
  * ------------------------------------------------------------------------- *
- * haze: v = v*(1-0.3I) + 0.3I*0.7 (float32); streaks: n_drops line segments
+ * haze: v = v*(1-0.3I) + 0.3I*0.7 (float32); streaks: line segments
  * (x0,y0,x1,y1,thickness) painted with colour (.8,.9,1.0); 3x3 Gaussian blur
- * sigma 0.5, BORDER_REFLECT_101, float32; quantise.  drops: device int32[n,5]
- * in drawing order (later drops overwrite earlier ones — same colour, so order
- * is immaterial).  OpenCV's rasteriser is not available offline: the coverage
- * rule is stated in oracle/awseg_oracle.c (parity unpinned).
+ * sigma 0.5, BORDER_REFLECT_101, float32; quantise.  drops: device int32[n,5],
+ * jobs[j] names its slice.  OpenCV's rasteriser is not available offline: the
+ * coverage rule is stated in oracle/awseg_oracle.c (parity unpinned).
+ * out must not alias imgs.
  */
-int awseg_rain_apply(const uint8_t* img, int height, int width,
-                     double intensity, const int32_t* drops, int n_drops,
+int awseg_rain_apply(const uint8_t* imgs, int height, int width,
+                     const awseg_prim_job* jobs, int n_jobs, const int32_t* drops,
                      uint8_t* out, float* norm_out,
                      const float* mean_host, const float* std_host,
                      awseg_stream_t stream);
@@ -205,12 +240,12 @@ int awseg_rain_apply(const uint8_t* img, int height, int width,
 /* ------------------------------------------------------------------------- *
  *  A5  _apply_snow           replaces PKG/data/preprocessing.py:176-202
  * ------------------------------------------------------------------------- *
- * v = clip(v + 0.2I, 0, 1); n_flakes filled discs (x,y,r) of 1.0; Gaussian
- * blur ksize 3 or 7, sigma 1.0, BORDER_REFLECT_101, float32; quantise.
- * flakes: device int32[n,3].
+ * v = clip(v + 0.2I, 0, 1); filled discs (x,y,r) of 1.0; Gaussian blur ksize 3
+ * or 7, sigma 1.0, BORDER_REFLECT_101, float32; quantise.  flakes: device
+ * int32[n,3].  out must not alias imgs.
  */
-int awseg_snow_apply(const uint8_t* img, int height, int width,
-                     double intensity, const int32_t* flakes, int n_flakes, int blur_ksize,
+int awseg_snow_apply(const uint8_t* imgs, int height, int width,
+                     const awseg_prim_job* jobs, int n_jobs, const int32_t* flakes,
                      uint8_t* out, float* norm_out,
                      const float* mean_host, const float* std_host,
                      awseg_stream_t stream);
@@ -219,11 +254,11 @@ int awseg_snow_apply(const uint8_t* img, int height, int width,
  *  A16  AdverseWeatherTrainer._estimate_fog_density
  *       replaces PKG/training/trainer.py:494-511 (and its .to(device) at :321)
  * ------------------------------------------------------------------------- *
- * density[b] = U[0,1) * scale(cond[b]) + offset(cond[b]) generated on device
- * (Philox; the reference draws from torch's CPU generator, so parity is in
- * distribution only).  cond: host int32[B] (0 clean,1 fog,2 rain,3 snow,4 night).
+ * density[b] = U[0,1) * scale[b] + offset[b] generated on device (Philox; the
+ * reference draws from torch's CPU generator, so parity is in distribution only).
+ * scale_offset: device float32 [B,2] ({.5,.5} fog, {.3,.2} rain/snow, {.1,0} else).
  */
-int awseg_fog_density_field(const int32_t* cond_host, int batch, int64_t hw, uint64_t seed,
+int awseg_fog_density_field(const float* scale_offset, int batch, int64_t hw, uint64_t seed,
                             float* density, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
@@ -231,14 +266,14 @@ int awseg_fog_density_field(const int32_t* cond_host, int batch, int64_t hw, uin
  * ------------------------------------------------------------------------- *
  * Forward: per pixel ce = logsumexp(x) - x[label]; focal: (1-exp(-ce))^2 * ce;
  * times (1 + sensitivity*density) when density != NULL.  Writes per-block
- * partial sums (float64) into `partials` (>= awseg_loss_partials(batch*hw)
+ * partial sums (float64) into `partials` (>= awseg_loss_partials(B, HW)
  * doubles) and the float32 mean into loss_mean[0] via a second tiny launch.
  * pixel_loss: optional float32 [B,HW] output.  A label outside [0,C) raises
  * *oob (torch raises IndexError; ignore_index=-100 never occurs for uint8).
  * Backward: grad_logits[b,c,p] = g * w_p * (softmax_c - [c==label]) * focal' / N
  * with g = grad_scale[0] (device float, the upstream gradient of the mean).
  */
-int64_t awseg_loss_partials(int64_t n_pixels);
+int64_t awseg_loss_partials(int64_t batch, int64_t hw);
 int awseg_fog_ce_forward(const float* logits, const void* label, int label_dtype,
                          const float* density, int64_t batch, int num_classes, int64_t hw,
                          int base_loss, float sensitivity,
@@ -252,8 +287,8 @@ int awseg_fog_ce_backward(const float* logits, const void* label, int label_dtyp
 /* _estimate_fog_density_from_depth, PKG/models/model.py:658-677.
  * depth float32 [B,H,W] -> density float32 [B,H,W]; statistics (min, max, mean
  * gradient magnitude) are global over the whole batch as in the reference.
- * workspace: >= awseg_density_workspace(batch*h*w) bytes. */
-int64_t awseg_density_workspace(int64_t n_pixels);
+ * workspace: >= awseg_density_workspace(B, H*W) bytes, 16-byte aligned. */
+int64_t awseg_density_workspace(int64_t batch, int64_t hw);
 int awseg_fog_density_from_depth(const float* depth, int64_t batch, int height, int width,
                                  float* density, void* workspace, awseg_stream_t stream);
 
@@ -262,15 +297,16 @@ int awseg_fog_density_from_depth(const float* depth, int64_t batch, int height, 
  *       replaces PKG/models/model.py:209-214 (F.interpolate x32 -> Conv3x3 ->
  *       BatchNorm(eval) -> ReLU -> Conv1x1)
  * ------------------------------------------------------------------------- *
- * feat float32 [B,Cin,h,w] (stride-32 encoder output); the full-resolution
- * [B,Cin,H,W] tensor is never materialised: because bilinear upsampling and the
- * 3x3 convolution are both linear, conv3x3(up(f)) = sum_tap shift_tap(up(W_tap f)).
- *   g9     float32 [B, 9, h, w, Cmid]  = per-tap 1x1 products W_tap . f, computed by the
- *          caller with a plain GEMM (tap = ky*3+kx, channel-last)
+ * The full-resolution [B,Cin,H,W] tensor is never materialised: bilinear
+ * upsampling and the 3x3 convolution are both linear, so
+ * conv3x3(up(f)) = sum_tap shift_tap(up(W_tap f)).
+ *   g9     float32 [B, h, w, 9, Cmid] = per-tap 1x1 products W_tap . f at the
+ *          encoder's resolution (tap = ky*3+kx, channel-last), computed by the
+ *          caller with one plain GEMM
  *   scale/shift float32 [Cmid]: conv bias + eval-mode BatchNorm folded to y*scale+shift
- *   w2     float32 [Cout, Cmid], b2 float32 [Cout]: the 1x1 classifier
+ *   w2     float32 [Cout, Cmid], b2 float32 [Cout]: the 1x1 classifier (Cout <= 32)
  * out float32 [B,Cout,H,W].  Zero padding of the 3x3 at the image border and
- * align_corners=False source coordinates follow torch exactly.
+ * align_corners=False source coordinates follow torch exactly.  Cmid % 32 == 0.
  */
 int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmid, int h, int w,
                                int height, int width,
@@ -284,7 +320,7 @@ int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmid, int h, 
  *       (call site PKG/models/model.py:259-265, 349)
  * ------------------------------------------------------------------------- *
  * x float32 NHWC [B,h,w,C]; wdw float32 [3 rates][9 taps][C]; out float32
- * [3][B,h,w,C] (NHWC per rate) ready for the pointwise GEMMs.
+ * [3][B,h,w,C] (NHWC per rate) ready for the pointwise GEMMs.  C % 4 == 0.
  */
 int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int channels,
                           const float* wdw, int rate0, int rate1, int rate2,
@@ -296,14 +332,14 @@ int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int chann
  * ------------------------------------------------------------------------- *
  * For every pixel with label != 255: conf = max softmax prob, bin k with
  * edges[k] < conf <= edges[k+1] (edges: device float32[n_bins+1] =
- * torch.linspace(0,1,n_bins+1)); bins[slot][k] += {1, conf, correct} as
- * (int64 count, float64 sum_conf, int64 sum_correct) packed in 3 x 8 bytes.
- * Slots as in awseg_combine_argmax_confusion.
+ * torch.linspace(0,1,n_bins+1), n_bins <= 64); bins[slot][k] accumulates
+ * {int64 count, float64 sum_conf, int64 sum_correct} (24 bytes per bin).
+ * Slots as in awseg_combine_argmax_confusion.  workspace as awseg_metrics_workspace.
  */
 int awseg_ece_accumulate(const float* logits, int64_t batch, int num_classes, int64_t hw,
                          const void* label, int label_dtype, const int32_t* cond,
                          const float* edges, int n_bins,
-                         void* bins, int n_slots, awseg_stream_t stream);
+                         void* bins, int n_slots, void* workspace, awseg_stream_t stream);
 
 #ifdef __cplusplus
 }

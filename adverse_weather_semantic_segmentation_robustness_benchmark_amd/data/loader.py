@@ -1,0 +1,99 @@
+"""Dataset glue of the hot path (PKG/data/loader.py:23-293, 390-420), re-designed so a batch is
+BORN on the GPU: synthetic frames, the per-sample weather choice, the corruption kernels and the
+fused Normalize+ToTensorV2 all run on device; only the scalar draws happen on the host.
+
+File discovery / decoding / resizing of real Cityscapes-KITTI trees is host I/O and out of scope
+(SURVEY §2 rows 3, 5); like the reference when no data is found (loader.py:103-105), the dataset
+serves synthetic samples: 100 for 'train', 20 otherwise (:165-179), uint8 images uniform on
+0..254 (:206) and uint8 labels uniform on 0..18 (:231).
+"""
+from __future__ import annotations
+
+import logging
+from typing import Dict, Iterator, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from .. import ops
+from .preprocessing import WeatherDegradationTransforms
+
+logger = logging.getLogger(__name__)
+
+
+class CityscapesKITTIDataset:
+    """Batch source with the reference dataset's constructor arguments.  Iterate it through
+    `create_dataloader` (or `.batches()`): each batch is the reference's collated dict
+    {'image' f32[B,3,H,W], 'label' u8[B,H,W], 'weather_condition' list[str], 'dataset' list[str]}
+    on the GPU."""
+
+    def __init__(self, data_root: str = "data", split: str = "train", image_size: Tuple[int, int] = (512, 1024),
+                 weather_conditions: Optional[List[str]] = None, apply_augmentation: bool = True, include_depth: bool = True,
+                 dataset_type: str = "combined", device="cuda", rng: str = "philox", weather_schedule: str = "random",
+                 num_samples: Optional[int] = None, seed: int = 42) -> None:
+        self.data_root, self.split, self.image_size = data_root, split, tuple(image_size)
+        self.weather_conditions = weather_conditions or ["clean", "fog", "rain", "snow", "night"]
+        self.apply_augmentation, self.include_depth, self.dataset_type = apply_augmentation, include_depth, dataset_type
+        self.device = torch.device(device)
+        self.weather_schedule = weather_schedule          # 'random' (loader.py:265) or 'round_robin' (bench)
+        self.num_samples = num_samples if num_samples is not None else (100 if split == "train" else 20)
+        self.weather_transforms = WeatherDegradationTransforms(rng=rng, device=self.device)
+        self._gen = torch.Generator(device=self.device)
+        self._gen.manual_seed(seed)
+        self._host_rng = np.random.RandomState(seed)
+        logger.info("Generated %d synthetic samples for testing", self.num_samples)
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+    def synth_raw(self, n: int):
+        """uint8 frames / labels generated on device (shapes and ranges of loader.py:206, 231)."""
+        h, w = self.image_size
+        imgs = torch.randint(0, 255, (n, h, w, 3), dtype=torch.uint8, device=self.device, generator=self._gen)
+        labels = torch.randint(0, 19, (n, h, w), dtype=torch.uint8, device=self.device, generator=self._gen)
+        return imgs, labels
+
+    def choose_conditions(self, start: int, n: int) -> List[str]:
+        if self.weather_schedule == "round_robin":
+            return [self.weather_conditions[(start + i) % len(self.weather_conditions)] for i in range(n)]
+        return [str(self._host_rng.choice(self.weather_conditions)) for _ in range(n)]
+
+    def make_batch(self, start: int, n: int, raw=None) -> Dict[str, object]:
+        imgs, labels = raw if raw is not None else self.synth_raw(n)
+        conds = self.choose_conditions(start, n)
+        h, w = self.image_size
+        image = torch.empty(n, 3, h, w, dtype=torch.float32, device=self.device)
+        self.weather_transforms.apply_batch(imgs, conds, norm_out=image)
+        return {"image": image, "label": labels, "weather_condition": conds, "dataset": ["synthetic"] * n}
+
+    def batches(self, batch_size: int, drop_last: bool = False, rank: int = 0, world_size: int = 1) -> Iterator[Dict[str, object]]:
+        """Contiguous block sharding of the sample index range over ranks."""
+        per = (self.num_samples + world_size - 1) // world_size
+        lo, hi = min(rank * per, self.num_samples), min((rank + 1) * per, self.num_samples)
+        i = lo
+        while i < hi:
+            n = min(batch_size, hi - i)
+            if n < batch_size and drop_last:
+                break
+            yield self.make_batch(i, n)
+            i += n
+
+
+class _Loader:
+    def __init__(self, dataset, batch_size, drop_last, rank, world_size):
+        self.dataset, self.batch_size, self.drop_last, self.rank, self.world_size = dataset, batch_size, drop_last, rank, world_size
+
+    def __iter__(self):
+        return self.dataset.batches(self.batch_size, self.drop_last, self.rank, self.world_size)
+
+    def __len__(self):
+        per = (len(self.dataset) + self.world_size - 1) // self.world_size
+        n = max(0, min((self.rank + 1) * per, len(self.dataset)) - self.rank * per)
+        return n // self.batch_size if self.drop_last else (n + self.batch_size - 1) // self.batch_size
+
+
+def create_dataloader(dataset, batch_size: int = 8, shuffle: bool = True, num_workers: int = 4, pin_memory: bool = True,
+                      rank: int = 0, world_size: int = 1):
+    """PKG/data/loader.py:390-420: `drop_last = shuffle`.  Worker processes / pinned memory are
+    meaningless for a device-resident source and are accepted and ignored."""
+    return _Loader(dataset, batch_size, drop_last=shuffle, rank=rank, world_size=world_size)

@@ -1,0 +1,208 @@
+"""Weather degradation transforms with the reference's class / method names
+(PKG/data/preprocessing.py:15-288), executed by the HIP kernels of csrc/weather.hip.
+
+Randomness.  The reference draws everything from numpy's global legacy RNG
+in a fixed call order.  Two modes:
+
+* ``rng="numpy"`` (default for the drop-in API): the host draws the SAME numbers in the SAME
+  order from ``np.random`` and uploads them, so for a given ``np.random.seed`` the uint8 result
+  is what the reference produces (bit-exact for fog / night; rain / snow depend on OpenCV's
+  rasteriser, parity unpinned).
+* ``rng="philox"``: scalar parameters still come from the host, per-pixel noise is generated
+  in-kernel by Philox4x32-10 — nothing per-pixel crosses PCIe.  Same distributions, different
+  stream: parity is not defined in this mode; it is the throughput mode the batch path uses.
+
+Inputs may be numpy HWC uint8 arrays (reference calling convention: uploaded, processed,
+downloaded) or CUDA uint8 tensors [H,W,3] / [B,H,W,3] (stay on device).
+"""
+from __future__ import annotations
+
+import logging
+from typing import List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+
+from .. import ops
+
+logger = logging.getLogger(__name__)
+
+WEATHER_TYPES = ("clean", "fog", "rain", "snow", "night")
+
+
+# --- host-side parameter draws, in the reference's RNG call order ---------------------------
+def draw_fog(h: int, w: int, intensity=None, per_pixel: bool = True):
+    """depth noise first (preprocessing.py:239 via :104), then intensity (:108)."""
+    noise = np.random.normal(0, 10, (h, w)) if per_pixel else None
+    if intensity is None:
+        intensity = np.random.uniform(0.3, 0.9)
+    return noise, intensity
+
+
+def draw_night(h: int, w: int, intensity=None, per_pixel: bool = True):
+    """intensity (:207), brightness factor (:212), noise (:222)."""
+    if intensity is None:
+        intensity = np.random.uniform(0.4, 0.8)
+    brightness = 1 - intensity * np.random.uniform(0.2, 0.6)
+    noise = np.random.normal(0, 5.0 / 255.0, (h, w, 3)) if per_pixel else None
+    return intensity, brightness, noise
+
+
+def draw_rain(h: int, w: int, intensity=None):
+    """intensity (:128); per drop x, y, length, thickness in {1,3}, angle (:144-148); end point
+    truncated toward zero and clipped into the image (:151-156)."""
+    if intensity is None:
+        intensity = np.random.uniform(0.2, 0.8)
+    n = int(100 + intensity * (500 - 100))
+    drops = np.empty((n, 5), dtype=np.int32)
+    for i in range(n):
+        x = np.random.randint(0, w)
+        y = np.random.randint(0, h)
+        length = np.random.randint(5, 20)
+        thickness = np.random.choice((1, 3))
+        angle = np.random.uniform(-15, 15)
+        ex = np.clip(int(x + length * np.sin(np.radians(angle))), 0, w - 1)
+        ey = np.clip(int(y + length * np.cos(np.radians(angle))), 0, h - 1)
+        drops[i] = (x, y, ex, ey, thickness)
+    return intensity, drops
+
+
+def draw_snow(h: int, w: int, intensity=None):
+    """intensity (:173); per flake x, y, radius in {2,8} (:189-191); blur kernel in {3,7} (:197)."""
+    if intensity is None:
+        intensity = np.random.uniform(0.2, 0.7)
+    n = int(50 + intensity * (200 - 50))
+    flakes = np.empty((n, 3), dtype=np.int32)
+    for i in range(n):
+        flakes[i] = (np.random.randint(0, w), np.random.randint(0, h), np.random.choice((2, 8)))
+    k = int(np.random.choice((3, 7)))
+    return intensity, flakes, (k + 1 if k % 2 == 0 else k)
+
+
+class WeatherDegradationTransforms:
+    """PKG/data/preprocessing.py:15-288."""
+
+    def __init__(self, seed: Optional[int] = None, rng: str = "numpy", device: Union[str, torch.device] = "cuda") -> None:
+        if seed is not None:
+            np.random.seed(seed)
+        if rng not in ("numpy", "philox"):
+            raise ValueError("rng must be 'numpy' or 'philox'")
+        self.rng = rng
+        self.device = torch.device(device)
+        self._philox_seed = 0x5EED if seed is None else int(seed)
+        self.fog_parameters = {"beta_range": (0.005, 0.05), "A_range": (0.7, 1.0), "depth_scale": 100.0}
+        self.rain_parameters = {"intensity_range": (0.1, 0.8), "drop_size_range": (1, 3), "angle_range": (-15, 15),
+                                "num_drops_range": (100, 500)}
+        self.snow_parameters = {"intensity_range": (0.1, 0.7), "flake_size_range": (2, 8), "num_flakes_range": (50, 200),
+                                "blur_kernel": (3, 7)}
+        self.night_parameters = {"brightness_reduction": (0.2, 0.6), "color_shift": {"r": 0.8, "g": 0.85, "b": 1.2},
+                                 "noise_std": 5.0}
+
+    def _next_seed(self) -> int:
+        self._philox_seed = (self._philox_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
+        return self._philox_seed
+
+    # ---- single-image API (reference calling convention) -------------------------------------
+    def apply_weather_effect(self, image, weather_type: str, intensity: Optional[float] = None):
+        if weather_type == "clean":
+            return image                                                             # :78-79
+        if weather_type not in WEATHER_TYPES:
+            raise ValueError(f"Unknown weather type: {weather_type}")                # :92
+        is_np = isinstance(image, np.ndarray)
+        dev_img = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(self.device) if is_np else image
+        batch = dev_img.unsqueeze(0) if dev_img.dim() == 3 else dev_img
+        out = self.apply_batch(batch, [weather_type] * batch.shape[0], intensities=[intensity] * batch.shape[0])
+        out = out[0] if dev_img.dim() == 3 else out
+        return out.cpu().numpy() if is_np else out
+
+    # ---- batched device API (one launch per condition present in the batch) -----------------
+    def apply_batch(self, imgs: torch.Tensor, conditions: Sequence[str], intensities: Optional[Sequence] = None,
+                    out: Optional[torch.Tensor] = None, norm_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+        """imgs uint8 [B,H,W,3] on device.  Writes the corrupted uint8 frames to `out` (allocated
+        when both outputs are None) and/or the normalised float32 [B,3,H,W] tensor to `norm_out`
+        (the loader's Normalize+ToTensorV2, fused).  'clean' frames are copied / normalised."""
+        B, H, W, _ = imgs.shape
+        if intensities is None:
+            intensities = [None] * B
+        if out is None and norm_out is None:
+            out = torch.empty_like(imgs)
+        per_pixel = self.rng == "numpy"
+        groups = {k: [] for k in WEATHER_TYPES}
+        for b, c in enumerate(conditions):
+            c = str(c)
+            if c not in groups:
+                raise ValueError(f"Unknown weather type: {c}")
+            groups[c].append(b)
+        # the reference handles samples one after another, so draws happen in sample order
+        draws = {}
+        for b, c in enumerate(conditions):
+            c = str(c)
+            if c == "fog":
+                draws[b] = draw_fog(H, W, intensities[b], per_pixel)
+            elif c == "night":
+                draws[b] = draw_night(H, W, intensities[b], per_pixel)
+            elif c == "rain":
+                draws[b] = draw_rain(H, W, intensities[b])
+            elif c == "snow":
+                draws[b] = draw_snow(H, W, intensities[b])
+        dev = imgs.device
+        if groups["clean"]:
+            idx = groups["clean"]
+            if out is not None and out.data_ptr() != imgs.data_ptr():
+                out[idx] = imgs[idx]
+            if norm_out is not None:
+                ops.normalize(imgs, out=norm_out, sel=torch.tensor(idx, dtype=torch.int32).to(dev, non_blocking=True))
+        if groups["fog"]:
+            idx = groups["fog"]
+            jobs = ops.fog_jobs(idx, [draws[b][1] for b in idx], [self._next_seed() for _ in idx])
+            noise = torch.from_numpy(np.stack([draws[b][0] for b in idx])).to(dev, non_blocking=True) if per_pixel else None
+            ops.fog(imgs, jobs, noise=noise, out=out, norm_out=norm_out)
+        if groups["night"]:
+            idx = groups["night"]
+            jobs = ops.night_jobs(idx, [draws[b][1] for b in idx], [draws[b][0] for b in idx], [self._next_seed() for _ in idx])
+            noise = torch.from_numpy(np.stack([draws[b][2] for b in idx])).to(dev, non_blocking=True) if per_pixel else None
+            ops.night(imgs, jobs, noise=noise, out=out, norm_out=norm_out)
+        if groups["rain"] or groups["snow"]:
+            tmp = out
+            if out is not None and out.data_ptr() == imgs.data_ptr():
+                tmp = torch.empty_like(imgs)                                         # blur reads neighbours: not in place
+            if groups["rain"]:
+                idx = groups["rain"]
+                jobs, prims = ops.prim_jobs(idx, [draws[b][0] for b in idx], [draws[b][1] for b in idx])
+                ops.rain(imgs, jobs, prims, out=tmp, norm_out=norm_out)
+            if groups["snow"]:
+                idx = groups["snow"]
+                jobs, prims = ops.prim_jobs(idx, [draws[b][0] for b in idx], [draws[b][1] for b in idx], [draws[b][2] for b in idx])
+                ops.snow(imgs, jobs, prims, out=tmp, norm_out=norm_out)
+            if tmp is not out and out is not None:
+                sel = groups["rain"] + groups["snow"]
+                out[sel] = tmp[sel]
+        return out
+
+    # ---- pieces the reference exposes ----------------------------------------------------------
+    def _generate_synthetic_depth(self, height: int, width: int) -> np.ndarray:
+        """preprocessing.py:227-248 -> float64 [H,W] (numpy, like the reference)."""
+        per_pixel = self.rng == "numpy"
+        noise = torch.from_numpy(np.random.normal(0, 10, (height, width))[None]).to(self.device) if per_pixel else None
+        jobs = ops.fog_jobs([0], [0.5], [self._next_seed()])
+        return ops.synthetic_depth(height, width, jobs, self.device, noise)[0].cpu().numpy()
+
+    def _apply_fog(self, image, intensity=None):
+        return self.apply_weather_effect(self._as_u8(image), "fog", intensity)
+
+    def _apply_rain(self, image, intensity=None):
+        return self.apply_weather_effect(self._as_u8(image), "rain", intensity)
+
+    def _apply_snow(self, image, intensity=None):
+        return self.apply_weather_effect(self._as_u8(image), "snow", intensity)
+
+    def _apply_night(self, image, intensity=None):
+        return self.apply_weather_effect(self._as_u8(image), "night", intensity)
+
+    @staticmethod
+    def _as_u8(image):
+        """The reference's private helpers take float32 images in [0,1] produced from uint8 by /255
+        (:81); map them back exactly (x*255 is within 1e-5 of the original integer)."""
+        if isinstance(image, np.ndarray) and image.dtype != np.uint8:
+            return np.rint(image.astype(np.float64) * 255.0).astype(np.uint8)
+        return image

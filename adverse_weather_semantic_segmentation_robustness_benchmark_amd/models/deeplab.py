@@ -1,0 +1,265 @@
+"""DeepLabV3+ (ResNet encoder, separable ASPP, decoder) with segmentation_models_pytorch's
+module tree and state_dict key names, written from scratch for torch-ROCm + HIP.
+
+The reference delegates this whole network to ``smp.DeepLabV3Plus(encoder_name='resnet50',
+classes=C, activation=None)`` (PKG/models/model.py:259-265); smp / torchvision are not
+available offline, so structure and key names follow the published packages from memory
+(parity for this part is against this repo's own as-written path only).
+
+Two forwards over the same parameters:
+  * ``forward``            — the as-written module graph (autograd-capable; training path)
+  * ``forward_fused``      — eval path: channels-last convs, the three atrous depthwise
+                             convolutions of the ASPP in ONE HIP pass (awseg_aspp_depthwise3),
+                             BatchNorm folded into the pointwise GEMMs, no 1280-channel concat
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+# --------------------------------------------------------------------------- ResNet encoder
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        identity = x
+        out = self.relu(self.bn1(self.conv1(x)))
+        out = self.relu(self.bn2(self.conv2(out)))
+        out = self.bn3(self.conv3(out))
+        if self.downsample is not None:
+            identity = self.downsample(x)
+        out += identity
+        return self.relu(out)
+
+
+_RESNET_LAYERS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}
+
+
+class ResNetEncoder(nn.Module):
+    """torchvision ResNet trunk (no fc), smp's feature list and `make_dilated(output_stride=16)`."""
+
+    out_channels = (3, 64, 256, 512, 1024, 2048)
+
+    def __init__(self, name="resnet50", output_stride=16):
+        super().__init__()
+        layers = _RESNET_LAYERS.get(name, _RESNET_LAYERS["resnet50"])
+        self.inplanes = 64
+        self.conv1 = nn.Conv2d(3, 64, 7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(3, stride=2, padding=1)
+        self.layer1 = self._make_layer(64, layers[0])
+        self.layer2 = self._make_layer(128, layers[1], stride=2)
+        self.layer3 = self._make_layer(256, layers[2], stride=2)
+        self.layer4 = self._make_layer(512, layers[3], stride=2)
+        for m in self.modules():                         # torchvision's init
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        if output_stride == 16:
+            self._dilate(self.layer4, 2)
+        elif output_stride == 8:
+            self._dilate(self.layer3, 2)
+            self._dilate(self.layer4, 4)
+
+    def _make_layer(self, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * 4:
+            downsample = nn.Sequential(nn.Conv2d(self.inplanes, planes * 4, 1, stride=stride, bias=False),
+                                       nn.BatchNorm2d(planes * 4))
+        layers = [Bottleneck(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * 4
+        layers += [Bottleneck(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*layers)
+
+    @staticmethod
+    def _dilate(layer, rate):
+        """smp.base.utils.replace_strides_with_dilation: every conv loses its stride, gets the rate."""
+        for m in layer.modules():
+            if isinstance(m, nn.Conv2d):
+                m.stride = (1, 1)
+                m.dilation = (rate, rate)
+                kh, kw = m.kernel_size
+                m.padding = ((kh // 2) * rate, (kw // 2) * rate)
+
+    def forward(self, x) -> List[torch.Tensor]:
+        feats = [x]
+        x = self.relu(self.bn1(self.conv1(x)))
+        feats.append(x)
+        x = self.layer1(self.maxpool(x))
+        feats.append(x)
+        x = self.layer2(x)
+        feats.append(x)
+        x = self.layer3(x)
+        feats.append(x)
+        x = self.layer4(x)
+        feats.append(x)
+        return feats
+
+
+# --------------------------------------------------------------------------- decoder pieces
+class SeparableConv2d(nn.Sequential):
+    def __init__(self, in_ch, out_ch, kernel_size, padding=0, dilation=1, bias=True):
+        super().__init__(
+            nn.Conv2d(in_ch, in_ch, kernel_size, padding=padding, dilation=dilation, groups=in_ch, bias=False),
+            nn.Conv2d(in_ch, out_ch, 1, bias=bias))
+
+
+class ASPPSeparableConv(nn.Sequential):
+    def __init__(self, in_ch, out_ch, dilation):
+        super().__init__(SeparableConv2d(in_ch, out_ch, 3, padding=dilation, dilation=dilation, bias=False),
+                         nn.BatchNorm2d(out_ch), nn.ReLU())
+
+
+class ASPPPooling(nn.Sequential):
+    def __init__(self, in_ch, out_ch):
+        super().__init__(nn.AdaptiveAvgPool2d(1), nn.Conv2d(in_ch, out_ch, 1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU())
+
+    def forward(self, x):
+        size = x.shape[-2:]
+        for mod in self:
+            x = mod(x)
+        return F.interpolate(x, size=size, mode="bilinear", align_corners=False)
+
+
+class ASPP(nn.Module):
+    def __init__(self, in_ch, out_ch, atrous_rates):
+        super().__init__()
+        self.rates = tuple(atrous_rates)
+        mods = [nn.Sequential(nn.Conv2d(in_ch, out_ch, 1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU())]
+        mods += [ASPPSeparableConv(in_ch, out_ch, r) for r in self.rates]
+        mods.append(ASPPPooling(in_ch, out_ch))
+        self.convs = nn.ModuleList(mods)
+        self.project = nn.Sequential(nn.Conv2d(5 * out_ch, out_ch, 1, bias=False), nn.BatchNorm2d(out_ch), nn.ReLU(),
+                                     nn.Dropout(0.5))
+
+    def forward(self, x):
+        return self.project(torch.cat([conv(x) for conv in self.convs], dim=1))
+
+
+def _bn_fold(bn: nn.BatchNorm2d):
+    """eval-mode BatchNorm as y*scale + shift."""
+    inv = torch.rsqrt(bn.running_var + bn.eps)
+    scale = bn.weight * inv
+    return scale, bn.bias - bn.running_mean * scale
+
+
+class DeepLabV3PlusDecoder(nn.Module):
+    def __init__(self, encoder_channels, out_channels=256, atrous_rates=(12, 24, 36), output_stride=16):
+        super().__init__()
+        self.out_channels = out_channels
+        self.aspp = nn.Sequential(ASPP(encoder_channels[-1], out_channels, atrous_rates),
+                                  SeparableConv2d(out_channels, out_channels, 3, padding=1, bias=False),
+                                  nn.BatchNorm2d(out_channels), nn.ReLU())
+        self.up = nn.UpsamplingBilinear2d(scale_factor=2 if output_stride == 8 else 4)   # align_corners=True
+        self.block1 = nn.Sequential(nn.Conv2d(encoder_channels[-4], 48, 1, bias=False), nn.BatchNorm2d(48), nn.ReLU())
+        self.block2 = nn.Sequential(SeparableConv2d(48 + out_channels, out_channels, 3, padding=1, bias=False),
+                                    nn.BatchNorm2d(out_channels), nn.ReLU())
+
+    def forward(self, *features):
+        a = self.up(self.aspp(features[-1]))
+        hi = self.block1(features[-4])
+        return self.block2(torch.cat([a, hi], dim=1))
+
+    # ---- eval fusion -----------------------------------------------------------------
+    @torch.no_grad()
+    def aspp_fused(self, x: torch.Tensor) -> torch.Tensor:
+        """ASPP + projection for eval: x [B,2048,h,w] -> [B,256,h,w].
+        One HIP pass produces the three atrous depthwise maps; each branch is then a GEMM with
+        BatchNorm folded into its weights, and the 1x1 projection is accumulated branch by
+        branch (project(cat(b_i)) = sum_i b_i @ P_i) so the 1280-channel concat never exists."""
+        aspp: ASPP = self.aspp[0]
+        B, Cin, h, w = x.shape
+        xl = x.permute(0, 2, 3, 1).contiguous()                      # NHWC (free when x is channels_last)
+        flat = xl.view(B * h * w, Cin)
+        Cout = self.out_channels
+        P = aspp.project[0].weight.view(Cout, 5 * Cout)              # [out, 5*in]
+        ps, pb = _bn_fold(aspp.project[1])
+
+        def branch(inp, wmat, bn):
+            s, b = _bn_fold(bn)
+            return torch.addmm(b, inp, (wmat * s[:, None]).t()).relu_()
+
+        acc = None
+        # branch 0: 1x1
+        y = branch(flat, aspp.convs[0][0].weight.view(Cout, Cin), aspp.convs[0][1])
+        acc = y @ P[:, 0:Cout].t()
+        # branches 1-3: depthwise (HIP, all three rates at once) then pointwise GEMM
+        wdw = torch.stack([aspp.convs[1 + r][0][0].weight.view(Cin, 9).t() for r in range(3)]).contiguous()  # [3,9,C]
+        dw = ops.aspp_depthwise3(xl, wdw, aspp.rates).view(3, B * h * w, Cin)
+        for r in range(3):
+            mod = aspp.convs[1 + r]
+            y = branch(dw[r], mod[0][1].weight.view(Cout, Cin), mod[1])
+            acc.addmm_(y, P[:, (1 + r) * Cout:(2 + r) * Cout].t())
+        # pooling branch: global mean -> 1x1 -> BN -> ReLU; bilinear upsample of a 1x1 map is a broadcast
+        pool = aspp.convs[4]
+        g = branch(xl.mean(dim=(1, 2)), pool[1].weight.view(Cout, Cin), pool[2])       # [B,256]
+        gproj = g @ P[:, 4 * Cout:5 * Cout].t()                                       # [B,256]
+        acc = acc.view(B, h * w, Cout) + gproj[:, None, :]
+        out = (acc * ps + pb).relu_()                                                 # project BN + ReLU (Dropout: eval)
+        return out.view(B, h, w, Cout).permute(0, 3, 1, 2)                            # NCHW view, channels_last memory
+
+    @torch.no_grad()
+    def forward_fused(self, *features):
+        a = self.aspp_fused(features[-1])
+        a = self.aspp[3](self.aspp[2](self.aspp[1](a)))
+        a = self.up(a)
+        hi = self.block1(features[-4])
+        return self.block2(torch.cat([a, hi], dim=1))
+
+
+class SegmentationHead(nn.Sequential):
+    def __init__(self, in_ch, out_ch, kernel_size=1, upsampling=4):
+        super().__init__(nn.Conv2d(in_ch, out_ch, kernel_size, padding=kernel_size // 2),
+                         nn.UpsamplingBilinear2d(scale_factor=upsampling) if upsampling > 1 else nn.Identity(),
+                         nn.Identity())
+
+
+class DeepLabV3Plus(nn.Module):
+    """smp.DeepLabV3Plus(encoder_name, encoder_weights=None, classes, activation=None) counterpart."""
+
+    def __init__(self, encoder_name="resnet50", classes=19, encoder_output_stride=16, decoder_channels=256,
+                 decoder_atrous_rates=(12, 24, 36), upsampling=4):
+        super().__init__()
+        self.encoder = ResNetEncoder(encoder_name, encoder_output_stride)
+        self.decoder = DeepLabV3PlusDecoder(self.encoder.out_channels, decoder_channels, decoder_atrous_rates,
+                                            encoder_output_stride)
+        self.segmentation_head = SegmentationHead(decoder_channels, classes, 1, upsampling)
+        for m in list(self.decoder.modules()) + list(self.segmentation_head.modules()):   # smp initialize_decoder/head
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_uniform_(m.weight, mode="fan_in", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.constant_(m.weight, 1)
+                nn.init.constant_(m.bias, 0)
+        nn.init.xavier_uniform_(self.segmentation_head[0].weight)
+
+    def forward(self, x):
+        feats = self.encoder(x)
+        return self.segmentation_head(self.decoder(*feats))
+
+    @torch.no_grad()
+    def forward_fused(self, x, return_features=False):
+        feats = self.encoder(x)
+        out = self.segmentation_head(self.decoder.forward_fused(*feats))
+        return (out, feats[-1]) if return_features else out

@@ -1,0 +1,108 @@
+"""One-process-per-GPU data parallelism for the hot path.
+
+Evaluation shards the image index range over ranks with NO data-path collective; the only
+exchange is one SUM all-reduce of the int64 counters (6 x 19 x 19 confusion + ECE bins, ~20 KB —
+latency-bound, xGMI topology irrelevant) at the end.  Integer sums are order-independent, so
+the pooled mIoU is bit-identical at any GPU count.  Training all-reduces flattened gradient
+buckets (RCCL ring/tree over the 7 xGMI links) — see `GradientBuckets`.
+Backend "nccl" IS RCCL on ROCm; CPU tests use "gloo".
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """(rank, local_rank, world_size); initialises the default group when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def is_dist() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def shard_range(n: int, rank: int, world: int) -> range:
+    """Contiguous block of sample indices owned by `rank` (ceil-sized blocks, tail rank may be short)."""
+    per = (n + world - 1) // world
+    return range(min(rank * per, n), min((rank + 1) * per, n))
+
+
+def all_reduce_sum_(tensors: Iterable[torch.Tensor]) -> None:
+    """In-place SUM all-reduce of several small counter tensors as ONE message per dtype."""
+    if not is_dist():
+        return
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for group in by_dtype.values():
+        flat = torch.cat([t.reshape(-1) for t in group])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        off = 0
+        for t in group:
+            n = t.numel()
+            t.copy_(flat[off:off + n].view_as(t))
+            off += n
+
+
+def barrier() -> None:
+    if is_dist():
+        dist.barrier()
+
+
+class GradientBuckets:
+    """Bucketed gradient averaging for the trainer (classic DP; BatchNorm stays per rank, as the
+    reference has no SyncBN).  Parameters are grouped into ~`bucket_mb` flat buckets in reverse
+    registration order (≈ backward order) and each bucket is all-reduced asynchronously on RCCL's
+    stream as soon as it is packed; `finish()` waits and scatters the averages back.  With ~36 M
+    fp32 parameters (144 MB) and 7 x 153 GB/s xGMI links, 25-50 MB buckets keep every link busy
+    without serialising behind one giant message."""
+
+    def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 32.0) -> None:
+        self.params = [p for p in params if p.requires_grad]
+        cap = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets, cur, size = [], [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            size += p.numel()
+            if size >= cap:
+                self.buckets.append(cur)
+                cur, size = [], 0
+        if cur:
+            self.buckets.append(cur)
+
+    def all_reduce_(self) -> None:
+        if not is_dist():
+            return
+        world = dist.get_world_size()
+        pending = []
+        for bucket in self.buckets:
+            grads = [p.grad for p in bucket if p.grad is not None]
+            if not grads:
+                continue
+            flat = torch.cat([g.reshape(-1) for g in grads])
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+            pending.append((work, flat, grads))
+        for work, flat, grads in pending:
+            work.wait()
+            flat.div_(world)
+            off = 0
+            for g in grads:
+                n = g.numel()
+                g.copy_(flat[off:off + n].view_as(g))
+                off += n

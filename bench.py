@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""bench.py — images/s of the north-star hot path on MI355X.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the hot path over one batch of B synthetic 1024x2048 frames that are
+already resident in HBM as uint8 HWC (+ uint8 labels):
+
+    weather corruption (round-robin clean/fog/rain/snow/night, in-kernel Philox noise)
+      -> fused Normalize/ToTensor -> SegFormer-B0 + DeepLabV3+-R50 ensemble forward (fp32)
+      -> combine / temperature / argmax / 19x19 confusion (overall + per condition) in one pass
+
+After the K timed steps the int64 counters are SUM-all-reduced over ranks (RCCL) and the mIoU /
+degradation ratios are finished on the host — inside the timed region.  Weak scaling: every rank
+runs its own B frames per step; value = N*B*K / max-over-ranks time.
+
+The line also carries `roofline` for the dominant hand-written kernel (HIP events recorded around
+every launch of it on the launching stream, inside the timed region) and `cpu_baseline` (the CPU
+oracle path timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+
+
+class KernelClock:
+    """HIP event pairs around named launches on the current torch stream (the stream the C ABI
+    launches on).  Reading happens after the timed region is synchronised."""
+
+    def __init__(self):
+        self.enabled = False
+        self.pairs = {}
+
+    def wrap(self, name, fn, *a, **k):
+        if not self.enabled:
+            return fn(*a, **k)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = fn(*a, **k)
+        e.record()
+        self.pairs.setdefault(name, []).append((s, e))
+        return out
+
+    def summary(self):
+        return {n: (len(p), sum(s.elapsed_time(e) for s, e in p) / len(p)) for n, p in self.pairs.items()}
+
+
+CLOCK = KernelClock()
+
+
+def instrument(ops):
+    """Time every hand-written kernel family by wrapping the ops entry points (no change in work)."""
+    for name in ("fog", "night", "rain", "snow", "normalize", "segformer_head_fused", "aspp_depthwise3",
+                 "combine_argmax_confusion"):
+        orig = getattr(ops, name)
+
+        def make(n, f):
+            return lambda *a, **k: CLOCK.wrap(n, f, *a, **k)
+        setattr(ops, name, make(name, orig))
+
+
+def algorithmic_work(name, B, H, W, C, info):
+    """Algorithmic bytes (or flops) per launch, SURVEY §8(d) per-unit figure x units per launch."""
+    px = H * W
+    n = info.get(name + "_images", B)
+    if name == "fog":
+        return "hbm", (3 + 3 + 12) * px * n            # u8 in + (u8 out) + f32 CHW normalised out; Philox noise: 0 B
+    if name == "night":
+        return "hbm", (3 + 12) * px * n
+    if name in ("rain", "snow"):
+        return "hbm", (3 + 12) * px * n
+    if name == "normalize":
+        return "hbm", 15 * px * n
+    if name == "combine_argmax_confusion":
+        return "hbm", (2 * C * 4 + 1) * px * B         # two member logit maps in, labels in; nothing per-pixel out
+    if name == "aspp_depthwise3":
+        h, w = H // 16, W // 16
+        return "hbm", (2048 * 4 + 3 * 2048 * 4) * h * w * B
+    if name == "segformer_head_fused":
+        cmid, cout = info.get("head_cmid", 256), info.get("head_cout", C)
+        # restructured count: 36 gathers x Cmid + Cmid x Cout FMAs per pixel (x2 flops)
+        return "mfma", 2.0 * (36 * cmid + cmid * cout) * px * B
+    return "hbm", 0
+
+
+def cpu_baseline(model, H, W, C, seed=0):
+    """The CPU oracle path ("port") on this box's host cores: one 1024x2048 frame per weather
+    condition through the C oracle transforms, one frame through the as-written torch-CPU
+    ensemble forward, oracle combine/argmax/confusion.  Bounded sample; a reported baseline,
+    not the optimisation target."""
+    import copy
+    from oracle import cpu_oracle as O
+    O.build()
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    rs = np.random.RandomState(seed)
+    img = rs.randint(0, 255, (H, W, 3), dtype=np.uint8)
+    lab = rs.randint(0, C, (H, W)).astype(np.uint8)
+    np.random.seed(42)
+    t_weather = []
+    outs = {}
+    for cond in ("clean", "fog", "rain", "snow", "night"):
+        t0 = time.perf_counter()
+        o = O.apply_weather_effect(img, cond)
+        x = O.normalize(o)
+        t_weather.append(time.perf_counter() - t0)
+        outs[cond] = x
+    cpu_model = copy.deepcopy(model).cpu().eval()
+    for m in cpu_model.modules():
+        m.fused_eval = False
+    x = torch.from_numpy(outs["fog"][None])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        res = cpu_model(x)
+        t_fwd = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    pred = O.argmax(res["segmentation"].numpy())
+    O.confusion(pred, lab[None], C)
+    t_metric = time.perf_counter() - t0
+    per_image = float(np.mean(t_weather)) + t_fwd + t_metric
+    return {"value": 1.0 / per_image, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"5 frames {H}x{W} (one per condition) through the C oracle transforms (mean {np.mean(t_weather):.2f} s), "
+                      f"1 frame through the as-written torch-CPU ensemble forward ({t_fwd:.2f} s, torch threads={cores}), "
+                      f"oracle argmax+confusion ({t_metric:.2f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (README.md:125 batch size)")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--no-depth", action="store_true", help="build the ensemble with include_depth=False")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import ops, parallel
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import EnsembleModel
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.evaluation.metrics import RobustnessMetrics
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data.preprocessing import WeatherDegradationTransforms
+
+    rank, local, world = parallel.init_from_env()
+    assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+    B, H, W, C = args.batch, args.height, args.width, 19
+    conds_all = ["clean", "fog", "rain", "snow", "night"]
+
+    torch.manual_seed(42)
+    np.random.seed(42 + rank)
+    model = EnsembleModel(num_classes=C, include_depth=not args.no_depth, pretrained=False).to(dev).eval()
+    metrics = RobustnessMetrics(num_classes=C, weather_conditions=conds_all)
+    acc = metrics.new_accumulator(dev)
+    tf = WeatherDegradationTransforms(seed=1234 + rank, rng="philox", device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(42 + rank)
+    raw = torch.randint(0, 255, (B, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)      # loader.py:206
+    labels = torch.randint(0, C, (B, H, W), dtype=torch.uint8, device=dev, generator=gen)        # loader.py:231
+    image = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+    instrument(ops)
+    info = {"head_cmid": 256, "head_cout": C}
+
+    def step(i):
+        start = (rank * B + i * B * world) % len(conds_all)
+        conds = [conds_all[(start + k) % len(conds_all)] for k in range(B)]
+        for c in conds_all:
+            info[c + "_images"] = conds.count(c)
+        info["normalize_images"] = conds.count("clean")
+        tf.apply_batch(raw, conds, norm_out=image)
+        model.forward_eval(image, labels, acc.counts, acc.oob, acc.cond_ids(conds), want_logits=False, want_pred=False)
+
+    with torch.no_grad():
+        for i in range(args.warmup):
+            step(i)
+        acc.counts.zero_()
+        torch.cuda.synchronize()
+        parallel.barrier()
+        CLOCK.enabled = True
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i)
+        acc.all_reduce()
+        acc.check()
+        results = {"overall_miou": acc.miou(0)}
+        for k, name in enumerate(conds_all):
+            if acc.present(1 + k):
+                results[f"miou_{name}"] = acc.miou(1 + k)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        dt = time.perf_counter() - t0
+        CLOCK.enabled = False
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if parallel.is_dist():
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    total_images = B * args.steps * world
+
+    # ---- roofline of the dominant hand-written kernel (rank 0's launches) ----------------------
+    kernels = []
+    for name, (count, avg_ms) in CLOCK.summary().items():
+        bound, work = algorithmic_work(name, B, H, W, C, info)
+        if work <= 0 or avg_ms <= 0:
+            continue
+        if bound == "hbm":
+            achieved, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        else:
+            achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+        kernels.append({"kernel": name, "launches": count, "avg_ms": round(avg_ms, 4), "bound": bound,
+                        "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
+                        "time_share_of_step": round(count * avg_ms / (dt * 1e3), 4)})
+    kernels.sort(key=lambda k: -k["launches"] * k["avg_ms"])
+    roofline = None
+    if kernels:
+        k0 = kernels[0]
+        roofline = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
+                    "unit": k0["unit"], "frac": k0["frac"], "traffic": None}
+
+    if rank == 0:
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(model, H, W, C)
+            except Exception as e:  # noqa: BLE001
+                cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        line = {
+            "metric": "images/sec (1024x2048, 5 weather conds, ensemble eval)",
+            "value": round(total_images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ensemble_eval_{H}x{W}_5cond (BASELINE.json configs[1]: SegFormer-B0 + DeepLabV3+-R50, "
+                                   "all 5 weather conditions round-robin)", "per_gpu_batch": B, "global_batch": B * world,
+                       "include_depth": not args.no_depth, "weather_rng": "philox (in-kernel)", "ensemble_logits_materialised": False,
+                       "weights": "random init (no checkpoints offline)", "parallelism": f"batch-sharded x{world}, one int64 counter all-reduce"},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "miou": {k: round(v, 6) for k, v in results.items()},
+        }
+        print(json.dumps(line))
+    if parallel.is_dist():
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,7 @@ SIGNATURES = {
     "awseg_density_workspace": (c_i64, [c_i64, c_i64]),
     "awseg_fog_density_from_depth": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_segformer_head_fused": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "awseg_upconv3x3_bn_relu": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "awseg_aspp_depthwise3": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "awseg_ece_accumulate": (c_i, [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
 }
@@ -87,6 +88,16 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = lib().awseg_error_string(rc)
         raise AwsegError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+launch_hook = None     # bench.py installs a (name, thunk) -> rc wrapper to time launches with HIP events
+
+
+def call(name: str, *args) -> None:
+    """Invoke one C-ABI launcher and raise on a non-zero return code."""
+    fn = getattr(lib(), name)
+    rc = fn(*args) if launch_hook is None else launch_hook(name, lambda: fn(*args))
+    check(rc, name)
 
 
 def ptr(t):

@@ -7,6 +7,7 @@
 // caller runs once).  The 2.15 GB / image full-resolution 256-channel tensor and 2.47 TFLOP /
 // image of the as-written op never exist; per pixel we spend 36 gathers x Cmid + Cmid x Cout.
 #include "awseg_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -81,6 +82,199 @@ void segformer_head_kernel(const float* __restrict__ g9, int cmid, int h, int w,
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// v2 (MFMA): the same arithmetic as two chained fp32 GEMMs per 32-pixel row segment, on
+// v_mfma_f32_32x32x2_f32 (exact fp32 = fmaf chain, 157 TF peak).  Block = 32 px x R rows,
+// 8 waves; every wave owns whole row segments.
+//
+//   stage 0  the <= 3 x 4 low-res cells the tile can touch (x 9 taps x Cmid) are copied once
+//            into LDS (108 KB for Cmid = 256) — all later gathers are conflict-free ds_reads.
+//   GEMM 1   mid^T[o, px] = sum_k T[o, k] * cx[k, px],  k = (kx, cell column) in 12 slots:
+//            T[o,k] = sum_ky wy * G[cell row][cell col k][tap ky,kx][o]  (vertical taps folded on
+//            the VALU into the A operand), cx = horizontal bilinear weights (B operand, fixed
+//            per block).  Zero padding of the 3x3 = dropped taps.
+//   epilogue BatchNorm(eval)+ReLU on the accumulator registers.
+//   GEMM 2   logits^T[cls, px] = sum_o W2[cls, o] * mid^T[o, px]: the accumulator tile of GEMM 1
+//            IS the B operand (lane = pixel column, register = k), so nothing moves through LDS;
+//            the k order is the accumulator's row order and W2 is pre-permuted into registers.
+// Per 32 pixels: 6*OT + 16*OT MFMAs (OT = Cmid/32), i.e. 176 x 64 cycles for Cmid = 256.
+// ---------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int kHeadThreads = 512;
+
+template <int OT, bool CLASSIFY>
+__global__ __launch_bounds__(kHeadThreads, 2)
+void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, int R,
+                      const float* __restrict__ scale, const float* __restrict__ shift,
+                      const float* __restrict__ w2, const float* __restrict__ b2, int cout,
+                      float* __restrict__ out)
+{
+    constexpr int CM = OT * 32;
+    extern __shared__ float smem[];
+    float* Gl = smem;                       // [3 cell rows][4 cell cols][9 taps][CM]
+    float* s_scale = smem + 108 * CM;
+    float* s_shift = s_scale + CM;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lo = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, y0 = blockIdx.y * R, x0 = blockIdx.x * 32;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int ibase = bilinear_src(y0 > 0 ? y0 - 1 : 0, sh, h).i0;
+    const int jbase = bilinear_src(x0 > 0 ? x0 - 1 : 0, sw, w).i0;
+
+    const float* g = g9 + (int64_t)b * h * w * 9 * CM;
+    constexpr int CELL4 = 9 * CM / 4;       // float4 per cell
+    for (int i = tid; i < 12 * CELL4; i += kHeadThreads) {
+        int cell = i / CELL4, q = i - cell * CELL4;
+        int ci = ibase + (cell >> 2), cj = jbase + (cell & 3);
+        if (ci > h - 1) ci = h - 1;
+        if (cj > w - 1) cj = w - 1;
+        reinterpret_cast<float4*>(Gl)[i] = reinterpret_cast<const float4*>(g + ((int64_t)ci * w + cj) * 9 * CM)[q];
+    }
+    for (int i = tid; i < CM; i += kHeadThreads) { s_scale[i] = scale[i]; s_shift[i] = shift[i]; }
+
+    // B operand of GEMM 1: horizontal weights, lane (hh, lo = pixel), k = 2s + hh -> (kx, cell col)
+    float cx[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int k = 2 * s + hh, kx = k >> 2, c = k & 3;
+        const int xx = x0 + lo + kx - 1;
+        float v = 0.f;
+        if (xx >= 0 && xx < W && x0 + lo < W) {
+            src_idx sx = bilinear_src(xx, sw, w);
+            if (sx.i0 - jbase == c) v += sx.l0;
+            if (sx.i1 - jbase == c) v += sx.l1;
+        }
+        cx[s] = v;
+    }
+    // A operand of GEMM 2: W2 in the accumulator's row order, one float per (o-tile, k-step, lane),
+    // lane = (kk = hh, cls = lo); kept in LDS (32 KB at Cmid = 256) to stay under 256 VGPRs
+    float* s_w2 = s_shift + CM;             // [OT][16][64]
+    if (CLASSIFY) {
+        for (int i = tid; i < OT * 16 * 64; i += kHeadThreads) {
+            const int ln = i & 63, s2 = (i >> 6) & 15, ot = i >> 10;
+            const int cls = ln & 31, kk = ln >> 5;
+            const int o = ot * 32 + (s2 & 3) + 8 * (s2 >> 2) + 4 * kk;
+            s_w2[i] = (cls < cout) ? w2[(int64_t)cls * CM + o] : 0.f;
+        }
+    }
+    __syncthreads();
+
+    const int64_t HW = (int64_t)H * W;
+    for (int ry = wv; ry < R; ry += kHeadThreads / 64) {
+        const int y = y0 + ry;
+        if (y >= H) break;
+        // vertical taps of this row (wave-uniform)
+        int r0[3], r1[3]; float l0[3], l1[3]; bool ok[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            ok[ky] = (yy >= 0 && yy < H);
+            src_idx sy = bilinear_src(ok[ky] ? yy : 0, sh, h);
+            r0[ky] = sy.i0 - ibase; r1[ky] = sy.i1 - ibase; l0[ky] = sy.l0; l1[ky] = sy.l1;
+        }
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll 1
+        for (int ot = 0; ot < OT; ++ot) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const int k = 2 * s + hh, kx = k >> 2, c = k & 3;
+                float t = 0.f;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (ok[ky]) {
+                        const int tap = ky * 3 + kx;
+                        float a0 = Gl[((r0[ky] * 4 + c) * 9 + tap) * CM + ot * 32 + lo];
+                        float a1 = Gl[((r1[ky] * 4 + c) * 9 + tap) * CM + ot * 32 + lo];
+                        t = fmaf(l0[ky], a0, t);
+                        t = fmaf(l1[ky], a1, t);
+                    }
+                }
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t, cx[s], acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                float v = fmaf(acc[r], s_scale[o], s_shift[o]);
+                acc[r] = v > 0.f ? v : 0.f;
+            }
+            if (CLASSIFY) {
+#pragma unroll
+                for (int s2 = 0; s2 < 16; ++s2)
+                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w2[(ot * 16 + s2) * 64 + lane], acc[s2], acc2, 0, 0, 0);
+            } else if (x0 + lo < W) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    out[((int64_t)b * CM + o) * HW + (int64_t)y * W + x0 + lo] = acc[r];
+                }
+            }
+        }
+        if (CLASSIFY && x0 + lo < W) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cls = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (cls < cout) out[((int64_t)b * cout + cls) * HW + (int64_t)y * W + x0 + lo] = acc2[r] + b2[cls];
+            }
+        }
+    }
+}
+
+// host mirror of bilinear_src's i0 / i1 (same float expressions; file is built -ffp-contract=off)
+static void host_src(int dst, float scale, int in_size, int* i0, int* i1)
+{
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    if (s < 0.f) s = 0.f;
+    int a = (int)s;
+    if (a > in_size - 1) a = in_size - 1;
+    *i0 = a; *i1 = a + (a < in_size - 1 ? 1 : 0);
+}
+
+// Largest row count R <= 32 for which every tile touches <= 3 cell rows, and whether every
+// 32-pixel column tile touches <= 4 cell columns.  0 = geometry not supported by the MFMA path.
+static int mfma_tile_rows(int h, int w, int H, int W)
+{
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    for (int x0 = 0; x0 < W; x0 += 32) {
+        int a, b, c, d;
+        host_src(x0 > 0 ? x0 - 1 : 0, sw, w, &a, &b);
+        int xe = x0 + 32 < W ? x0 + 32 : W - 1;
+        host_src(xe, sw, w, &c, &d);
+        if (d - a > 3) return 0;
+    }
+    for (int R = 32; R >= 1; R >>= 1) {
+        bool good = true;
+        for (int y0 = 0; y0 < H && good; y0 += R) {
+            int a, b, c, d;
+            host_src(y0 > 0 ? y0 - 1 : 0, sh, h, &a, &b);
+            int ye = y0 + R < H ? y0 + R : H - 1;
+            host_src(ye, sh, h, &c, &d);
+            if (d - a > 2) good = false;
+        }
+        if (good) return R;
+    }
+    return 0;
+}
+
+template <int OT, bool CLASSIFY>
+static int launch_head_mfma(const float* g9, int64_t batch, int h, int w, int H, int W, int R, const float* scale,
+                            const float* shift, const float* w2, const float* b2, int cout, float* out, hipStream_t s)
+{
+    constexpr int CM = OT * 32;
+    const size_t lds = (size_t)(110 * CM + (CLASSIFY ? OT * 16 * 64 : 0)) * sizeof(float);
+    auto kern = head_mfma_kernel<OT, CLASSIFY>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((W + 31) / 32, (H + R - 1) / R, (unsigned)batch);
+    hipLaunchKernelGGL(kern, grid, dim3(kHeadThreads), lds, s, g9, h, w, H, W, R, scale, shift, w2, b2, cout, out);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // A9: depthwise atrous 3x3 for the three ASPP rates in one pass over x (NHWC, float4 over C).
 __global__ __launch_bounds__(kThreads)
 void aspp_dw3_kernel(const float* __restrict__ x, int64_t batch, int h, int w, int C,
@@ -121,21 +315,55 @@ void aspp_dw3_kernel(const float* __restrict__ x, int64_t batch, int h, int w, i
 
 }  // namespace
 
+static bool force_v1()
+{
+    const char* e = getenv("AWSEG_HEAD_V1");
+    return e && e[0] == '1';
+}
+
+static int head_dispatch(bool classify, const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
+                         const float* scale, const float* shift, const float* w2, const float* b2, int cout,
+                         float* out, hipStream_t s)
+{
+    if (!g9 || !scale || !shift || !out) return AWSEG_EINVAL;
+    if (classify && (!w2 || !b2 || cout < 1 || cout > 32)) return AWSEG_EINVAL;
+    if (batch < 1 || cmid < 1 || h < 1 || w < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (batch > 65535 || height > 65535) return AWSEG_ERANGE;
+    if ((int64_t)h * w * 9 * cmid > 0x7fffffffLL) return AWSEG_ERANGE;
+    const int R = ((cmid % 32) == 0 && cmid <= 256 && (((uintptr_t)g9 & 15) == 0) && !force_v1())
+                      ? mfma_tile_rows(h, w, height, width) : 0;
+    if (R > 0) {
+#define AWSEG_HEAD(OTV)                                                                                              \
+    case OTV:                                                                                                         \
+        return classify ? launch_head_mfma<OTV, true>(g9, batch, h, w, height, width, R, scale, shift, w2, b2, cout, out, s) \
+                        : launch_head_mfma<OTV, false>(g9, batch, h, w, height, width, R, scale, shift, w2, b2, cout, out, s);
+        switch (cmid / 32) {
+            AWSEG_HEAD(1) AWSEG_HEAD(2) AWSEG_HEAD(4) AWSEG_HEAD(8)
+            default: break;
+        }
+#undef AWSEG_HEAD
+    }
+    if (!classify) return AWSEG_ERANGE;             // the VALU path only implements the classifier form
+    const size_t lds = (size_t)HPX * cmid * sizeof(float);
+    if (lds > 60 * 1024) return AWSEG_ERANGE;
+    dim3 grid((width + HPX - 1) / HPX, height, (unsigned)batch);
+    hipLaunchKernelGGL(segformer_head_kernel, grid, dim3(kThreads), lds, s, g9, cmid, h, w, height, width,
+                       scale, shift, w2, b2, cout, out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 AWSEG_API int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
                                          const float* scale, const float* shift, const float* w2, const float* b2,
                                          int cout, float* out, awseg_stream_t stream)
 {
-    if (!g9 || !scale || !shift || !w2 || !b2 || !out) return AWSEG_EINVAL;
-    if (batch < 1 || cmid < 1 || h < 1 || w < 1 || height < 1 || width < 1 || cout < 1 || cout > 32) return AWSEG_EINVAL;
-    if (batch > 65535 || height > 65535) return AWSEG_ERANGE;
-    if ((int64_t)h * w * 9 * cmid > 0x7fffffffLL) return AWSEG_ERANGE;
-    const size_t lds = (size_t)HPX * cmid * sizeof(float);
-    if (lds > 96 * 1024) return AWSEG_ERANGE;
-    dim3 grid((width + HPX - 1) / HPX, height, (unsigned)batch);
-    hipLaunchKernelGGL(segformer_head_kernel, grid, dim3(kThreads), lds, awseg_s(stream), g9, cmid, h, w, height, width,
-                       scale, shift, w2, b2, cout, out);
-    AWSEG_LAUNCH_CHECK();
-    return 0;
+    return head_dispatch(true, g9, batch, cmid, h, w, height, width, scale, shift, w2, b2, cout, out, awseg_s(stream));
+}
+
+AWSEG_API int awseg_upconv3x3_bn_relu(const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
+                                      const float* scale, const float* shift, float* out, awseg_stream_t stream)
+{
+    return head_dispatch(false, g9, batch, cmid, h, w, height, width, scale, shift, nullptr, nullptr, 0, out, awseg_s(stream));
 }
 
 AWSEG_API int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int channels, const float* wdw,

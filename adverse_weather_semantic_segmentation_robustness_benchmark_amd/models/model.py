@@ -130,18 +130,10 @@ def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
 
 @torch.no_grad()
 def upconv3x3_bn_relu(feats, conv, bn, height, width):
-    """relu(bn(conv3x3(interpolate(feats)))) at full resolution via the fused HIP head with an
-    identity classifier block per 32 channels (keeps one kernel; Cout <= 32 per launch)."""
-    g9 = _head_g9(feats, conv)
+    """relu(bn(conv3x3(interpolate(feats)))) at full resolution (HIP, MFMA): the 256-channel
+    upsampled tensor in front of the conv is never materialised."""
     scale, shift = _fold_conv_bn(conv, bn)
-    cmid = conv.weight.shape[0]
-    outs = []
-    eye = torch.eye(cmid, device=feats.device, dtype=torch.float32)
-    zero = torch.zeros(32, device=feats.device, dtype=torch.float32)
-    for c0 in range(0, cmid, 32):
-        c1 = min(c0 + 32, cmid)
-        outs.append(ops.segformer_head_fused(g9, scale, shift, eye[c0:c1].contiguous(), zero[:c1 - c0], height, width))
-    return torch.cat(outs, dim=1)
+    return ops.upconv3x3_bn_relu(_head_g9(feats, conv), scale, shift, height, width)
 
 
 class SegFormerModel(nn.Module):

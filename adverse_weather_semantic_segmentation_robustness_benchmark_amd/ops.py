@@ -52,9 +52,9 @@ def confusion_accumulate(pred: torch.Tensor, label: torch.Tensor, num_classes: i
         wrap_u8 = label.dtype == torch.uint8
     n = pred.numel()
     ws = N.workspace.get(pred.device, N.lib().awseg_metrics_workspace(1, num_classes, n))
-    N.check(N.lib().awseg_confusion_accumulate(N.ptr(pred), N.label_dtype(pred), N.ptr(label), N.label_dtype(label), n,
+    N.call("awseg_confusion_accumulate", N.ptr(pred), N.label_dtype(pred), N.ptr(label), N.label_dtype(label), n,
                                                num_classes, ignore_index, int(wrap_u8), N.ptr(counts), N.ptr(oob),
-                                               N.ptr(ws), N.stream()), "awseg_confusion_accumulate")
+                                               N.ptr(ws), N.stream())
 
 
 def argmax(logits: torch.Tensor, out_dtype=torch.int64) -> torch.Tensor:
@@ -63,7 +63,7 @@ def argmax(logits: torch.Tensor, out_dtype=torch.int64) -> torch.Tensor:
     b, c = logits.shape[0], logits.shape[1]
     hw = logits[0, 0].numel()
     pred = torch.empty((b,) + tuple(logits.shape[2:]), dtype=out_dtype, device=logits.device)
-    N.check(N.lib().awseg_argmax(N.ptr(logits), b, c, hw, N.ptr(pred), N.label_dtype(pred), N.stream()), "awseg_argmax")
+    N.call("awseg_argmax", N.ptr(logits), b, c, hw, N.ptr(pred), N.label_dtype(pred), N.stream())
     return pred
 
 
@@ -91,17 +91,15 @@ def combine_argmax_confusion(seg1: torch.Tensor, seg2: Optional[torch.Tensor], m
     n_slots = 0 if counts is None else counts.shape[0]
     pdt = N.label_dtype(pred) if pred is not None else N.U8
     if seg2 is None:
-        rc = N.lib().awseg_argmax_confusion(N.ptr(seg1), b, c, hw, N.ptr(pred), pdt, N.ptr(label), ldt, ignore_index,
+        N.call("awseg_argmax_confusion", N.ptr(seg1), b, c, hw, N.ptr(pred), pdt, N.ptr(label), ldt, ignore_index,
                                             int(bool(wrap_u8)), N.ptr(cond), N.ptr(counts), n_slots, N.ptr(oob),
                                             N.ptr(ws), N.stream())
-        N.check(rc, "awseg_argmax_confusion")
         return seg1, pred
     seg2 = seg2.contiguous()
-    rc = N.lib().awseg_combine_argmax_confusion(N.ptr(seg1), N.ptr(seg2), b, c, hw, mode, N.ptr(weights),
+    N.call("awseg_combine_argmax_confusion", N.ptr(seg1), N.ptr(seg2), b, c, hw, mode, N.ptr(weights),
                                                 N.ptr(temperature), N.ptr(out), N.ptr(pred), pdt, N.ptr(label), ldt,
                                                 ignore_index, int(bool(wrap_u8)), N.ptr(cond), N.ptr(counts), n_slots,
                                                 N.ptr(oob), N.ptr(ws), N.stream())
-    N.check(rc, "awseg_combine_argmax_confusion")
     return out, pred
 
 
@@ -119,9 +117,8 @@ def ece_accumulate(logits: torch.Tensor, label: torch.Tensor, bins: torch.Tensor
     b, c = logits.shape[0], logits.shape[1]
     hw = logits[0, 0].numel()
     ws = N.workspace.get(logits.device, N.lib().awseg_metrics_workspace(b, c, hw))
-    N.check(N.lib().awseg_ece_accumulate(N.ptr(logits), b, c, hw, N.ptr(label), N.label_dtype(label), N.ptr(cond),
-                                         N.ptr(edges), bins.shape[1], N.ptr(bins), bins.shape[0], N.ptr(ws), N.stream()),
-            "awseg_ece_accumulate")
+    N.call("awseg_ece_accumulate", N.ptr(logits), b, c, hw, N.ptr(label), N.label_dtype(label), N.ptr(cond),
+                                         N.ptr(edges), bins.shape[1], N.ptr(bins), bins.shape[0], N.ptr(ws), N.stream())
 
 
 def ece_bins_to_numpy(bins: torch.Tensor) -> np.ndarray:
@@ -137,8 +134,8 @@ def normalize(imgs: torch.Tensor, out: Optional[torch.Tensor] = None, sel: Optio
     if out is None:
         out = torch.empty(b, 3, h, w, dtype=torch.float32, device=imgs.device)
     m, s = _mean_std(mean, std)
-    N.check(N.lib().awseg_normalize(N.ptr(imgs), b, h, w, N.ptr(sel), 0 if sel is None else sel.numel(), N.host(m),
-                                    N.host(s), N.ptr(out), N.stream()), "awseg_normalize")
+    N.call("awseg_normalize", N.ptr(imgs), b, h, w, N.ptr(sel), 0 if sel is None else sel.numel(), N.host(m),
+                                    N.host(s), N.ptr(out), N.stream())
     return out
 
 
@@ -192,8 +189,7 @@ def synthetic_depth(h: int, w: int, jobs: np.ndarray, device, noise: Optional[to
     """PKG/data/preprocessing.py:227-248 -> float64 [n_jobs,H,W]."""
     jd = N.jobs_to_device(jobs, device)
     out = torch.empty(len(jobs), h, w, dtype=torch.float64, device=device)
-    N.check(N.lib().awseg_synthetic_depth(h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out), N.stream()),
-            "awseg_synthetic_depth")
+    N.call("awseg_synthetic_depth", h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out), N.stream())
     return out
 
 
@@ -207,12 +203,11 @@ def fog(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = No
     jd = N.jobs_to_device(jobs, imgs.device)
     m, s = _mean_std(mean, std)
     if depth is not None:
-        N.check(N.lib().awseg_fog_apply(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(depth.contiguous()), N.ptr(out),
-                                        N.ptr(norm_out), N.host(m), N.host(s), N.stream()), "awseg_fog_apply")
+        N.call("awseg_fog_apply", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(depth.contiguous()), N.ptr(out),
+                                        N.ptr(norm_out), N.host(m), N.host(s), N.stream())
     else:
-        N.check(N.lib().awseg_fog_fused(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out),
-                                        N.ptr(norm_out), N.ptr(depth_out), N.host(m), N.host(s), N.stream()),
-                "awseg_fog_fused")
+        N.call("awseg_fog_fused", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out),
+                                        N.ptr(norm_out), N.ptr(depth_out), N.host(m), N.host(s), N.stream())
 
 
 def night(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = None, out=None, norm_out=None,
@@ -222,8 +217,8 @@ def night(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = 
     _, h, w, _ = imgs.shape
     jd = N.jobs_to_device(jobs, imgs.device)
     m, s = _mean_std(mean, std)
-    N.check(N.lib().awseg_night_apply(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(NIGHT_GAINS), N.ptr(out),
-                                      N.ptr(norm_out), N.host(m), N.host(s), N.stream()), "awseg_night_apply")
+    N.call("awseg_night_apply", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(NIGHT_GAINS), N.ptr(out),
+                                      N.ptr(norm_out), N.host(m), N.host(s), N.stream())
 
 
 def rain(imgs: torch.Tensor, jobs: np.ndarray, drops: np.ndarray, out=None, norm_out=None, mean=None, std=None) -> None:
@@ -233,8 +228,8 @@ def rain(imgs: torch.Tensor, jobs: np.ndarray, drops: np.ndarray, out=None, norm
     jd = N.jobs_to_device(jobs, imgs.device)
     pd = torch.from_numpy(np.ascontiguousarray(drops, dtype=np.int32)).to(imgs.device, non_blocking=True)
     m, s = _mean_std(mean, std)
-    N.check(N.lib().awseg_rain_apply(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
-                                     N.host(m), N.host(s), N.stream()), "awseg_rain_apply")
+    N.call("awseg_rain_apply", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
+                                     N.host(m), N.host(s), N.stream())
 
 
 def snow(imgs: torch.Tensor, jobs: np.ndarray, flakes: np.ndarray, out=None, norm_out=None, mean=None, std=None) -> None:
@@ -244,8 +239,8 @@ def snow(imgs: torch.Tensor, jobs: np.ndarray, flakes: np.ndarray, out=None, nor
     jd = N.jobs_to_device(jobs, imgs.device)
     pd = torch.from_numpy(np.ascontiguousarray(flakes, dtype=np.int32)).to(imgs.device, non_blocking=True)
     m, s = _mean_std(mean, std)
-    N.check(N.lib().awseg_snow_apply(N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
-                                     N.host(m), N.host(s), N.stream()), "awseg_snow_apply")
+    N.call("awseg_snow_apply", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
+                                     N.host(m), N.host(s), N.stream())
 
 
 _DENSITY_TABLE = {"fog": (0.5, 0.5), "rain": (0.3, 0.2), "snow": (0.3, 0.2)}   # trainer.py:501-509, else (0.1, 0)
@@ -256,8 +251,8 @@ def fog_density_field(conditions: Sequence[str], h: int, w: int, device, seed: i
     so = np.array([_DENSITY_TABLE.get(str(c), (0.1, 0.0)) for c in conditions], dtype=np.float32)
     sod = torch.from_numpy(so).to(device, non_blocking=True)
     out = torch.empty(len(conditions), h, w, dtype=torch.float32, device=device)
-    N.check(N.lib().awseg_fog_density_field(N.ptr(sod), len(conditions), h * w, seed & 0xFFFFFFFFFFFFFFFF, N.ptr(out),
-                                            N.stream()), "awseg_fog_density_field")
+    N.call("awseg_fog_density_field", N.ptr(sod), len(conditions), h * w, seed & 0xFFFFFFFFFFFFFFFF, N.ptr(out),
+                                            N.stream())
     return out
 
 
@@ -273,9 +268,9 @@ def fog_ce_forward(logits: torch.Tensor, label: torch.Tensor, density: Optional[
     mean = torch.empty(1, dtype=torch.float32, device=logits.device)
     pix = torch.empty((b,) + tuple(logits.shape[2:]), dtype=torch.float32, device=logits.device) if want_pixel else None
     dens = None if density is None else density.contiguous()
-    N.check(N.lib().awseg_fog_ce_forward(N.ptr(logits), N.ptr(label), N.label_dtype(label), N.ptr(dens), b, c, hw,
+    N.call("awseg_fog_ce_forward", N.ptr(logits), N.ptr(label), N.label_dtype(label), N.ptr(dens), b, c, hw,
                                          N.LOSS_FOCAL if focal else N.LOSS_CE, float(sensitivity), N.ptr(pix),
-                                         N.ptr(partials), N.ptr(mean), N.ptr(oob), N.stream()), "awseg_fog_ce_forward")
+                                         N.ptr(partials), N.ptr(mean), N.ptr(oob), N.stream())
     return mean, pix
 
 
@@ -286,9 +281,9 @@ def fog_ce_backward(logits, label, density, focal: bool, sensitivity: float, gra
     grad = torch.empty_like(logits)
     dens = None if density is None else density.contiguous()
     gs = grad_scale.to(torch.float32).reshape(1).contiguous()
-    N.check(N.lib().awseg_fog_ce_backward(N.ptr(logits), N.ptr(label), N.label_dtype(label), N.ptr(dens), b, c, hw,
+    N.call("awseg_fog_ce_backward", N.ptr(logits), N.ptr(label), N.label_dtype(label), N.ptr(dens), b, c, hw,
                                           N.LOSS_FOCAL if focal else N.LOSS_CE, float(sensitivity), N.ptr(gs), N.ptr(grad),
-                                          N.stream()), "awseg_fog_ce_backward")
+                                          N.stream())
     return grad
 
 
@@ -298,8 +293,7 @@ def fog_density_from_depth(depth: torch.Tensor) -> torch.Tensor:
     b, h, w = depth.shape
     ws = N.workspace.get(depth.device, N.lib().awseg_density_workspace(b, h * w), "density")
     out = torch.empty_like(depth)
-    N.check(N.lib().awseg_fog_density_from_depth(N.ptr(depth), b, h, w, N.ptr(out), N.ptr(ws), N.stream()),
-            "awseg_fog_density_from_depth")
+    N.call("awseg_fog_density_from_depth", N.ptr(depth), b, h, w, N.ptr(out), N.ptr(ws), N.stream())
     return out
 
 
@@ -311,9 +305,21 @@ def segformer_head_fused(g9: torch.Tensor, scale, shift, w2, b2, height: int, wi
     assert nine == 9
     cout = w2.shape[0]
     out = torch.empty(b, cout, height, width, dtype=torch.float32, device=g9.device)
-    N.check(N.lib().awseg_segformer_head_fused(N.ptr(g9), b, cmid, h, w, height, width, N.ptr(scale.contiguous()),
+    N.call("awseg_segformer_head_fused", N.ptr(g9), b, cmid, h, w, height, width, N.ptr(scale.contiguous()),
                                                N.ptr(shift.contiguous()), N.ptr(w2.contiguous()), N.ptr(b2.contiguous()),
-                                               cout, N.ptr(out), N.stream()), "awseg_segformer_head_fused")
+                                               cout, N.ptr(out), N.stream())
+    return out
+
+
+def upconv3x3_bn_relu(g9: torch.Tensor, scale, shift, height: int, width: int) -> torch.Tensor:
+    """relu(bn(conv3x3(interpolate(f)))) at full resolution without the upsampled tensor: the first
+    stage of the fused head only (DepthEstimationHead's first 3x3 on the SegFormer branch)."""
+    g9 = g9.contiguous()
+    b, h, w, nine, cmid = g9.shape
+    assert nine == 9
+    out = torch.empty(b, cmid, height, width, dtype=torch.float32, device=g9.device)
+    N.call("awseg_upconv3x3_bn_relu", N.ptr(g9), b, cmid, h, w, height, width, N.ptr(scale.contiguous()),
+                                            N.ptr(shift.contiguous()), N.ptr(out), N.stream())
     return out
 
 
@@ -323,6 +329,6 @@ def aspp_depthwise3(x_nhwc: torch.Tensor, wdw: torch.Tensor, rates) -> torch.Ten
     x = x_nhwc.contiguous()
     b, h, w, c = x.shape
     out = torch.empty(3, b, h, w, c, dtype=torch.float32, device=x.device)
-    N.check(N.lib().awseg_aspp_depthwise3(N.ptr(x), b, h, w, c, N.ptr(wdw.contiguous()), int(rates[0]), int(rates[1]),
-                                          int(rates[2]), N.ptr(out), N.stream()), "awseg_aspp_depthwise3")
+    N.call("awseg_aspp_depthwise3", N.ptr(x), b, h, w, c, N.ptr(wdw.contiguous()), int(rates[0]), int(rates[1]),
+                                          int(rates[2]), N.ptr(out), N.stream())
     return out

@@ -314,6 +314,15 @@ int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmid, int h, 
                                const float* w2, const float* b2, int cout,
                                float* out, awseg_stream_t stream);
 
+/* First stage only (no classifier): relu(bn(conv3x3(interpolate(f)))) written at full
+ * resolution, out float32 [B,Cmid,H,W].  Used for the first 3x3 of DepthEstimationHead on
+ * the SegFormer branch (PKG/models/model.py:42-45 applied to the upsampled features, :219-221).
+ * Needs the MFMA geometry (Cmid in {32,64,128,256}, upsample factor >= ~17); else AWSEG_ERANGE. */
+int awseg_upconv3x3_bn_relu(const float* g9, int64_t batch, int cmid, int h, int w,
+                            int height, int width,
+                            const float* scale, const float* shift,
+                            float* out, awseg_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  *  A9  DeepLabV3+ ASPP: depthwise atrous 3x3 of all three rates in one pass
  *       replaces the three SeparableConv2d depthwise halves of smp's ASPP

@@ -322,3 +322,38 @@ def test_aspp_depthwise3(ops):
     for r in range(3):
         ref = torch.nn.functional.conv2d(x, wdw[r], padding=rates[r], dilation=rates[r], groups=Cc)
         assert (out[r].permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("cfg", [(2, 256, 4, 6, 128, 192, 19), (1, 256, 3, 5, 96, 160, 19), (1, 128, 5, 3, 150, 100, 7),
+                                 (1, 64, 2, 2, 64, 64, 32), (1, 256, 32, 64, 1024, 2048, 19)])
+def test_segformer_head_mfma_vs_v1_and_torch(ops, cfg, monkeypatch):
+    """MFMA head (v2) vs the as-written torch op sequence and vs the VALU kernel (v1), incl. image
+    borders (zero padding of the 3x3), non-multiple-of-32 sizes and the full 1024x2048 geometry."""
+    B, cmid, h, w, H, W, cout = cfg
+    torch.manual_seed(sum(cfg))
+    cin = 32
+    feat = torch.randn(B, cin, h, w, device="cuda")
+    conv1 = torch.nn.Conv2d(cin, cmid, 3, padding=1).cuda()
+    bn = torch.nn.BatchNorm2d(cmid).cuda().eval()
+    conv2 = torch.nn.Conv2d(cmid, cout, 1).cuda()
+    with torch.no_grad():
+        bn.running_mean.uniform_(-0.3, 0.3); bn.running_var.uniform_(0.5, 2.0)
+        bn.weight.uniform_(0.5, 1.5); bn.bias.uniform_(-0.3, 0.3)
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        scale = (bn.weight * inv).contiguous()
+        shift = ((conv1.bias - bn.running_mean) * scale + bn.bias).contiguous()
+        g9 = torch.einsum("bchw,ockl->bhwklo", feat, conv1.weight).reshape(B, h, w, 9, cmid).contiguous()
+        w2 = conv2.weight.view(cout, cmid).contiguous()
+        got = ops.segformer_head_fused(g9, scale, shift, w2, conv2.bias, H, W)
+        if H * W <= 256 * 256:
+            up = torch.nn.functional.interpolate(feat, size=(H, W), mode="bilinear", align_corners=False)
+            mid_ref = torch.relu(bn(conv1(up)))
+            ref = conv2(mid_ref)
+            assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+            if cmid in (32, 64, 128, 256) and min(H / h, W / w) >= 17:
+                mid = ops.upconv3x3_bn_relu(g9, scale, shift, H, W)
+                assert (mid - mid_ref).abs().max().item() < 1e-4 * max(1.0, mid_ref.abs().max().item())
+        monkeypatch.setenv("AWSEG_HEAD_V1", "1")
+        v1 = ops.segformer_head_fused(g9, scale, shift, w2, conv2.bias, H, W)
+        monkeypatch.delenv("AWSEG_HEAD_V1")
+        assert (got - v1).abs().max().item() < 1e-4 * max(1.0, v1.abs().max().item())

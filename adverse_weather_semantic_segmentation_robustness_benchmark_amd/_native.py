@@ -19,6 +19,7 @@ LIB_PATH = _PKG / "libawseg_hip.so"
 U8, I64 = 0, 1
 COMBINE_WEIGHTED, COMBINE_MAXCONF, COMBINE_MEAN = 0, 1, 2
 LOSS_CE, LOSS_FOCAL = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 MAX_CLASSES = 32
 
 c_i, c_i64, c_u64, c_f, c_d, c_p = C.c_int, C.c_int64, C.c_uint64, C.c_float, C.c_double, C.c_void_p
@@ -54,8 +55,10 @@ SIGNATURES = {
     "awseg_density_workspace": (c_i64, [c_i64, c_i64]),
     "awseg_fog_density_from_depth": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_segformer_head_fused": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
-    "awseg_upconv3x3_bn_relu": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "awseg_upconv3x3_bn_relu": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
     "awseg_aspp_depthwise3": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "awseg_dwconv3x3_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
+    "awseg_bias_act_nhwc": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_i, c_p]),
     "awseg_ece_accumulate": (c_i, [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
 }
 

@@ -1,0 +1,109 @@
+// backbone.hip — channel-last helper kernels around the torch-ROCm backbones (A8/A9 callers).
+//
+// The profile of the first end-to-end build (profiles/r01_bench_step_kernels_v1.csv) showed that
+// MIOpen runs every fp32 depthwise 3x3 (MiT Mix-FFN `dwconv`, smp SeparableConv2d) through its
+// naive reference kernel (12.9 ms / step) and that eval-mode BatchNorm + ReLU + residual add are
+// three separate full passes (≈20 ms / step).  Both are HBM-bound elementwise / stencil work:
+//   * awseg_dwconv3x3_nhwc : depthwise 3x3 (stride 1, dilation d, zero pad d) on [B,H,W,C] with a
+//                            fused per-channel bias and activation (none / ReLU / exact GELU);
+//   * awseg_bias_act_nhwc  : y = act(x + bias[c] (+ residual)) in place — the epilogue of a
+//                            convolution whose BatchNorm scale has been folded into its weights.
+// float4 over the channel dimension (C % 4 == 0): 16 B per lane, 64 lanes = one 1 KiB line.
+#include "awseg_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+
+__device__ __forceinline__ float act1(float v, int act)
+{
+    if (act == 1) return v > 0.f ? v : 0.f;
+    if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // torch GELU (erf form)
+    return v;
+}
+__device__ __forceinline__ float4 act4(float4 v, int act)
+{
+    return make_float4(act1(v.x, act), act1(v.y, act), act1(v.z, act), act1(v.w, act));
+}
+
+__global__ __launch_bounds__(kThreads)
+void dwconv3x3_nhwc_kernel(const float* __restrict__ x, int64_t batch, int H, int W, int C, int dil,
+                           const float* __restrict__ w9, const float* __restrict__ bias, int act,
+                           float* __restrict__ out)
+{
+    const int c4n = C / 4;
+    const int64_t total = batch * H * W * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int c4 = (int)(i % c4n);
+        const int64_t p = i / c4n;
+        const int xx = (int)(p % W);
+        const int64_t t = p / W;
+        const int yy = (int)(t % H);
+        const int64_t b = t / H;
+        const float* xb = x + b * (int64_t)H * W * C;
+        float4 acc = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = yy + (ky - 1) * dil;
+            if (sy < 0 || sy >= H) continue;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int sx = xx + (kx - 1) * dil;
+                if (sx < 0 || sx >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(xb + ((int64_t)sy * W + sx) * C + c4 * 4);
+                const float4 k = *reinterpret_cast<const float4*>(w9 + (ky * 3 + kx) * C + c4 * 4);
+                acc.x = fmaf(v.x, k.x, acc.x); acc.y = fmaf(v.y, k.y, acc.y);
+                acc.z = fmaf(v.z, k.z, acc.z); acc.w = fmaf(v.w, k.w, acc.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + p * C + c4 * 4) = act4(acc, act);
+    }
+}
+
+__global__ __launch_bounds__(kThreads)
+void bias_act_nhwc_kernel(float* __restrict__ x, int64_t n_pixels, int C, const float* __restrict__ bias,
+                          const float* __restrict__ residual, int act)
+{
+    const int c4n = C / 4;
+    const int64_t total = n_pixels * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int c4 = (int)(i % c4n);
+        float4 v = reinterpret_cast<float4*>(x)[i];
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + c4 * 4);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (residual) {
+            const float4 r = reinterpret_cast<const float4*>(residual)[i];
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        reinterpret_cast<float4*>(x)[i] = act4(v, act);
+    }
+}
+
+}  // namespace
+
+AWSEG_API int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, int width, int channels, int dilation,
+                                   const float* w9, const float* bias, int act, float* out, awseg_stream_t stream)
+{
+    if (!x || !w9 || !out || batch < 1 || height < 1 || width < 1 || channels < 4 || (channels & 3) || dilation < 1) return AWSEG_EINVAL;
+    if (act < 0 || act > 2 || x == out) return AWSEG_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w9 & 15) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15))) return AWSEG_EALIGN;
+    const int64_t total = batch * height * width * (channels / 4);
+    hipLaunchKernelGGL(dwconv3x3_nhwc_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, batch,
+                       height, width, channels, dilation, w9, bias, act, out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_bias_act_nhwc(float* x, int64_t n_pixels, int channels, const float* bias, const float* residual,
+                                  int act, awseg_stream_t stream)
+{
+    if (!x || n_pixels < 1 || channels < 4 || (channels & 3) || act < 0 || act > 2) return AWSEG_EINVAL;
+    if (((uintptr_t)x & 15) || (bias && ((uintptr_t)bias & 15)) || (residual && ((uintptr_t)residual & 15))) return AWSEG_EALIGN;
+    const int64_t total = n_pixels * (channels / 4);
+    hipLaunchKernelGGL(bias_act_nhwc_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, n_pixels,
+                       channels, bias, residual, act);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

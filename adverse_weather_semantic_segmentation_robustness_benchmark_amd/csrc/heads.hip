@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kHeadThreads, 2)
 void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, int R,
                       const float* __restrict__ scale, const float* __restrict__ shift,
                       const float* __restrict__ w2, const float* __restrict__ b2, int cout,
-                      float* __restrict__ out)
+                      float* __restrict__ out, int out_nhwc)
 {
     constexpr int CM = OT * 32;
     extern __shared__ float smem[];
@@ -207,10 +207,19 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
                 for (int s2 = 0; s2 < 16; ++s2)
                     acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w2[(ot * 16 + s2) * 64 + lane], acc[s2], acc2, 0, 0, 0);
             } else if (x0 + lo < W) {
+                if (out_nhwc) {
+                    // a lane holds channels {8q+4hh .. 8q+4hh+3} of its pixel: four 16-byte stores; the two
+                    // half-waves fill adjacent halves of every 32-byte run
+                    float* px = out + (((int64_t)b * H + y) * W + x0 + lo) * CM + ot * 32 + 4 * hh;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                    out[((int64_t)b * CM + o) * HW + (int64_t)y * W + x0 + lo] = acc[r];
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<float4*>(px + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                        out[((int64_t)b * CM + o) * HW + (int64_t)y * W + x0 + lo] = acc[r];
+                    }
                 }
             }
         }
@@ -262,7 +271,8 @@ static int mfma_tile_rows(int h, int w, int H, int W)
 
 template <int OT, bool CLASSIFY>
 static int launch_head_mfma(const float* g9, int64_t batch, int h, int w, int H, int W, int R, const float* scale,
-                            const float* shift, const float* w2, const float* b2, int cout, float* out, hipStream_t s)
+                            const float* shift, const float* w2, const float* b2, int cout, float* out, int out_nhwc,
+                            hipStream_t s)
 {
     constexpr int CM = OT * 32;
     const size_t lds = (size_t)(110 * CM + (CLASSIFY ? OT * 16 * 64 : 0)) * sizeof(float);
@@ -270,7 +280,7 @@ static int launch_head_mfma(const float* g9, int64_t batch, int h, int w, int H,
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     dim3 grid((W + 31) / 32, (H + R - 1) / R, (unsigned)batch);
-    hipLaunchKernelGGL(kern, grid, dim3(kHeadThreads), lds, s, g9, h, w, H, W, R, scale, shift, w2, b2, cout, out);
+    hipLaunchKernelGGL(kern, grid, dim3(kHeadThreads), lds, s, g9, h, w, H, W, R, scale, shift, w2, b2, cout, out, out_nhwc);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -323,7 +333,7 @@ static bool force_v1()
 
 static int head_dispatch(bool classify, const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
                          const float* scale, const float* shift, const float* w2, const float* b2, int cout,
-                         float* out, hipStream_t s)
+                         float* out, int out_nhwc, hipStream_t s)
 {
     if (!g9 || !scale || !shift || !out) return AWSEG_EINVAL;
     if (classify && (!w2 || !b2 || cout < 1 || cout > 32)) return AWSEG_EINVAL;
@@ -335,8 +345,8 @@ static int head_dispatch(bool classify, const float* g9, int64_t batch, int cmid
     if (R > 0) {
 #define AWSEG_HEAD(OTV)                                                                                              \
     case OTV:                                                                                                         \
-        return classify ? launch_head_mfma<OTV, true>(g9, batch, h, w, height, width, R, scale, shift, w2, b2, cout, out, s) \
-                        : launch_head_mfma<OTV, false>(g9, batch, h, w, height, width, R, scale, shift, w2, b2, cout, out, s);
+        return classify ? launch_head_mfma<OTV, true>(g9, batch, h, w, height, width, R, scale, shift, w2, b2, cout, out, 0, s) \
+                        : launch_head_mfma<OTV, false>(g9, batch, h, w, height, width, R, scale, shift, w2, b2, cout, out, out_nhwc, s);
         switch (cmid / 32) {
             AWSEG_HEAD(1) AWSEG_HEAD(2) AWSEG_HEAD(4) AWSEG_HEAD(8)
             default: break;
@@ -357,13 +367,16 @@ AWSEG_API int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmi
                                          const float* scale, const float* shift, const float* w2, const float* b2,
                                          int cout, float* out, awseg_stream_t stream)
 {
-    return head_dispatch(true, g9, batch, cmid, h, w, height, width, scale, shift, w2, b2, cout, out, awseg_s(stream));
+    return head_dispatch(true, g9, batch, cmid, h, w, height, width, scale, shift, w2, b2, cout, out, 0, awseg_s(stream));
 }
 
 AWSEG_API int awseg_upconv3x3_bn_relu(const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
-                                      const float* scale, const float* shift, float* out, awseg_stream_t stream)
+                                      const float* scale, const float* shift, float* out, int channels_last,
+                                      awseg_stream_t stream)
 {
-    return head_dispatch(false, g9, batch, cmid, h, w, height, width, scale, shift, nullptr, nullptr, 0, out, awseg_s(stream));
+    if (channels_last && ((uintptr_t)out & 15)) return AWSEG_EALIGN;
+    return head_dispatch(false, g9, batch, cmid, h, w, height, width, scale, shift, nullptr, nullptr, 0, out,
+                         channels_last ? 1 : 0, awseg_s(stream));
 }
 
 AWSEG_API int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int channels, const float* wdw,

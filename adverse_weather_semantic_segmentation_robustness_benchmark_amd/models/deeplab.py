@@ -220,11 +220,14 @@ class DeepLabV3PlusDecoder(nn.Module):
 
     @torch.no_grad()
     def forward_fused(self, *features):
+        from . import fused
+        from .. import _native as N
         a = self.aspp_fused(features[-1])
-        a = self.aspp[3](self.aspp[2](self.aspp[1](a)))
+        a = fused.separable_bn_relu(a, self.aspp[1], self.aspp[2])          # SeparableConv2d -> BN -> ReLU
         a = self.up(a)
-        hi = self.block1(features[-4])
-        return self.block2(torch.cat([a, hi], dim=1))
+        hi = fused.conv_bn_act(features[-4], self.block1[0], self.block1[1], N.ACT_RELU)
+        cat = torch.cat([a, hi], dim=1).contiguous(memory_format=torch.channels_last)
+        return fused.separable_bn_relu(cat, self.block2[0], self.block2[1])
 
 
 class SegmentationHead(nn.Sequential):
@@ -260,6 +263,9 @@ class DeepLabV3Plus(nn.Module):
 
     @torch.no_grad()
     def forward_fused(self, x, return_features=False):
-        feats = self.encoder(x)
-        out = self.segmentation_head(self.decoder.forward_fused(*feats))
+        from . import fused
+        feats = fused.resnet_features(self.encoder, x)
+        dec = self.decoder.forward_fused(*feats)
+        low = self.segmentation_head[0](dec).contiguous()                   # [B,C,H/4,W/4] NCHW (small)
+        out = self.segmentation_head[1](low)                                # x4 bilinear, align_corners=True -> NCHW
         return (out, feats[-1]) if return_features else out

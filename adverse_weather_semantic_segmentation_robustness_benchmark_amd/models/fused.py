@@ -1,0 +1,164 @@
+"""Eval-mode executors for the two backbones: same parameters, same arithmetic, but laid out for
+MI355X (everything channel-last, no layout copies) and with the obvious fusions the module graphs
+miss.  They read the parameters of the standard modules (`transformers.SegformerModel`, the
+ResNet / decoder modules of `deeplab.py`), so state_dicts and training are untouched.
+
+What changes relative to the module graphs (profiles/r01_bench_step_kernels_v1.csv):
+  * eval BatchNorm is folded into the preceding convolution's weights (cached per parameter
+    version) and `+shift [+identity] -> ReLU` is ONE in-place HIP pass (awseg_bias_act_nhwc)
+    instead of BN, add and clamp kernels;
+  * fp32 depthwise 3x3 convolutions (MiT Mix-FFN, smp SeparableConv2d) run on
+    awseg_dwconv3x3_nhwc with bias + GELU fused, instead of MIOpen's naive reference kernel;
+  * MiT tokens stay [B,H,W,C]: the token<->NCHW transposes of the HF forward disappear
+    (a channels_last NCHW view of the same memory feeds the strided convolutions).
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import _native as N
+from .. import ops
+
+CL = torch.channels_last
+
+
+# --------------------------------------------------------------------------- parameter caches
+def _versions(*tensors):
+    return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
+
+
+def folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """(weight * bn_scale in channels_last, shift) for eval-mode Conv -> BN; cached on the modules
+    and recomputed whenever a parameter / running stat changes (in-place version counters)."""
+    key = _versions(conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    cache = getattr(conv, "_awseg_fold", None)
+    if cache is not None and cache[0] == key:
+        return cache[1], cache[2]
+    inv = torch.rsqrt(bn.running_var + bn.eps)
+    scale = bn.weight * inv
+    shift = bn.bias - bn.running_mean * scale
+    if conv.bias is not None:
+        shift = shift + conv.bias * scale
+    w = (conv.weight * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
+    conv._awseg_fold = (key, w, shift.contiguous())
+    return w, shift.contiguous()
+
+
+def cached(module: nn.Module, name: str, tensors, fn):
+    key = _versions(*tensors)
+    cache = getattr(module, "_awseg_" + name, None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    val = fn()
+    setattr(module, "_awseg_" + name, (key, val))
+    return val
+
+
+def dw_taps(conv: nn.Conv2d) -> torch.Tensor:
+    """[C,1,3,3] depthwise weight -> [9, C] tap-major."""
+    return cached(conv, "w9", [conv.weight], lambda: conv.weight.view(conv.weight.shape[0], 9).t().contiguous())
+
+
+def nhwc_view(t: torch.Tensor) -> torch.Tensor:
+    """[B,C,H,W] channels_last tensor -> contiguous [B,H,W,C] view of the same memory."""
+    if not t.is_contiguous(memory_format=CL):
+        t = t.contiguous(memory_format=CL)
+    v = t.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, residual: torch.Tensor = None) -> torch.Tensor:
+    """act(bn(conv(x)) [+ residual]) with x / result logically NCHW in channels_last memory."""
+    w, shift = folded_conv_bn(conv, bn)
+    y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+    if not y.is_contiguous(memory_format=CL):
+        y = y.contiguous(memory_format=CL)
+    ops.bias_act_nhwc_(y.permute(0, 2, 3, 1), shift, None if residual is None else nhwc_view(residual), act)
+    return y
+
+
+# --------------------------------------------------------------------------- ResNet encoder
+@torch.no_grad()
+def resnet_features(enc, x: torch.Tensor) -> List[torch.Tensor]:
+    """smp feature list [x, stem, layer1..layer4] of `deeplab.ResNetEncoder`, fused eval execution."""
+    x = x.contiguous(memory_format=CL)
+    feats = [x]
+    y = conv_bn_act(x, enc.conv1, enc.bn1, N.ACT_RELU)
+    feats.append(y)
+    y = enc.maxpool(y)
+    for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
+        for blk in layer:
+            out = conv_bn_act(y, blk.conv1, blk.bn1, N.ACT_RELU)
+            out = conv_bn_act(out, blk.conv2, blk.bn2, N.ACT_RELU)
+            idn = y if blk.downsample is None else conv_bn_act(y, blk.downsample[0], blk.downsample[1], N.ACT_NONE)
+            y = conv_bn_act(out, blk.conv3, blk.bn3, N.ACT_RELU, residual=idn)
+        feats.append(y)
+    return feats
+
+
+@torch.no_grad()
+def separable_bn_relu(x: torch.Tensor, sep, bn: nn.BatchNorm2d) -> torch.Tensor:
+    """smp SeparableConv2d(3x3 depthwise, 1x1 pointwise) -> BN -> ReLU on a channels_last tensor."""
+    dwc, pwc = sep[0], sep[1]
+    xl = nhwc_view(x)
+    B, H, W, C = xl.shape
+    d = ops.dwconv3x3_nhwc(xl, dw_taps(dwc), None, N.ACT_NONE, dilation=dwc.dilation[0])
+    w, shift = folded_conv_bn(pwc, bn)                                   # [Cout,Cin,1,1]
+    y = d.view(B * H * W, C) @ w.view(w.shape[0], C).t()
+    ops.bias_act_nhwc_(y, shift, None, N.ACT_RELU)
+    return y.view(B, H, W, -1).permute(0, 3, 1, 2)                       # NCHW view, channels_last memory
+
+
+# --------------------------------------------------------------------------- MiT encoder
+def _ln(t, ln: nn.LayerNorm):
+    return F.layer_norm(t, (t.shape[-1],), ln.weight, ln.bias, ln.eps)
+
+
+@torch.no_grad()
+def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
+    """Last-stage hidden state of transformers.SegformerModel as [B,h,w,C] (NHWC).  Same arithmetic
+    as the HF forward (modeling_segformer.py SegformerStage / Layer / Attention / MixMLP)."""
+    if not hasattr(seg, "stages"):
+        # other transformers versions name their sub-modules differently: use their own forward
+        return seg(x).last_hidden_state.permute(0, 2, 3, 1).contiguous()
+    t = x.contiguous(memory_format=CL)
+    tok = None
+    for st in seg.stages:
+        pe = st.patch_embeddings
+        w = cached(pe.proj, "wcl", [pe.proj.weight], lambda: pe.proj.weight.contiguous(memory_format=CL))
+        y = F.conv2d(t, w, pe.proj.bias, pe.proj.stride, pe.proj.padding)
+        tok = _ln(nhwc_view(y), pe.layer_norm)                               # [B,H,W,C]
+        B, H, W, C = tok.shape
+        for blk in st.blocks:
+            a = blk.attention
+            hcur = _ln(tok, blk.layernorm_before)
+            q = F.linear(hcur, a.q_proj.weight, a.q_proj.bias)
+            if a.sequence_reduction_ratio > 1:
+                sr = a.sequence_reduction
+                wsr = cached(sr.sequence_reduction, "wcl", [sr.sequence_reduction.weight],
+                             lambda: sr.sequence_reduction.weight.contiguous(memory_format=CL))
+                kv = F.conv2d(hcur.permute(0, 3, 1, 2), wsr, sr.sequence_reduction.bias, sr.sequence_reduction.stride)
+                kv = _ln(nhwc_view(kv), sr.layer_norm)
+            else:
+                kv = hcur
+            k = F.linear(kv, a.k_proj.weight, a.k_proj.bias)
+            v = F.linear(kv, a.v_proj.weight, a.v_proj.bias)
+            nh, d = a.num_attention_heads, a.head_dim
+            o = F.scaled_dot_product_attention(q.view(B, H * W, nh, d).transpose(1, 2), k.reshape(B, -1, nh, d).transpose(1, 2),
+                                               v.reshape(B, -1, nh, d).transpose(1, 2), scale=a.scaling)
+            o = F.linear(o.transpose(1, 2).reshape(B, H, W, C), a.o_proj.weight, a.o_proj.bias)
+            tok = tok + o
+            m = blk.mlp
+            hcur = F.linear(_ln(tok, blk.layernorm_after), m.fc1.weight, m.fc1.bias)
+            if getattr(seg.config, "hidden_act", "gelu") == "gelu":
+                hcur = ops.dwconv3x3_nhwc(hcur, dw_taps(m.dwconv.dwconv), m.dwconv.dwconv.bias, N.ACT_GELU)   # dwconv + GELU fused
+            else:
+                hcur = m.activation_fn(ops.dwconv3x3_nhwc(hcur, dw_taps(m.dwconv.dwconv), m.dwconv.dwconv.bias, N.ACT_NONE))
+            tok = tok + F.linear(hcur, m.fc2.weight, m.fc2.bias)
+        tok = _ln(tok, st.layer_norm)
+        t = tok.permute(0, 3, 1, 2)                                          # NCHW view (channels_last) for the next stage
+    return tok

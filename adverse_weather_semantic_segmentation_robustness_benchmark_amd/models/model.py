@@ -22,6 +22,7 @@ import torch.nn.functional as F
 
 from .. import _native as N
 from .. import ops
+from . import fused
 from .deeplab import DeepLabV3Plus, _bn_fold
 
 logger = logging.getLogger(__name__)
@@ -109,17 +110,25 @@ class DepthEstimationHead(nn.Module):
         rest (3x3 on the hidden map, 1x1, sigmoid) stays on MIOpen."""
         h = self.depth_head
         mid = upconv3x3_bn_relu(feats, h[0], h[1], height, width)            # [B,hidden,H,W]
-        y = F.relu(h[5](h[4](mid)), inplace=True)
+        y = fused.conv_bn_act(mid, h[4], h[5], N.ACT_RELU)
+        return torch.sigmoid(h[7](y)).contiguous()
+
+    @torch.no_grad()
+    def forward_fused(self, feats_cl: torch.Tensor) -> torch.Tensor:
+        """Eval path on a stride-16 feature map (DeepLab branch): BN folded, bias+ReLU one HIP pass."""
+        h = self.depth_head
+        y = fused.conv_bn_act(feats_cl, h[0], h[1], N.ACT_RELU)
+        y = fused.conv_bn_act(y, h[4], h[5], N.ACT_RELU)
         return torch.sigmoid(h[7](y))
 
 
-def _head_g9(feats: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
-    """The nine per-tap 1x1 products W_tap . f at the encoder's resolution: [B,h,w,9,Cmid]."""
-    B, Cin, h, w = feats.shape
+def _head_g9(tok: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
+    """The nine per-tap 1x1 products W_tap . f at the encoder's resolution: [B,h,w,9,Cmid].
+    `tok` is the encoder output as NHWC tokens [B,h,w,Cin]."""
+    B, h, w, Cin = tok.shape
     cmid = conv.weight.shape[0]
-    w1r = conv.weight.permute(1, 2, 3, 0).reshape(Cin, 9 * cmid)               # [c, tap*Cmid + o]
-    flat = feats.permute(0, 2, 3, 1).reshape(B * h * w, Cin)
-    return (flat @ w1r).view(B, h, w, 9, cmid)
+    w1r = fused.cached(conv, "w1r", [conv.weight], lambda: conv.weight.permute(1, 2, 3, 0).reshape(Cin, 9 * cmid).contiguous())
+    return (tok.reshape(B * h * w, Cin) @ w1r).view(B, h, w, 9, cmid)
 
 
 def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
@@ -133,7 +142,7 @@ def upconv3x3_bn_relu(feats, conv, bn, height, width):
     """relu(bn(conv3x3(interpolate(feats)))) at full resolution (HIP, MFMA): the 256-channel
     upsampled tensor in front of the conv is never materialised."""
     scale, shift = _fold_conv_bn(conv, bn)
-    return ops.upconv3x3_bn_relu(_head_g9(feats, conv), scale, shift, height, width)
+    return ops.upconv3x3_bn_relu(_head_g9(feats, conv), scale, shift, height, width, channels_last=True)
 
 
 class SegFormerModel(nn.Module):
@@ -178,7 +187,7 @@ class SegFormerModel(nn.Module):
             if not x.is_cuda:
                 raise N.AwsegError("eval-mode forward runs HIP kernels: it needs CUDA (HIP) tensors; no CPU fallback exists")
             with torch.no_grad():
-                return self._forward_hip(self.encode(x), H, W)
+                return self._forward_hip(fused.mit_features_nhwc(self.segformer, x), H, W)
         feats = self.encode(x)
         up = F.interpolate(feats, size=(H, W), mode="bilinear", align_corners=False)     # model.py:211
         results = {"segmentation": self.segmentation_head(up)}
@@ -239,7 +248,7 @@ class DeepLabV3PlusModel(nn.Module):
             if self.include_depth:
                 # the reference runs the encoder a second time here (model.py:358); in eval mode the
                 # result is identical, so the features of the first pass are reused
-                d = self.depth_head(enc)
+                d = self.depth_head.forward_fused(enc)
                 results["depth"] = F.interpolate(d, size=x.shape[2:], mode="bilinear", align_corners=False).contiguous()
             return results
 

@@ -311,16 +311,17 @@ def segformer_head_fused(g9: torch.Tensor, scale, shift, w2, b2, height: int, wi
     return out
 
 
-def upconv3x3_bn_relu(g9: torch.Tensor, scale, shift, height: int, width: int) -> torch.Tensor:
+def upconv3x3_bn_relu(g9: torch.Tensor, scale, shift, height: int, width: int, channels_last: bool = False) -> torch.Tensor:
     """relu(bn(conv3x3(interpolate(f)))) at full resolution without the upsampled tensor: the first
     stage of the fused head only (DepthEstimationHead's first 3x3 on the SegFormer branch)."""
     g9 = g9.contiguous()
     b, h, w, nine, cmid = g9.shape
     assert nine == 9
-    out = torch.empty(b, cmid, height, width, dtype=torch.float32, device=g9.device)
+    shape = (b, height, width, cmid) if channels_last else (b, cmid, height, width)
+    out = torch.empty(shape, dtype=torch.float32, device=g9.device)
     N.call("awseg_upconv3x3_bn_relu", N.ptr(g9), b, cmid, h, w, height, width, N.ptr(scale.contiguous()),
-                                            N.ptr(shift.contiguous()), N.ptr(out), N.stream())
-    return out
+           N.ptr(shift.contiguous()), N.ptr(out), int(channels_last), N.stream())
+    return out.permute(0, 3, 1, 2) if channels_last else out          # logical NCHW either way
 
 
 def aspp_depthwise3(x_nhwc: torch.Tensor, wdw: torch.Tensor, rates) -> torch.Tensor:
@@ -332,3 +333,24 @@ def aspp_depthwise3(x_nhwc: torch.Tensor, wdw: torch.Tensor, rates) -> torch.Ten
     N.call("awseg_aspp_depthwise3", N.ptr(x), b, h, w, c, N.ptr(wdw.contiguous()), int(rates[0]), int(rates[1]),
                                           int(rates[2]), N.ptr(out), N.stream())
     return out
+
+
+# ----------------------------------------------------------------------------- backbone helpers
+def dwconv3x3_nhwc(x: torch.Tensor, w9: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
+                   dilation: int = 1) -> torch.Tensor:
+    """Depthwise 3x3 (stride 1, zero pad = dilation) on [B,H,W,C] float32 with fused bias + activation.
+    w9 [9,C] (tap-major).  act: 0 none, 1 ReLU, 2 exact GELU."""
+    x = x.contiguous()
+    b, h, w, c = x.shape
+    out = torch.empty_like(x)
+    N.call("awseg_dwconv3x3_nhwc", N.ptr(x), b, h, w, c, int(dilation), N.ptr(w9.contiguous()),
+           N.ptr(None if bias is None else bias.contiguous()), int(act), N.ptr(out), N.stream())
+    return out
+
+
+def bias_act_nhwc_(x_nhwc: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
+                   act: int = 0) -> torch.Tensor:
+    """In place: x = act(x + bias[c] (+ residual)) on a contiguous [..., C] float32 tensor."""
+    c = x_nhwc.shape[-1]
+    N.call("awseg_bias_act_nhwc", N.ptr(x_nhwc), x_nhwc.numel() // c, c, N.ptr(bias), N.ptr(residual), int(act), N.stream())
+    return x_nhwc

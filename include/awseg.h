@@ -315,13 +315,13 @@ int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmid, int h, 
                                float* out, awseg_stream_t stream);
 
 /* First stage only (no classifier): relu(bn(conv3x3(interpolate(f)))) written at full
- * resolution, out float32 [B,Cmid,H,W].  Used for the first 3x3 of DepthEstimationHead on
+ * resolution, out float32 [B,Cmid,H,W] (channels_last = 0) or [B,H,W,Cmid] (channels_last = 1).  Used for the first 3x3 of DepthEstimationHead on
  * the SegFormer branch (PKG/models/model.py:42-45 applied to the upsampled features, :219-221).
  * Needs the MFMA geometry (Cmid in {32,64,128,256}, upsample factor >= ~17); else AWSEG_ERANGE. */
 int awseg_upconv3x3_bn_relu(const float* g9, int64_t batch, int cmid, int h, int w,
                             int height, int width,
                             const float* scale, const float* shift,
-                            float* out, awseg_stream_t stream);
+                            float* out, int channels_last, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A9  DeepLabV3+ ASPP: depthwise atrous 3x3 of all three rates in one pass
@@ -334,6 +334,28 @@ int awseg_upconv3x3_bn_relu(const float* g9, int64_t batch, int cmid, int h, int
 int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int channels,
                           const float* wdw, int rate0, int rate1, int rate2,
                           float* out, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  channel-last helpers around the torch-ROCm backbones (callers of A8 / A9)
+ * ------------------------------------------------------------------------- *
+ * awseg_dwconv3x3_nhwc: depthwise 3x3, stride 1, dilation d, zero padding d, on float32
+ * [B,H,W,C] (C % 4 == 0) with fused per-channel bias (nullable) and activation:
+ * act 0 none, 1 ReLU, 2 exact (erf) GELU.  w9 float32 [9 taps][C].  Replaces
+ * transformers' SegformerDepthWiseConv (nn.Conv2d(dim, dim, 3, 1, 1, groups=dim)) + GELU inside
+ * the encoder PKG/models/model.py:193 calls, and the depthwise halves of smp's SeparableConv2d
+ * in the DeepLabV3+ decoder (call site PKG/models/model.py:349).  out must not alias x.
+ */
+#define AWSEG_ACT_NONE 0
+#define AWSEG_ACT_RELU 1
+#define AWSEG_ACT_GELU 2
+int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, int width, int channels, int dilation,
+                         const float* w9, const float* bias, int act, float* out, awseg_stream_t stream);
+
+/* awseg_bias_act_nhwc: x = act(x + bias[c] (+ residual)) in place on float32 [n_pixels, C]:
+ * the epilogue of a convolution whose eval-mode BatchNorm scale was folded into its weights
+ * (Conv -> BN -> [+identity] -> ReLU of the ResNet bottlenecks behind PKG/models/model.py:349). */
+int awseg_bias_act_nhwc(float* x, int64_t n_pixels, int channels, const float* bias, const float* residual,
+                        int act, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  next #1  ConfidenceCalibration.compute_ece accumulators

@@ -357,3 +357,35 @@ def test_segformer_head_mfma_vs_v1_and_torch(ops, cfg, monkeypatch):
         v1 = ops.segformer_head_fused(g9, scale, shift, w2, conv2.bias, H, W)
         monkeypatch.delenv("AWSEG_HEAD_V1")
         assert (got - v1).abs().max().item() < 1e-4 * max(1.0, v1.abs().max().item())
+
+
+def test_dwconv3x3_nhwc_and_bias_act(ops):
+    torch.manual_seed(0)
+    B, H, W, Cc = 2, 17, 23, 24
+    x = torch.randn(B, Cc, H, W, device="cuda")
+    conv = torch.nn.Conv2d(Cc, Cc, 3, padding=1, groups=Cc).cuda()
+    xl = x.permute(0, 2, 3, 1).contiguous()
+    w9 = conv.weight.view(Cc, 9).t().contiguous()
+    with torch.no_grad():
+        ref = conv(x)
+        got = ops.dwconv3x3_nhwc(xl, w9, conv.bias, 0).permute(0, 3, 1, 2)
+        assert (got - ref).abs().max().item() < 1e-5
+        got = ops.dwconv3x3_nhwc(xl, w9, conv.bias, 2).permute(0, 3, 1, 2)
+        assert (got - torch.nn.functional.gelu(ref)).abs().max().item() < 1e-5
+        ref_d = torch.nn.functional.conv2d(x, conv.weight, None, padding=3, dilation=3, groups=Cc)
+        got = ops.dwconv3x3_nhwc(xl, w9, None, 1, dilation=3).permute(0, 3, 1, 2)
+        assert (got - torch.relu(ref_d)).abs().max().item() < 1e-5
+        y = torch.randn(B, H, W, Cc, device="cuda"); r = torch.randn_like(y); b = torch.randn(Cc, device="cuda")
+        exp = torch.relu(y + b + r)
+        assert torch.equal(ops.bias_act_nhwc_(y.clone(), b, r, 1), exp)
+        assert torch.equal(ops.bias_act_nhwc_(y.clone(), b, None, 0), y + b)
+
+
+def test_upconv_channels_last_matches_nchw(ops):
+    torch.manual_seed(1)
+    B, cmid, h, w, H, W = 1, 128, 3, 4, 96, 128
+    g9 = torch.randn(B, h, w, 9, cmid, device="cuda")
+    sc, sf = torch.rand(cmid, device="cuda") + 0.5, torch.randn(cmid, device="cuda") * 0.1
+    a = ops.upconv3x3_bn_relu(g9, sc, sf, H, W, channels_last=False)
+    b = ops.upconv3x3_bn_relu(g9, sc, sf, H, W, channels_last=True)
+    assert b.shape == a.shape and b.is_contiguous(memory_format=torch.channels_last) and torch.equal(a, b.contiguous())

@@ -177,3 +177,32 @@ def test_trainer_one_epoch(P, tmp_path):
     assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "scheduler_state_dict", "metrics", "config"}
     t.load_checkpoint(str(tmp_path / "ck" / "latest.pth"))
     assert t.current_epoch == 0
+
+
+def test_mit_fused_forward_matches_hf(P):
+    """NHWC functional MiT forward (HIP depthwise+GELU, no layout copies) vs transformers' own forward."""
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models import fused
+    torch.manual_seed(7)
+    m = P.SegFormerModel(num_classes=19, include_depth=False, pretrained=False).cuda().eval()
+    x = torch.randn(2, 3, 128, 160, device="cuda")
+    with torch.no_grad():
+        ref = m.encode(x)                                           # HF forward -> [B,C,h,w]
+        got = fused.mit_features_nhwc(m.segformer, x).permute(0, 3, 1, 2)
+    assert rel_err(got, ref) < 1e-4
+
+
+def test_resnet_fused_matches_modules(P):
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models import fused
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.deeplab import ResNetEncoder
+    torch.manual_seed(8)
+    enc = calibrate_bn(ResNetEncoder("resnet50")).cuda().eval()
+    x = torch.randn(1, 3, 96, 128, device="cuda")
+    with torch.no_grad():
+        ref = enc(x)
+        got = fused.resnet_features(enc, x)
+    for a, b in zip(got[1:], ref[1:]):
+        assert a.shape == b.shape and rel_err(a, b) < 1e-4
+    # fold cache follows in-place weight updates
+    with torch.no_grad():
+        enc.conv1.weight.mul_(0.5)
+        assert rel_err(fused.resnet_features(enc, x)[1], enc(x)[1]) < 1e-4

@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Per-kernel micro-benchmark: every hand-written kernel on a full batch (B frames of HxW of the
+SAME kind per launch), timed with HIP events over repeated launches on the launching stream, against
+its roofline.  Interleaved rounds in one process (cdna_hip_programming.md rule 24).
+
+    python tools/kernel_bench.py [--batch 8] [--height 1024] [--width 2048] [--iters 20] [--only fog,night]
+"""
+import argparse
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+from adverse_weather_semantic_segmentation_robustness_benchmark_amd import ops  # noqa: E402
+from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data import preprocessing as P  # noqa: E402
+
+HBM, MFMA = 8000.0, 157.3
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(iters):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record(); fn(); e.record()
+        torch.cuda.synchronize()
+        ts.append(s.elapsed_time(e))
+    ts.sort()
+    return ts[len(ts) // 2], ts[0]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", type=str, default="")
+    a = ap.parse_args()
+    B, H, W, C = a.batch, a.height, a.width, 19
+    px = H * W
+    dev = "cuda"
+    torch.manual_seed(0); np.random.seed(0)
+    imgs = torch.randint(0, 255, (B, H, W, 3), dtype=torch.uint8, device=dev)
+    out = torch.empty_like(imgs)
+    norm = torch.empty(B, 3, H, W, device=dev)
+    labels = torch.randint(0, C, (B, H, W), dtype=torch.uint8, device=dev)
+    idx = list(range(B))
+    cases = {}
+
+    fj = ops.fog_jobs(idx, [0.5] * B, list(range(1, B + 1)))
+    cases["fog_fused philox ->norm"] = (lambda: ops.fog(imgs, fj, norm_out=norm), "hbm", (3 + 12) * px * B)
+    cases["fog_fused philox ->u8"] = (lambda: ops.fog(imgs, fj, out=out), "hbm", (3 + 3) * px * B)
+    nj = ops.night_jobs(idx, [0.8] * B, [0.6] * B, list(range(1, B + 1)))
+    cases["night philox ->norm"] = (lambda: ops.night(imgs, nj, norm_out=norm), "hbm", (3 + 12) * px * B)
+    cases["night philox ->u8"] = (lambda: ops.night(imgs, nj, out=out), "hbm", (3 + 3) * px * B)
+    rd = [P.draw_rain(H, W, 0.5) for _ in range(B)]
+    rj, rp = ops.prim_jobs(idx, [d[0] for d in rd], [d[1] for d in rd])
+    cases["rain ->norm"] = (lambda: ops.rain(imgs, rj, rp, norm_out=norm), "hbm", (3 + 12) * px * B)
+    cases["rain ->u8"] = (lambda: ops.rain(imgs, rj, rp, out=out), "hbm", (3 + 3) * px * B)
+    sd = [P.draw_snow(H, W, 0.5) for _ in range(B)]
+    for ks in (3, 7):
+        sj, sp = ops.prim_jobs(idx, [d[0] for d in sd], [d[1] for d in sd], [ks] * B)
+        cases[f"snow k{ks} ->norm"] = (lambda sj=sj, sp=sp: ops.snow(imgs, sj, sp, norm_out=norm), "hbm", (3 + 12) * px * B)
+    cases["normalize"] = (lambda: ops.normalize(imgs, out=norm), "hbm", 15 * px * B)
+
+    s1 = torch.randn(B, C, H, W, device=dev); s2 = torch.randn(B, C, H, W, device=dev)
+    wts = torch.tensor([0.5, 0.5], device=dev); T = torch.ones(1, device=dev)
+    counts = ops.new_counts(C, dev, 6); oob = torch.zeros(1, dtype=torch.int64, device=dev)
+    cond = torch.tensor([i % 5 for i in range(B)], dtype=torch.int32, device=dev)
+    cases["combine+argmax+confusion (no logits out)"] = (
+        lambda: ops.combine_argmax_confusion(s1, s2, 0, wts, T, want_logits=False, label=labels, counts=counts, oob=oob, cond=cond),
+        "hbm", (2 * C * 4 + 1) * px * B)
+    cases["combine+argmax+confusion (+logits out)"] = (
+        lambda: ops.combine_argmax_confusion(s1, s2, 0, wts, T, want_logits=True, label=labels, counts=counts, oob=oob, cond=cond),
+        "hbm", (3 * C * 4 + 1) * px * B)
+    cases["argmax+confusion single model"] = (
+        lambda: ops.combine_argmax_confusion(s1, None, 3, want_logits=False, label=labels, counts=counts, oob=oob, cond=cond),
+        "hbm", (C * 4 + 1) * px * B)
+    pred = torch.randint(0, C, (B, H, W), dtype=torch.uint8, device=dev)
+    c1 = ops.new_counts(C, dev)
+    cases["confusion from u8 predictions"] = (lambda: ops.confusion_accumulate(pred, labels, C, c1, oob), "hbm", 2 * px * B)
+    dens = torch.rand(B, H, W, device=dev)
+    cases["fog_ce forward"] = (lambda: ops.fog_ce_forward(s1, labels, dens, False, 2.0, oob), "hbm", (C * 4 + 1 + 4) * px * B)
+    g = torch.ones(1, device=dev)
+    cases["fog_ce backward"] = (lambda: ops.fog_ce_backward(s1, labels, dens, False, 2.0, g), "hbm", (2 * C * 4 + 1 + 4) * px * B)
+    edges = torch.linspace(0, 1, 16).to(dev); bins = ops.new_ece_bins(15, dev, 6)
+    cases["ece accumulate"] = (lambda: ops.ece_accumulate(s1, labels, bins, edges, cond), "hbm", (C * 4 + 1) * px * B)
+
+    h, w = H // 32, W // 32
+    g9 = torch.randn(B, h, w, 9, 256, device=dev)
+    sc, sf = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1
+    w2, b2 = torch.randn(C, 256, device=dev) * 0.05, torch.zeros(C, device=dev)
+    cases["segformer_head_fused (MFMA)"] = (lambda: ops.segformer_head_fused(g9, sc, sf, w2, b2, H, W), "mfma",
+                                             2.0 * (12 * 256 + 256 * 32) * px * B)
+    g9d = torch.randn(B, h, w, 9, 128, device=dev)
+    cases["upconv3x3_bn_relu 128ch NHWC (MFMA)"] = (lambda: ops.upconv3x3_bn_relu(g9d, sc[:128].contiguous(), sf[:128].contiguous(), H, W, True),
+                                                     "mfma", 2.0 * (12 * 128) * px * B)
+    xa = torch.randn(B, H // 16, W // 16, 2048, device=dev); wdw = torch.randn(3, 9, 2048, device=dev)
+    cases["aspp_depthwise3"] = (lambda: ops.aspp_depthwise3(xa, wdw, (12, 24, 36)), "hbm", 4 * 2048 * 4 * (H // 16) * (W // 16) * B)
+    xd = torch.randn(B, H // 4, W // 4, 128, device=dev); w9 = torch.randn(9, 128, device=dev); bb = torch.randn(128, device=dev)
+    cases["dwconv3x3_nhwc+gelu 128ch @1/4"] = (lambda: ops.dwconv3x3_nhwc(xd, w9, bb, 2), "hbm", 2 * 128 * 4 * (H // 4) * (W // 4) * B)
+    xe = torch.randn(B, H // 4, W // 4, 256, device=dev); re_ = torch.randn_like(xe); b256 = torch.randn(256, device=dev)
+    cases["bias_act_nhwc +res 256ch @1/4"] = (lambda: ops.bias_act_nhwc_(xe, b256, re_, 1), "hbm", 3 * 256 * 4 * (H // 4) * (W // 4) * B)
+
+    only = [s for s in a.only.split(",") if s]
+    rows = []
+    for name, (fn, bound, work) in cases.items():
+        if only and not any(o in name for o in only):
+            continue
+        med, best = timeit(fn, a.iters)
+        if bound == "hbm":
+            ach, peak, unit = work / (med * 1e-3) / 1e9, HBM, "GB/s"
+        else:
+            ach, peak, unit = work / (med * 1e-3) / 1e12, MFMA, "TFLOP/s"
+        rows.append({"kernel": name, "median_ms": round(med, 4), "min_ms": round(best, 4), "bound": bound,
+                     "achieved": round(ach, 1), "unit": unit, "frac_of_peak": round(ach / peak, 3)})
+        print(f"{name:45s} {med:8.3f} ms (min {best:7.3f})  {ach:9.1f} {unit:8s} {100 * ach / peak:5.1f}% of {bound} peak", flush=True)
+    print(json.dumps({"batch": B, "height": H, "width": W, "rows": rows}))
+
+
+if __name__ == "__main__":
+    main()

@@ -159,53 +159,79 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
     }
     __syncthreads();
 
+    // classifier bias of the 16 classes this lane's accumulator rows hold
+    float b2v[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int cls = (r & 3) + 8 * (r >> 2) + 4 * hh;
+        b2v[r] = (CLASSIFY && cls < cout) ? b2[cls] : 0.f;
+    }
+    // lane part of the A-operand gather address: (cell col c, tap column kx) of k-slot 2s+hh, + o_local
+    int lbase[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int k = 2 * s + hh;
+        lbase[s] = ((k & 3) * 9 + (k >> 2)) * CM + lo;
+    }
     const int64_t HW = (int64_t)H * W;
     for (int ry = wv; ry < R; ry += kHeadThreads / 64) {
         const int y = y0 + ry;
         if (y >= H) break;
-        // vertical taps of this row (wave-uniform)
-        int r0[3], r1[3]; float l0[3], l1[3]; bool ok[3];
+        // vertical taps of this row: wave-uniform scalars; an out-of-image tap keeps a valid address
+        // and gets zero weights, so the gather below is branch-free
+        int ub[6]; float lw[6];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int yy = y + ky - 1;
-            ok[ky] = (yy >= 0 && yy < H);
-            src_idx sy = bilinear_src(ok[ky] ? yy : 0, sh, h);
-            r0[ky] = sy.i0 - ibase; r1[ky] = sy.i1 - ibase; l0[ky] = sy.l0; l1[ky] = sy.l1;
+            const bool ok = (yy >= 0 && yy < H);
+            src_idx sy = bilinear_src(ok ? yy : 0, sh, h);
+            const int r0 = __builtin_amdgcn_readfirstlane(sy.i0 - ibase), r1 = __builtin_amdgcn_readfirstlane(sy.i1 - ibase);
+            ub[2 * ky] = (r0 * 36 + ky * 3) * CM;
+            ub[2 * ky + 1] = (r1 * 36 + ky * 3) * CM;
+            lw[2 * ky] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ok ? sy.l0 : 0.f)));
+            lw[2 * ky + 1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ok ? sy.l1 : 0.f)));
         }
+        auto gather = [&](int ot, float* t) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const float* base = Gl + lbase[s] + ot * 32;
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 6; ++j) v = fmaf(lw[j], base[ub[j]], v);
+                t[s] = v;
+            }
+        };
         f32x16 acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        float tcur[6], tnext[6];
+        gather(0, tcur);
 #pragma unroll 1
         for (int ot = 0; ot < OT; ++ot) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-            for (int s = 0; s < 6; ++s) {
-                const int k = 2 * s + hh, kx = k >> 2, c = k & 3;
-                float t = 0.f;
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    if (ok[ky]) {
-                        const int tap = ky * 3 + kx;
-                        float a0 = Gl[((r0[ky] * 4 + c) * 9 + tap) * CM + ot * 32 + lo];
-                        float a1 = Gl[((r1[ky] * 4 + c) * 9 + tap) * CM + ot * 32 + lo];
-                        t = fmaf(l0[ky], a0, t);
-                        t = fmaf(l1[ky], a1, t);
-                    }
-                }
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(t, cx[s], acc, 0, 0, 0);
-            }
+            for (int s = 0; s < 6; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tcur[s], cx[s], acc, 0, 0, 0);
+            // operands that do not depend on the MFMA chain: next tile's A values, this tile's BN constants
+            // and classifier fragments — issued while the matrix pipe works
+            const int otn = ot + 1 < OT ? ot + 1 : ot;
+            gather(otn, tnext);
+            float bsc[16], bsh[16], wf[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                float v = fmaf(acc[r], s_scale[o], s_shift[o]);
+                bsc[r] = s_scale[o]; bsh[r] = s_shift[o];
+                if (CLASSIFY) wf[r] = s_w2[(ot * 16 + r) * 64 + lane];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float v = fmaf(acc[r], bsc[r], bsh[r]);
                 acc[r] = v > 0.f ? v : 0.f;
             }
             if (CLASSIFY) {
 #pragma unroll
-                for (int s2 = 0; s2 < 16; ++s2)
-                    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(s_w2[(ot * 16 + s2) * 64 + lane], acc[s2], acc2, 0, 0, 0);
+                for (int s2 = 0; s2 < 16; ++s2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s2], acc[s2], acc2, 0, 0, 0);
             } else if (x0 + lo < W) {
                 if (out_nhwc) {
                     // a lane holds channels {8q+4hh .. 8q+4hh+3} of its pixel: four 16-byte stores; the two
@@ -222,12 +248,14 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
                     }
                 }
             }
+#pragma unroll
+            for (int s = 0; s < 6; ++s) tcur[s] = tnext[s];
         }
         if (CLASSIFY && x0 + lo < W) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int cls = (r & 3) + 8 * (r >> 2) + 4 * hh;
-                if (cls < cout) out[((int64_t)b * cout + cls) * HW + (int64_t)y * W + x0 + lo] = acc2[r] + b2[cls];
+                if (cls < cout) out[((int64_t)b * cout + cls) * HW + (int64_t)y * W + x0 + lo] = acc2[r] + b2v[r];
             }
         }
     }

@@ -55,37 +55,33 @@ template <int DT> __device__ __forceinline__ int64_t awseg_ld_label(const void* 
     return ((const int64_t*)p)[i];
 }
 
-// Philox4x32-10 counter-based generator (throughput-mode noise; parity mode takes host draws).
+// Philox4x32-7 counter-based generator (Salmon et al., Random123: 7 rounds pass BigCrush) for the
+// throughput-mode noise; parity mode takes host draws instead.  One call = four uint32.
 struct awseg_philox {
-    uint32_t c[4];
-    __device__ __forceinline__ static void round(uint32_t* c, uint32_t k0, uint32_t k1)
-    {
-        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-        uint32_t hi0 = __umulhi(M0, c[0]), lo0 = M0 * c[0];
-        uint32_t hi1 = __umulhi(M1, c[2]), lo1 = M1 * c[2];
-        uint32_t n0 = hi1 ^ c[1] ^ k0, n1 = lo1, n2 = hi0 ^ c[3] ^ k1, n3 = lo0;
-        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
-    }
     __device__ __forceinline__ static void gen(uint64_t seed, uint64_t ctr, uint32_t stream, uint32_t out[4])
     {
-        uint32_t c[4] = { (uint32_t)ctr, (uint32_t)(ctr >> 32), stream, 0x9E3779B9u };
+        const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+        uint32_t c0 = (uint32_t)ctr, c1 = (uint32_t)(ctr >> 32), c2 = stream, c3 = 0x9E3779B9u;
         uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
 #pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            round(c, k0, k1);
+        for (int r = 0; r < 7; ++r) {
+            uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+            uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+            uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+            c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
             k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
         }
-        out[0] = c[0]; out[1] = c[1]; out[2] = c[2]; out[3] = c[3];
+        out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
     }
 };
-// two uint32 -> one N(0,1) pair (Box-Muller, float32; distribution-only parity)
+// two uint32 -> one N(0,1) pair (Box-Muller in float32 on the hardware transcendental units:
+// v_log_f32 is log2, v_sin/v_cos take their argument in revolutions).  Distribution-only parity.
 __device__ __forceinline__ void awseg_box_muller(uint32_t a, uint32_t b, float& n0, float& n1)
 {
     float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float u2 = ((float)(b >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    float r = sqrtf(-2.0f * __logf(u1));
-    float s, c;
-    __sincosf(6.28318530717958647692f * u2, &s, &c);
-    n0 = r * c; n1 = r * s;
+    float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);
+    float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));   // sqrt(-2 ln u1), ln = log2 * ln2
+    n0 = r * __builtin_amdgcn_cosf(u2);
+    n1 = r * __builtin_amdgcn_sinf(u2);
 }
 __device__ __forceinline__ float awseg_u01(uint32_t a) { return (float)(a >> 8) * (1.0f / 16777216.0f); }

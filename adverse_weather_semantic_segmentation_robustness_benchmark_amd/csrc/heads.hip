@@ -100,16 +100,15 @@ void segformer_head_kernel(const float* __restrict__ g9, int cmid, int h, int w,
 // Per 32 pixels: 6*OT + 16*OT MFMAs (OT = Cmid/32), i.e. 176 x 64 cycles for Cmid = 256.
 // ---------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int kHeadThreads = 512;
-
-template <int OT, bool CLASSIFY>
-__global__ __launch_bounds__(kHeadThreads, 2)
+template <int OT, bool CLASSIFY, int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4)
 void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, int R,
                       const float* __restrict__ scale, const float* __restrict__ shift,
                       const float* __restrict__ w2, const float* __restrict__ b2, int cout,
                       float* __restrict__ out, int out_nhwc)
 {
     constexpr int CM = OT * 32;
+    constexpr int kHeadThreads = NW * 64;
     extern __shared__ float smem[];
     float* Gl = smem;                       // [3 cell rows][4 cell cols][9 taps][CM]
     float* s_scale = smem + 108 * CM;
@@ -130,7 +129,8 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
         if (cj > w - 1) cj = w - 1;
         reinterpret_cast<float4*>(Gl)[i] = reinterpret_cast<const float4*>(g + ((int64_t)ci * w + cj) * 9 * CM)[q];
     }
-    for (int i = tid; i < CM; i += kHeadThreads) { s_scale[i] = scale[i]; s_shift[i] = shift[i]; }
+    const bool has_scale = (scale != nullptr);
+    for (int i = tid; i < CM; i += kHeadThreads) { s_scale[i] = has_scale ? scale[i] : 1.f; s_shift[i] = shift[i]; }
 
     // B operand of GEMM 1: horizontal weights, lane (hh, lo = pixel), k = 2s + hh -> (kx, cell col)
     float cx[6];
@@ -204,30 +204,34 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
         f32x16 acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-        float tcur[6], tnext[6];
-        gather(0, tcur);
-#pragma unroll 1
-        for (int ot = 0; ot < OT; ++ot) {
-            f32x16 acc;
+        // Software pipeline over the o-tiles with two accumulator tiles: while tile `ot` goes through
+        // BatchNorm/ReLU (VALU) and GEMM 2, GEMM 1 of tile ot+1 is already in the matrix pipe and the
+        // A operands of tile ot+2 are being gathered from LDS.
+        // accumulators start at the folded BatchNorm shift of their rows (the C input of the first MFMA)
+        auto gemm1 = [&](int ot, const float* t) {
+            f32x16 a;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) a[r] = has_scale ? 0.f : s_shift[ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh];
 #pragma unroll
-            for (int s = 0; s < 6; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(tcur[s], cx[s], acc, 0, 0, 0);
-            // operands that do not depend on the MFMA chain: next tile's A values, this tile's BN constants
-            // and classifier fragments — issued while the matrix pipe works
-            const int otn = ot + 1 < OT ? ot + 1 : ot;
-            gather(otn, tnext);
-            float bsc[16], bsh[16], wf[16];
+            for (int s = 0; s < 6; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(t[s], cx[s], a, 0, 0, 0);
+            return a;
+        };
+        auto finish = [&](int ot, f32x16& acc) {
+            float wf[16];
+            if (CLASSIFY) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-                bsc[r] = s_scale[o]; bsh[r] = s_shift[o];
-                if (CLASSIFY) wf[r] = s_w2[(ot * 16 + r) * 64 + lane];
+                for (int r = 0; r < 16; ++r) wf[r] = s_w2[(ot * 16 + r) * 64 + lane];
             }
+            if (has_scale) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = fmaf(acc[r], bsc[r], bsh[r]);
-                acc[r] = v > 0.f ? v : 0.f;
+                for (int r = 0; r < 16; ++r) {
+                    const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                    float v = fmaf(acc[r], s_scale[o], s_shift[o]);
+                    acc[r] = v > 0.f ? v : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
             }
             if (CLASSIFY) {
 #pragma unroll
@@ -248,8 +252,21 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
                     }
                 }
             }
-#pragma unroll
-            for (int s = 0; s < 6; ++s) tcur[s] = tnext[s];
+        };
+        float ta[6], tb[6];
+        gather(0, ta);
+        f32x16 accA = gemm1(0, ta), accB;
+        if (OT > 1) gather(1, tb);
+#pragma unroll 1
+        for (int ot = 0; ot < OT; ot += 2) {
+            if (ot + 1 < OT) accB = gemm1(ot + 1, tb);         // GEMM 1 of tile ot+1
+            if (ot + 2 < OT) gather(ot + 2, ta);
+            finish(ot, accA);                                  // BN/ReLU + GEMM 2 of tile ot
+            if (ot + 1 < OT) {
+                if (ot + 2 < OT) accA = gemm1(ot + 2, ta);     // GEMM 1 of tile ot+2
+                if (ot + 3 < OT) gather(ot + 3, tb);
+                finish(ot + 1, accB);
+            }
         }
         if (CLASSIFY && x0 + lo < W) {
 #pragma unroll
@@ -297,18 +314,24 @@ static int mfma_tile_rows(int h, int w, int H, int W)
     return 0;
 }
 
-template <int OT, bool CLASSIFY>
-static int launch_head_mfma(const float* g9, int64_t batch, int h, int w, int H, int W, int R, const float* scale,
+static int head_waves()
+{
+    const char* e = getenv("AWSEG_HEAD_WAVES");
+    return (e && e[0] == '4') ? 4 : 8;
+}
+
+template <int OT, bool CLASSIFY, int NW>
+static int launch_head_mfma_nw(const float* g9, int64_t batch, int h, int w, int H, int W, int R, const float* scale,
                             const float* shift, const float* w2, const float* b2, int cout, float* out, int out_nhwc,
                             hipStream_t s)
 {
     constexpr int CM = OT * 32;
     const size_t lds = (size_t)(110 * CM + (CLASSIFY ? OT * 16 * 64 : 0)) * sizeof(float);
-    auto kern = head_mfma_kernel<OT, CLASSIFY>;
+    auto kern = head_mfma_kernel<OT, CLASSIFY, NW>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     dim3 grid((W + 31) / 32, (H + R - 1) / R, (unsigned)batch);
-    hipLaunchKernelGGL(kern, grid, dim3(kHeadThreads), lds, s, g9, h, w, H, W, R, scale, shift, w2, b2, cout, out, out_nhwc);
+    hipLaunchKernelGGL(kern, grid, dim3(NW * 64), lds, s, g9, h, w, H, W, R, scale, shift, w2, b2, cout, out, out_nhwc);
     e = hipGetLastError();
     return e == hipSuccess ? 0 : (int)e;
 }
@@ -353,6 +376,16 @@ void aspp_dw3_kernel(const float* __restrict__ x, int64_t batch, int h, int w, i
 
 }  // namespace
 
+template <int OT, bool CLASSIFY>
+static int launch_head_mfma(const float* g9, int64_t batch, int h, int w, int H, int W, int R, const float* scale,
+                            const float* shift, const float* w2, const float* b2, int cout, float* out, int out_nhwc,
+                            hipStream_t s)
+{
+    if (head_waves() == 4)
+        return launch_head_mfma_nw<OT, CLASSIFY, 4>(g9, batch, h, w, H, W, R, scale, shift, w2, b2, cout, out, out_nhwc, s);
+    return launch_head_mfma_nw<OT, CLASSIFY, 8>(g9, batch, h, w, H, W, R, scale, shift, w2, b2, cout, out, out_nhwc, s);
+}
+
 static bool force_v1()
 {
     const char* e = getenv("AWSEG_HEAD_V1");
@@ -363,7 +396,7 @@ static int head_dispatch(bool classify, const float* g9, int64_t batch, int cmid
                          const float* scale, const float* shift, const float* w2, const float* b2, int cout,
                          float* out, int out_nhwc, hipStream_t s)
 {
-    if (!g9 || !scale || !shift || !out) return AWSEG_EINVAL;
+    if (!g9 || !shift || !out) return AWSEG_EINVAL;
     if (classify && (!w2 || !b2 || cout < 1 || cout > 32)) return AWSEG_EINVAL;
     if (batch < 1 || cmid < 1 || h < 1 || w < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
     if (batch > 65535 || height > 65535) return AWSEG_ERANGE;
@@ -381,7 +414,7 @@ static int head_dispatch(bool classify, const float* g9, int64_t batch, int cmid
         }
 #undef AWSEG_HEAD
     }
-    if (!classify) return AWSEG_ERANGE;             // the VALU path only implements the classifier form
+    if (!classify || !scale) return AWSEG_ERANGE;   // the VALU path implements the classifier form with explicit scale
     const size_t lds = (size_t)HPX * cmid * sizeof(float);
     if (lds > 60 * 1024) return AWSEG_ERANGE;
     dim3 grid((width + HPX - 1) / HPX, height, (unsigned)batch);

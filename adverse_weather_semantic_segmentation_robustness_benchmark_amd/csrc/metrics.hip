@@ -158,19 +158,30 @@ void combine_argmax_confusion_kernel(const float* __restrict__ seg1, const float
     }
 }
 
-// One block per image: fold that image's block partials into slot 0 and slot 1+cond[img].
+// Fold the per-block uint32 partial histograms of one image into slot 0 and slot 1+cond[img].
+// grid = (images, ceil(bins/64)); a block owns 64 bins and its 4 waves each sum a quarter of the
+// partials (independent, unrolled loads), then one LDS step combines them: the dependent-load
+// chain is blocks_per_image/4 long and the bins run in parallel across blocks.
 __global__ __launch_bounds__(kThreads)
 void fold_partials_kernel(const uint32_t* __restrict__ partial, int blocks_per_image, int bins,
                           const int32_t* __restrict__ cond, int n_slots, int64_t* __restrict__ counts)
 {
+    __shared__ unsigned long long s_sum[4][64];
     const int img = blockIdx.x;
+    const int k = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
     const uint32_t* src = partial + (int64_t)img * blocks_per_image * bins;
-    int slot = -1;
-    if (cond) { int c = cond[img]; if (c >= 0 && c + 1 < n_slots) slot = c + 1; }
-    for (int k = threadIdx.x; k < bins; k += kThreads) {
-        unsigned long long s = 0;
-        for (int b = 0; b < blocks_per_image; ++b) s += src[(int64_t)b * bins + k];
+    unsigned long long s = 0;
+    if (k < bins) {
+#pragma unroll 8
+        for (int b = slice; b < blocks_per_image; b += 4) s += src[(int64_t)b * bins + k];
+    }
+    s_sum[slice][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (slice == 0 && k < bins) {
+        s = s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x] + s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x];
         if (s) {
+            int slot = -1;
+            if (cond) { int c = cond[img]; if (c >= 0 && c + 1 < n_slots) slot = c + 1; }
             atomicAdd((unsigned long long*)&counts[k], s);
             if (slot > 0) atomicAdd((unsigned long long*)&counts[(int64_t)slot * bins + k], s);
         }
@@ -381,8 +392,8 @@ static int fused_impl(int mode, const float* seg1, const float* seg2, int64_t ba
 #undef AWSEG_MODE
     AWSEG_LAUNCH_CHECK();
     if (label) {
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)batch), dim3(kThreads), 0, s, partial, bpi, C * C, cond,
-                           n_slots, counts);
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)batch, (C * C + 63) / 64), dim3(kThreads), 0, s, partial, bpi,
+                           C * C, cond, n_slots, counts);
         AWSEG_LAUNCH_CHECK();
     }
     return 0;
@@ -426,8 +437,10 @@ AWSEG_API int awseg_confusion_accumulate(const void* pred, int pred_dtype, const
     if (num_classes < 1 || num_classes > AWSEG_MAX_CLASSES) return AWSEG_EINVAL;
     if (n == 0) return 0;
     hipStream_t s = awseg_s(stream);
-    // same block count as the workspace query: blocks_per_image(n, 1, 1)
-    const int nblk = blocks_per_image(n, 1, 1);
+    // never more blocks than the workspace query assumed (blocks_per_image(n, 1, 1)); one block
+    // covers 4096 pixels per sweep, 1024 blocks keep every CU busy
+    int nblk = blocks_per_image((n + 15) / 16, 1, 1);
+    if (nblk > 1024) nblk = 1024;
     uint32_t* partial = (uint32_t*)workspace;
     const bool al = aligned16(pred) && aligned16(label);
     (void)al;  // unaligned byte maps still work: the uint4 path requires 16-B alignment
@@ -442,8 +455,8 @@ AWSEG_API int awseg_confusion_accumulate(const void* pred, int pred_dtype, const
     else return AWSEG_EINVAL;
 #undef AWSEG_CONF
     AWSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(1), dim3(kThreads), 0, s, partial, nblk, num_classes * num_classes,
-                       (const int32_t*)nullptr, 1, counts);
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(1, (num_classes * num_classes + 63) / 64), dim3(kThreads), 0, s, partial, nblk,
+                       num_classes * num_classes, (const int32_t*)nullptr, 1, counts);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -35,6 +35,22 @@ __device__ __forceinline__ float norm1(uint8_t q, float mean, float std)
     return d / std;
 }
 
+// Per-block lookup tables (4 KB of LDS): u8 -> (float)u/255 (preprocessing.py:81) and, per channel,
+// u8 -> ((float)q/255 - mean)/std (loader.py:195-198).  Entries are produced by the very same
+// separately rounded float32 operations, so a lookup is bit-identical to computing in place — it
+// just replaces two IEEE divisions per value by one ds_read.
+struct weather_lut { float in[256]; float nrm[3][256]; };
+__device__ __forceinline__ void lut_fill(weather_lut& L, const norm_consts& nc, bool want_norm)
+{
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+        L.in[i] = (float)i / 255.0f;
+        if (want_norm) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) L.nrm[c][i] = norm1((uint8_t)i, nc.mean[c], nc.std[c]);
+        }
+    }
+}
+
 // scipy 'reflect' (d c b a | a b c d | d c b a)
 __device__ __forceinline__ int reflect_sym(int i, int n)
 {
@@ -202,6 +218,142 @@ void fog_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_fog_
     }
 }
 
+// Throughput-mode fog (noise == NULL): same algorithm with the noise drawn in-kernel (Philox, four
+// normals per call) and the depth pipeline in float32 — parity is only defined for host-drawn
+// noise (the float64 kernel above), so this variant trades the float64 ladder, whose ~110
+// double-precision operations per pixel cap that kernel well below the HBM roof, for 4x cheaper
+// arithmetic.  320 threads: 80 staged columns x 4 row segments in the vertical pass (8 outputs per
+// lane from a 24-value register window), 4 adjacent outputs per lane in the horizontal pass.
+constexpr int kFogFastThreads = 320;
+struct gauss_taps_f32 { float w[2 * FR + 1]; };
+
+__global__ __launch_bounds__(kFogFastThreads)
+void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_fog_job* __restrict__ jobs,
+                     gauss_taps_f32 taps, uint8_t* __restrict__ out, float* __restrict__ norm_out,
+                     double* __restrict__ depth_out, norm_consts nc)
+{
+    __shared__ float s_in[FIH * FIW];         // 15 KB
+    __shared__ float s_v[FTH * FIW];          // 10 KB
+    __shared__ weather_lut L;
+    lut_fill(L, nc, norm_out != nullptr);
+    const awseg_fog_job job = jobs[blockIdx.z];
+    const int64_t hw = (int64_t)H * W;
+    const int x0 = blockIdx.x * FTW, y0 = blockIdx.y * FTH;
+    const int64_t Wq = (W + 3) / 4;
+    const float inv_h = 100.0f / (float)H;
+    const bool interior_x = (x0 - FR >= 0) && (x0 + FTW + FR <= W) && ((W & 3) == 0);
+
+    // phase 1: (y/H)*100 + N(0,10) for the tile and its halo
+    if (interior_x) {
+        for (int i = threadIdx.x; i < FIH * (FIW / 4); i += kFogFastThreads) {
+            const int ty = i / (FIW / 4), tq = i - ty * (FIW / 4);
+            const int gy = reflect_sym(y0 - FR + ty, H), gx = x0 - FR + tq * 4;
+            uint32_t r[4]; float n0, n1, n2, n3;
+            awseg_philox::gen(job.seed, (uint64_t)gy * Wq + (gx >> 2), 0x0F06u, r);
+            awseg_box_muller(r[0], r[1], n0, n1);
+            awseg_box_muller(r[2], r[3], n2, n3);
+            const float base = (float)gy * inv_h;
+            *reinterpret_cast<float4*>(s_in + ty * FIW + tq * 4) =
+                make_float4(base + 10.f * n0, base + 10.f * n1, base + 10.f * n2, base + 10.f * n3);
+        }
+    } else {
+        for (int i = threadIdx.x; i < FIH * FIW; i += kFogFastThreads) {
+            const int ty = i / FIW, tx = i - ty * FIW;
+            const int gy = reflect_sym(y0 - FR + ty, H), gx = reflect_sym(x0 - FR + tx, W);
+            uint32_t r[4]; float n[4];
+            awseg_philox::gen(job.seed, (uint64_t)gy * Wq + (gx >> 2), 0x0F06u, r);
+            awseg_box_muller(r[0], r[1], n[0], n[1]);
+            awseg_box_muller(r[2], r[3], n[2], n[3]);
+            const int sel = gx & 3;
+            const float nv = sel == 0 ? n[0] : (sel == 1 ? n[1] : (sel == 2 ? n[2] : n[3]));
+            s_in[i] = (float)gy * inv_h + 10.f * nv;
+        }
+    }
+    __syncthreads();
+    // phase 2: axis-0 pass; lane = (staged column, segment of 8 rows), 24-value register window
+    {
+        const int col = threadIdx.x % FIW, seg = threadIdx.x / FIW;     // 80 x 4
+        float win[8 + 2 * FR];
+#pragma unroll
+        for (int k = 0; k < 8 + 2 * FR; ++k) win[k] = s_in[(seg * 8 + k) * FIW + col];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float o = win[k + FR] * taps.w[FR];
+#pragma unroll
+            for (int j = 1; j <= FR; ++j) o = fmaf(win[k + FR - j] + win[k + FR + j], taps.w[FR + j], o);
+            s_v[(seg * 8 + k) * FIW + col] = o;
+        }
+    }
+    __syncthreads();
+    // phase 3: axis-1 pass (4 adjacent outputs per lane) + transmission / blend / quantise
+    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
+    uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
+    float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
+    double* ddst = depth_out ? depth_out + (int64_t)blockIdx.z * hw : nullptr;
+    const float beta = (float)job.beta, A32 = (float)job.atmos;
+    for (int q = threadIdx.x; q < FTH * (FTW / 4); q += kFogFastThreads) {
+        const int ty = q / (FTW / 4), tq = q - ty * (FTW / 4);
+        const int gy = y0 + ty, gx = x0 + tq * 4;
+        if (gy >= H || gx >= W) continue;
+        float win[4 + 2 * FR];
+        const float* row = s_v + ty * FIW + tq * 4;
+#pragma unroll
+        for (int k = 0; k < (4 + 2 * FR) / 4; ++k) {
+            float4 t = *reinterpret_cast<const float4*>(row + 4 * k);
+            win[4 * k] = t.x; win[4 * k + 1] = t.y; win[4 * k + 2] = t.z; win[4 * k + 3] = t.w;
+        }
+        float depth[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float o = win[k + FR] * taps.w[FR];
+#pragma unroll
+            for (int j = 1; j <= FR; ++j) o = fmaf(win[k + FR - j] + win[k + FR + j], taps.w[FR + j], o);
+            depth[k] = o > 1.0f ? o : 1.0f;
+        }
+        const int nvalid = (W - gx) < 4 ? (W - gx) : 4;
+        const int64_t p = (int64_t)gy * W + gx;
+        if (ddst) for (int k = 0; k < nvalid; ++k) ddst[p + k] = (double)depth[k];
+        uint8_t px[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, res[12];
+        const bool vec = (nvalid == 4) && (((p * 3) & 3) == 0);
+        if (vec) {
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
+            uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { px[k] = (w0 >> (8 * k)) & 0xFF; px[4 + k] = (w1 >> (8 * k)) & 0xFF; px[8 + k] = (w2 >> (8 * k)) & 0xFF; }
+        } else {
+            for (int k = 0; k < nvalid * 3; ++k) px[k] = src[p * 3 + k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = __expf(-beta * depth[k]);
+            const float hz = A32 * (1.0f - t);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) res[k * 3 + c] = quant_f32(fmaf(L.in[px[k * 3 + c]], t, hz));
+        }
+        if (dst) {
+            if (vec) {
+                uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    d4[w] = (uint32_t)res[4 * w] | ((uint32_t)res[4 * w + 1] << 8) | ((uint32_t)res[4 * w + 2] << 16) | ((uint32_t)res[4 * w + 3] << 24);
+            } else {
+                for (int k = 0; k < nvalid * 3; ++k) dst[p * 3 + k] = res[k];
+            }
+        }
+        if (ndst) {
+            if (nvalid == 4 && (p & 3) == 0 && (hw & 3) == 0) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
+                        make_float4(L.nrm[c][res[c]], L.nrm[c][res[3 + c]], L.nrm[c][res[6 + c]], L.nrm[c][res[9 + c]]);
+            } else {
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = L.nrm[c][res[k * 3 + c]];
+            }
+        }
+    }
+}
+
 // fog from a caller-provided depth map (the two-step form of the reference).
 __global__ __launch_bounds__(kThreads)
 void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_fog_job* __restrict__ jobs,
@@ -230,12 +382,17 @@ void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_
 }
 
 // ------------------------------------------------------------------------------ A6 night
+// 4 pixels per lane (12 B in as three dwords, 12 B and/or three float4 out).  Throughput mode draws
+// its 12 normals from three Philox calls; parity mode reads the host's float64 draws.
 template <bool PHILOX>
 __global__ __launch_bounds__(kThreads)
 void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_night_job* __restrict__ jobs,
                   const double* __restrict__ noise_all, float g0, float g1, float g2,
                   uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
 {
+    __shared__ weather_lut L;
+    lut_fill(L, nc, norm_out != nullptr);
+    __syncthreads();
     const awseg_night_job job = jobs[blockIdx.y];
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
     const double* noise = PHILOX ? nullptr : noise_all + (int64_t)blockIdx.y * hw * 3;
@@ -244,11 +401,12 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_nigh
     const float bf = (float)job.brightness;                       // Python float x f32 array -> f32, :213
     const float gains[3] = { g0, g1, g2 };
     const double sigma = 5.0 / 255.0;                             // :222
+    const double ni = job.intensity;
     const int64_t nquad = (hw + 3) / 4;
     for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
         const int64_t p = q * 4;
         const int nvalid = (hw - p) < 4 ? (int)(hw - p) : 4;
-        uint8_t px[12], res[12];
+        uint8_t px[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, res[12];
         if (nvalid == 4) {
             const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
             uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
@@ -260,26 +418,27 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_nigh
         double nz[12];
         if (PHILOX) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int j = 0; j < 3; ++j) {
                 uint32_t r[4]; float a, b, c, d;
-                awseg_philox::gen(job.seed, (uint64_t)(p + k), 0x0A17u, r);
+                awseg_philox::gen(job.seed, (uint64_t)q * 3 + j, 0x0A17u, r);
                 awseg_box_muller(r[0], r[1], a, b);
                 awseg_box_muller(r[2], r[3], c, d);
-                nz[k * 3] = (double)a * sigma; nz[k * 3 + 1] = (double)b * sigma; nz[k * 3 + 2] = (double)c * sigma;
+                nz[4 * j] = (double)a * sigma; nz[4 * j + 1] = (double)b * sigma;
+                nz[4 * j + 2] = (double)c * sigma; nz[4 * j + 3] = (double)d * sigma;
             }
         } else if (nvalid == 4) {
             const double2* n2 = reinterpret_cast<const double2*>(noise + p * 3);
 #pragma unroll
             for (int k = 0; k < 6; ++k) { double2 t = n2[k]; nz[2 * k] = t.x; nz[2 * k + 1] = t.y; }
         } else {
-            for (int k = 0; k < nvalid * 3; ++k) nz[k] = noise[p * 3 + k];
+            for (int k = 0; k < 12; ++k) nz[k] = k < nvalid * 3 ? noise[p * 3 + k] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
-            float v = (float)px[k] / 255.0f;
+            float v = L.in[px[k]];
             v = v * bf;
             v = v * gains[k % 3];                                  // :217-219
-            double n = nz[k] * job.intensity;
+            double n = nz[k] * ni;
             n = n * 0.5;                                           // :223
             res[k] = quant_f64((double)v + n);
         }
@@ -298,11 +457,10 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_nigh
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
-                        make_float4(norm1(res[c], nc.mean[c], nc.std[c]), norm1(res[3 + c], nc.mean[c], nc.std[c]),
-                                    norm1(res[6 + c], nc.mean[c], nc.std[c]), norm1(res[9 + c], nc.mean[c], nc.std[c]));
+                        make_float4(L.nrm[c][res[c]], L.nrm[c][res[3 + c]], L.nrm[c][res[6 + c]], L.nrm[c][res[9 + c]]);
             } else {
                 for (int c = 0; c < 3; ++c)
-                    for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = norm1(res[k * 3 + c], nc.mean[c], nc.std[c]);
+                    for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = L.nrm[c][res[k * 3 + c]];
             }
         }
     }
@@ -645,7 +803,12 @@ static int fog_common(int mode, const uint8_t* imgs, int H, int W, const awseg_f
     norm_consts nc = make_nc(mean_host, std_host);
 #define AWSEG_FOG(P, M) hipLaunchKernelGGL((fog_kernel<P, M>), grid, dim3(kThreads), 0, s, imgs, H, W, jobs, noise, t, out, norm_out, depth_out, nc)
     if (noise) { if (mode) AWSEG_FOG(false, 1); else AWSEG_FOG(false, 0); }
-    else { if (mode) AWSEG_FOG(true, 1); else AWSEG_FOG(true, 0); }
+    else if (mode == 0) AWSEG_FOG(true, 0);          // depth-only request keeps the float64 pipeline
+    else {
+        gauss_taps_f32 tf;
+        for (int i = 0; i < 2 * FR + 1; ++i) tf.w[i] = (float)taps_host[i];
+        hipLaunchKernelGGL(fog_fast_kernel, grid, dim3(kFogFastThreads), 0, s, imgs, H, W, jobs, tf, out, norm_out, depth_out, nc);
+    }
 #undef AWSEG_FOG
     AWSEG_LAUNCH_CHECK();
     return 0;

@@ -122,13 +122,20 @@ class DepthEstimationHead(nn.Module):
         return torch.sigmoid(h[7](y))
 
 
-def _head_g9(tok: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
-    """The nine per-tap 1x1 products W_tap . f at the encoder's resolution: [B,h,w,9,Cmid].
-    `tok` is the encoder output as NHWC tokens [B,h,w,Cin]."""
+def _head_g9(tok: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """The nine per-tap 1x1 products (W_tap * bn_scale) . f at the encoder's resolution,
+    [B,h,w,9,Cmid], plus the folded shift.  `tok` is the encoder output as NHWC tokens [B,h,w,Cin].
+    BatchNorm's scale is folded into the weights so the kernel's epilogue is `relu(acc + shift)`."""
     B, h, w, Cin = tok.shape
     cmid = conv.weight.shape[0]
-    w1r = fused.cached(conv, "w1r", [conv.weight], lambda: conv.weight.permute(1, 2, 3, 0).reshape(Cin, 9 * cmid).contiguous())
-    return (tok.reshape(B * h * w, Cin) @ w1r).view(B, h, w, 9, cmid)
+
+    def build():
+        scale, shift = _fold_conv_bn(conv, bn)
+        w1r = (conv.weight * scale.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(Cin, 9 * cmid).contiguous()
+        return w1r, shift
+
+    w1r, shift = fused.cached(conv, "w1r", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+    return (tok.reshape(B * h * w, Cin) @ w1r).view(B, h, w, 9, cmid), shift
 
 
 def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
@@ -141,8 +148,8 @@ def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
 def upconv3x3_bn_relu(feats, conv, bn, height, width):
     """relu(bn(conv3x3(interpolate(feats)))) at full resolution (HIP, MFMA): the 256-channel
     upsampled tensor in front of the conv is never materialised."""
-    scale, shift = _fold_conv_bn(conv, bn)
-    return ops.upconv3x3_bn_relu(_head_g9(feats, conv), scale, shift, height, width, channels_last=True)
+    g9, shift = _head_g9(feats, conv, bn)
+    return ops.upconv3x3_bn_relu(g9, None, shift, height, width, channels_last=True)
 
 
 class SegFormerModel(nn.Module):
@@ -199,9 +206,9 @@ class SegFormerModel(nn.Module):
     def _forward_hip(self, feats, H, W):
         if True:
             head = self.segmentation_head
-            scale, shift = _fold_conv_bn(head[0], head[1])
+            g9, shift = _head_g9(feats, head[0], head[1])
             w2 = head[4].weight.view(self.num_classes, -1)
-            seg = ops.segformer_head_fused(_head_g9(feats, head[0]), scale, shift, w2, head[4].bias, H, W)
+            seg = ops.segformer_head_fused(g9, None, shift, w2, head[4].bias, H, W)
             results = {"segmentation": seg}
             if self.include_depth:
                 results["depth"] = self.depth_head.forward_from_lowres(feats, H, W)

@@ -305,7 +305,7 @@ def segformer_head_fused(g9: torch.Tensor, scale, shift, w2, b2, height: int, wi
     assert nine == 9
     cout = w2.shape[0]
     out = torch.empty(b, cout, height, width, dtype=torch.float32, device=g9.device)
-    N.call("awseg_segformer_head_fused", N.ptr(g9), b, cmid, h, w, height, width, N.ptr(scale.contiguous()),
+    N.call("awseg_segformer_head_fused", N.ptr(g9), b, cmid, h, w, height, width, N.ptr(None if scale is None else scale.contiguous()),
                                                N.ptr(shift.contiguous()), N.ptr(w2.contiguous()), N.ptr(b2.contiguous()),
                                                cout, N.ptr(out), N.stream())
     return out
@@ -319,7 +319,7 @@ def upconv3x3_bn_relu(g9: torch.Tensor, scale, shift, height: int, width: int, c
     assert nine == 9
     shape = (b, height, width, cmid) if channels_last else (b, cmid, height, width)
     out = torch.empty(shape, dtype=torch.float32, device=g9.device)
-    N.call("awseg_upconv3x3_bn_relu", N.ptr(g9), b, cmid, h, w, height, width, N.ptr(scale.contiguous()),
+    N.call("awseg_upconv3x3_bn_relu", N.ptr(g9), b, cmid, h, w, height, width, N.ptr(None if scale is None else scale.contiguous()),
            N.ptr(shift.contiguous()), N.ptr(out), int(channels_last), N.stream())
     return out.permute(0, 3, 1, 2) if channels_last else out          # logical NCHW either way
 

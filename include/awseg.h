@@ -303,7 +303,8 @@ int awseg_fog_density_from_depth(const float* depth, int64_t batch, int height, 
  *   g9     float32 [B, h, w, 9, Cmid] = per-tap 1x1 products W_tap . f at the
  *          encoder's resolution (tap = ky*3+kx, channel-last), computed by the
  *          caller with one plain GEMM
- *   scale/shift float32 [Cmid]: conv bias + eval-mode BatchNorm folded to y*scale+shift
+ *   scale/shift float32 [Cmid]: conv bias + eval-mode BatchNorm folded to y*scale+shift;
+ *          scale may be NULL when the caller has already multiplied it into g9 (cheaper epilogue)
  *   w2     float32 [Cout, Cmid], b2 float32 [Cout]: the 1x1 classifier (Cout <= 32)
  * out float32 [B,Cout,H,W].  Zero padding of the 3x3 at the image border and
  * align_corners=False source coordinates follow torch exactly.  Cmid % 32 == 0.

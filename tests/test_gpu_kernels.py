@@ -389,3 +389,29 @@ def test_upconv_channels_last_matches_nchw(ops):
     a = ops.upconv3x3_bn_relu(g9, sc, sf, H, W, channels_last=False)
     b = ops.upconv3x3_bn_relu(g9, sc, sf, H, W, channels_last=True)
     assert b.shape == a.shape and b.is_contiguous(memory_format=torch.channels_last) and torch.equal(a, b.contiguous())
+
+
+def test_fog_throughput_mode_statistics_and_consistency(ops, oracle):
+    """Philox/float32 fog (noise=None): noise statistics match N(0,10) through the sigma=2 filter, and
+    the bytes equal the float64 oracle applied to the kernel's own depth up to 1 LSB."""
+    h, w = 256, 512
+    rs = np.random.RandomState(0)
+    imgs = rs.randint(0, 255, (2, h, w, 3), dtype=np.uint8)
+    jobs = ops.fog_jobs([0, 1], [0.5, 0.8], seeds=[5, 6])
+    out = torch.empty(2, h, w, 3, dtype=torch.uint8, device="cuda")
+    norm = torch.empty(2, 3, h, w, device="cuda")
+    d = torch.empty(2, h, w, dtype=torch.float64, device="cuda")
+    ops.fog(dev(imgs), jobs, out=out, norm_out=norm, depth_out=d)
+    depth = d.cpu().numpy()
+    base = (np.arange(h)[:, None] / h) * 100.0
+    resid = (depth[0] - base)[40:-8, 8:-8]                     # rows where the max(.,1) clamp is inactive
+    taps = ops.gaussian_taps()
+    expect_std = 10.0 * float((taps ** 2).sum())               # std of separably filtered white noise
+    assert abs(resid.mean()) < 0.05 and abs(resid.std() - expect_std) / expect_std < 0.05
+    assert abs(np.corrcoef(depth[0].ravel(), depth[1].ravel())[0, 1]) > 0.9  # same ramp, different noise
+    assert not np.array_equal(depth[0], depth[1])
+    for b, inten in ((0, 0.5), (1, 0.8)):
+        ref = oracle.fog(imgs[b], depth[b], inten)
+        diff = np.abs(out[b].cpu().numpy().astype(np.int16) - ref.astype(np.int16))
+        assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
+        assert np.array_equal(norm[b].cpu().numpy(), oracle.normalize(out[b].cpu().numpy()))

@@ -59,6 +59,7 @@ SIGNATURES = {
     "awseg_aspp_depthwise3": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "awseg_dwconv3x3_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
     "awseg_bias_act_nhwc": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_i, c_p]),
+    "awseg_layernorm_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_f, c_p, c_p]),
     "awseg_ece_accumulate": (c_i, [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
 }
 

@@ -84,4 +84,15 @@ __device__ __forceinline__ void awseg_box_muller(uint32_t a, uint32_t b, float& 
     n0 = r * __builtin_amdgcn_cosf(u2);
     n1 = r * __builtin_amdgcn_sinf(u2);
 }
+// One uint32 -> one N(0,1) pair from its two 16-bit halves.  The noise these feed is quantised to
+// 8 bits at sigma <= 1 LSB (night) or smoothed by a 17x17 Gaussian (fog depth), so 16-bit uniforms
+// (tails truncated at 4.7 sigma) are ample and halve the Philox calls per pixel.
+__device__ __forceinline__ void awseg_box_muller16(uint32_t a, float& n0, float& n1)
+{
+    float u1 = ((float)(a & 0xFFFFu) + 0.5f) * (1.0f / 65536.0f);
+    float u2 = (float)(a >> 16) * (1.0f / 65536.0f);
+    float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));
+    n0 = r * __builtin_amdgcn_cosf(u2);
+    n1 = r * __builtin_amdgcn_sinf(u2);
+}
 __device__ __forceinline__ float awseg_u01(uint32_t a) { return (float)(a >> 8) * (1.0f / 16777216.0f); }

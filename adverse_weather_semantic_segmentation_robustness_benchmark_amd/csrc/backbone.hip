@@ -81,6 +81,63 @@ void bias_act_nhwc_kernel(float* __restrict__ x, int64_t n_pixels, int C, const 
     }
 }
 
+// LayerNorm over the last dimension for token matrices [N, C] with small C (MiT: 32..512).  A row is
+// owned by L = 8..64 lanes of one wave (float4 chunks, strided by L), statistics are two shuffle
+// reductions inside those L lanes, the row never leaves registers: 8 B/element of HBM traffic.
+// (torch's kernel gives one row to a whole block: 0.98 ms for 1M x 32 against 0.054 ms of traffic.)
+template <int L>
+__global__ __launch_bounds__(kThreads)
+void layernorm_rows_kernel(const float* __restrict__ x, int64_t n_rows, int C, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, float eps, float* __restrict__ out)
+{
+    constexpr int MAXCH = 4;                               // chunks of 4 floats per lane -> C <= 16 * L
+    const int sub = threadIdx.x % L;
+    const int64_t rows_per_block = kThreads / L;
+    const int nchunk = C / 4;
+    const float inv_c = 1.0f / (float)C;
+    for (int64_t row = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / L; row < n_rows; row += (int64_t)gridDim.x * rows_per_block) {
+        const float* xr = x + row * C;
+        float4 v[MAXCH];
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int ch = sub + j * L;
+            if (ch < nchunk) {
+                v[j] = *reinterpret_cast<const float4*>(xr + ch * 4);
+                sum += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            }
+        }
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, L);
+        const float mean = sum * inv_c;
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int ch = sub + j * L;
+            if (ch < nchunk) {
+                const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+                sq += (a * a + b * b) + (c * c + d * d);
+            }
+        }
+#pragma unroll
+        for (int o = L / 2; o > 0; o >>= 1) sq += __shfl_xor(sq, o, L);
+        const float rstd = rsqrtf(sq * inv_c + eps);
+        float* orow = out + row * C;
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j) {
+            const int ch = sub + j * L;
+            if (ch < nchunk) {
+                const float4 g = *reinterpret_cast<const float4*>(gamma + ch * 4);
+                const float4 bb = *reinterpret_cast<const float4*>(beta + ch * 4);
+                float4 r;
+                r.x = (v[j].x - mean) * rstd * g.x + bb.x; r.y = (v[j].y - mean) * rstd * g.y + bb.y;
+                r.z = (v[j].z - mean) * rstd * g.z + bb.z; r.w = (v[j].w - mean) * rstd * g.w + bb.w;
+                *reinterpret_cast<float4*>(orow + ch * 4) = r;
+            }
+        }
+    }
+}
+
 }  // namespace
 
 AWSEG_API int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, int width, int channels, int dilation,
@@ -104,6 +161,31 @@ AWSEG_API int awseg_bias_act_nhwc(float* x, int64_t n_pixels, int channels, cons
     const int64_t total = n_pixels * (channels / 4);
     hipLaunchKernelGGL(bias_act_nhwc_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, n_pixels,
                        channels, bias, residual, act);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_layernorm_rows(const float* x, int64_t n_rows, int channels, const float* gamma, const float* beta,
+                                   float eps, float* out, awseg_stream_t stream)
+{
+    if (!x || !gamma || !beta || !out || n_rows < 1 || channels < 4 || (channels & 3) || channels > 1024) return AWSEG_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)gamma & 15) || ((uintptr_t)beta & 15)) return AWSEG_EALIGN;
+    const int nchunk = channels / 4;
+    int L = 8;
+    while (L < 64 && L * 4 < nchunk) L <<= 1;             // at most 4 chunks per lane
+    while (L < 64 && L < nchunk && nchunk <= 64) L <<= 1;  // one chunk per lane when the row fits a wave
+    if (nchunk > 4 * L) return AWSEG_ERANGE;
+    const int64_t rows_per_block = kThreads / L;
+    const int grid = awseg_grid_1d(n_rows, (int)rows_per_block);
+    hipStream_t s = awseg_s(stream);
+#define AWSEG_LN(LV) hipLaunchKernelGGL((layernorm_rows_kernel<LV>), dim3(grid), dim3(kThreads), 0, s, x, n_rows, channels, gamma, beta, eps, out)
+    switch (L) {
+        case 8: AWSEG_LN(8); break;
+        case 16: AWSEG_LN(16); break;
+        case 32: AWSEG_LN(32); break;
+        default: AWSEG_LN(64); break;
+    }
+#undef AWSEG_LN
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -239,34 +239,34 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg
     const awseg_fog_job job = jobs[blockIdx.z];
     const int64_t hw = (int64_t)H * W;
     const int x0 = blockIdx.x * FTW, y0 = blockIdx.y * FTH;
-    const int64_t Wq = (W + 3) / 4;
     const float inv_h = 100.0f / (float)H;
-    const bool interior_x = (x0 - FR >= 0) && (x0 + FTW + FR <= W) && ((W & 3) == 0);
+    const bool interior_x = (x0 - FR >= 0) && (x0 + FTW + FR <= W);
 
-    // phase 1: (y/H)*100 + N(0,10) for the tile and its halo
+    // phase 1: (y/H)*100 + N(0,10) for the tile and its halo; one Philox call = 8 normals = 8 columns
+    const int64_t Wo = (W + 7) / 8;
     if (interior_x) {
-        for (int i = threadIdx.x; i < FIH * (FIW / 4); i += kFogFastThreads) {
-            const int ty = i / (FIW / 4), tq = i - ty * (FIW / 4);
-            const int gy = reflect_sym(y0 - FR + ty, H), gx = x0 - FR + tq * 4;
-            uint32_t r[4]; float n0, n1, n2, n3;
-            awseg_philox::gen(job.seed, (uint64_t)gy * Wq + (gx >> 2), 0x0F06u, r);
-            awseg_box_muller(r[0], r[1], n0, n1);
-            awseg_box_muller(r[2], r[3], n2, n3);
+        for (int i = threadIdx.x; i < FIH * (FIW / 8); i += kFogFastThreads) {
+            const int ty = i / (FIW / 8), to = i - ty * (FIW / 8);
+            const int gy = reflect_sym(y0 - FR + ty, H), gx = x0 - FR + to * 8;      // x0 - 8 is a multiple of 8
+            uint32_t r[4]; float n[8];
+            awseg_philox::gen(job.seed, (uint64_t)gy * Wo + (gx >> 3), 0x0F06u, r);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) awseg_box_muller16(r[k], n[2 * k], n[2 * k + 1]);
             const float base = (float)gy * inv_h;
-            *reinterpret_cast<float4*>(s_in + ty * FIW + tq * 4) =
-                make_float4(base + 10.f * n0, base + 10.f * n1, base + 10.f * n2, base + 10.f * n3);
+            float* d = s_in + ty * FIW + to * 8;
+            *reinterpret_cast<float4*>(d) = make_float4(base + 10.f * n[0], base + 10.f * n[1], base + 10.f * n[2], base + 10.f * n[3]);
+            *reinterpret_cast<float4*>(d + 4) = make_float4(base + 10.f * n[4], base + 10.f * n[5], base + 10.f * n[6], base + 10.f * n[7]);
         }
     } else {
         for (int i = threadIdx.x; i < FIH * FIW; i += kFogFastThreads) {
             const int ty = i / FIW, tx = i - ty * FIW;
             const int gy = reflect_sym(y0 - FR + ty, H), gx = reflect_sym(x0 - FR + tx, W);
-            uint32_t r[4]; float n[4];
-            awseg_philox::gen(job.seed, (uint64_t)gy * Wq + (gx >> 2), 0x0F06u, r);
-            awseg_box_muller(r[0], r[1], n[0], n[1]);
-            awseg_box_muller(r[2], r[3], n[2], n[3]);
-            const int sel = gx & 3;
-            const float nv = sel == 0 ? n[0] : (sel == 1 ? n[1] : (sel == 2 ? n[2] : n[3]));
-            s_in[i] = (float)gy * inv_h + 10.f * nv;
+            uint32_t r[4]; float n0, n1;
+            awseg_philox::gen(job.seed, (uint64_t)gy * Wo + (gx >> 3), 0x0F06u, r);
+            const int sel = gx & 7;
+            const uint32_t word = (sel >> 1) == 0 ? r[0] : ((sel >> 1) == 1 ? r[1] : ((sel >> 1) == 2 ? r[2] : r[3]));
+            awseg_box_muller16(word, n0, n1);
+            s_in[i] = (float)gy * inv_h + 10.f * ((sel & 1) ? n1 : n0);
         }
     }
     __syncthreads();
@@ -417,14 +417,21 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_nigh
         }
         double nz[12];
         if (PHILOX) {
+            // throughput mode: 12 normals from 6 of the 8 words of two Philox calls, all float32
+            // (parity is only defined for host-drawn noise)
+            float nf[12];
+            uint32_t r[8];
+            awseg_philox::gen(job.seed, (uint64_t)q * 2, 0x0A17u, r);
+            awseg_philox::gen(job.seed, (uint64_t)q * 2 + 1, 0x0A17u, r + 4);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                uint32_t r[4]; float a, b, c, d;
-                awseg_philox::gen(job.seed, (uint64_t)q * 3 + j, 0x0A17u, r);
-                awseg_box_muller(r[0], r[1], a, b);
-                awseg_box_muller(r[2], r[3], c, d);
-                nz[4 * j] = (double)a * sigma; nz[4 * j + 1] = (double)b * sigma;
-                nz[4 * j + 2] = (double)c * sigma; nz[4 * j + 3] = (double)d * sigma;
+            for (int j = 0; j < 6; ++j) awseg_box_muller16(r[j], nf[2 * j], nf[2 * j + 1]);
+            const float amp = (float)(sigma * ni * 0.5);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                float v = L.in[px[k]];
+                v = v * bf;
+                v = v * gains[k % 3];
+                res[k] = quant_f32(fmaf(nf[k], amp, v));
             }
         } else if (nvalid == 4) {
             const double2* n2 = reinterpret_cast<const double2*>(noise + p * 3);
@@ -433,14 +440,16 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_nigh
         } else {
             for (int k = 0; k < 12; ++k) nz[k] = k < nvalid * 3 ? noise[p * 3 + k] : 0.0;
         }
+        if (!PHILOX) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
-            float v = L.in[px[k]];
-            v = v * bf;
-            v = v * gains[k % 3];                                  // :217-219
-            double n = nz[k] * ni;
-            n = n * 0.5;                                           // :223
-            res[k] = quant_f64((double)v + n);
+            for (int k = 0; k < 12; ++k) {
+                float v = L.in[px[k]];
+                v = v * bf;
+                v = v * gains[k % 3];                              // :217-219
+                double n = nz[k] * ni;
+                n = n * 0.5;                                       // :223
+                res[k] = quant_f64((double)v + n);
+            }
         }
         if (dst) {
             if (nvalid == 4) {

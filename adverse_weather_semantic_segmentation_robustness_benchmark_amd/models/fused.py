@@ -115,7 +115,10 @@ def separable_bn_relu(x: torch.Tensor, sep, bn: nn.BatchNorm2d) -> torch.Tensor:
 
 # --------------------------------------------------------------------------- MiT encoder
 def _ln(t, ln: nn.LayerNorm):
-    return F.layer_norm(t, (t.shape[-1],), ln.weight, ln.bias, ln.eps)
+    c = t.shape[-1]
+    if c % 4 == 0 and c <= 1024 and ln.weight is not None and ln.bias is not None:
+        return ops.layernorm_rows(t, ln.weight, ln.bias, ln.eps)           # sub-wave rows (HIP)
+    return F.layer_norm(t, (c,), ln.weight, ln.bias, ln.eps)
 
 
 @torch.no_grad()

@@ -354,3 +354,13 @@ def bias_act_nhwc_(x_nhwc: torch.Tensor, bias: Optional[torch.Tensor], residual:
     c = x_nhwc.shape[-1]
     N.call("awseg_bias_act_nhwc", N.ptr(x_nhwc), x_nhwc.numel() // c, c, N.ptr(bias), N.ptr(residual), int(act), N.stream())
     return x_nhwc
+
+
+def layernorm_rows(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    """torch.nn.functional.layer_norm over the last dimension for small channel counts (MiT tokens)."""
+    x = x.contiguous()
+    c = x.shape[-1]
+    out = torch.empty_like(x)
+    N.call("awseg_layernorm_rows", N.ptr(x), x.numel() // c, c, N.ptr(gamma.contiguous()), N.ptr(beta.contiguous()), float(eps),
+           N.ptr(out), N.stream())
+    return out

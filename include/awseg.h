@@ -358,6 +358,13 @@ int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, int width, i
 int awseg_bias_act_nhwc(float* x, int64_t n_pixels, int channels, const float* bias, const float* residual,
                         int act, awseg_stream_t stream);
 
+/* awseg_layernorm_rows: LayerNorm over the last dimension of float32 [n_rows, C] (C % 4 == 0,
+ * C <= 1024): out = (x - mean) * rsqrt(var + eps) * gamma + beta, biased variance, as
+ * torch.nn.LayerNorm.  Replaces the nn.LayerNorm calls inside the SegFormer encoder that
+ * PKG/models/model.py:193 runs (32..512 channels per token: far below torch's kernel sweet spot). */
+int awseg_layernorm_rows(const float* x, int64_t n_rows, int channels, const float* gamma, const float* beta,
+                         float eps, float* out, awseg_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  *  next #1  ConfidenceCalibration.compute_ece accumulators
  *       replaces PKG/evaluation/metrics.py:161-194 (the per-pixel part)

@@ -415,3 +415,12 @@ def test_fog_throughput_mode_statistics_and_consistency(ops, oracle):
         diff = np.abs(out[b].cpu().numpy().astype(np.int16) - ref.astype(np.int16))
         assert diff.max() <= 1 and (diff > 0).mean() < 1e-3
         assert np.array_equal(norm[b].cpu().numpy(), oracle.normalize(out[b].cpu().numpy()))
+
+
+@pytest.mark.parametrize("shape", [(1000, 32), (257, 64), (130, 160), (64, 256), (33, 320), (20, 512), (7, 1024)])
+def test_layernorm_rows(ops, shape):
+    torch.manual_seed(shape[1])
+    x = torch.randn(*shape, device="cuda") * 3 + 1
+    g, b = torch.randn(shape[1], device="cuda"), torch.randn(shape[1], device="cuda")
+    ref = torch.nn.functional.layer_norm(x, (shape[1],), g, b, 1e-5)
+    assert (ops.layernorm_rows(x, g, b, 1e-5) - ref).abs().max().item() < 2e-5

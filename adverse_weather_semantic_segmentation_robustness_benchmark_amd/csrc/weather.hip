@@ -476,52 +476,57 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_nigh
 }
 
 // ---------------------------------------------------------------- rasteriser (A4 / A5)
-// Integer restatement of OpenCV's drawing primitives (PARITY UNPINNED, see the oracle header).
-// Primitives are rasterised by one lane each into an LDS coverage mask that covers the
-// tile + blur halo, clipped to the image.
+// Integer restatement of OpenCV's drawing primitives (PARITY UNPINNED, see the oracle header),
+// producing the same pixel sets as the scanline code in oracle/awseg_oracle.c.  A primitive is
+// rasterised by ONE WAVE into an LDS coverage mask (tile + blur halo, clipped to the image): the
+// inherently serial parts (midpoint-circle recurrence, polygon edge walk) run wave-uniformly, the
+// span fills and the fixed-point line steps are spread over the 64 lanes.
 struct tile_mask {
     uint8_t* m; int x0, y0, w, h;   // rect origin / size in image coordinates
     int W, H;                       // image size (OpenCV clips to the image first)
 };
-__device__ __forceinline__ void m_hline(const tile_mask& k, int y, int xa, int xb)
+__device__ __forceinline__ void m_hline(const tile_mask& k, int y, int xa, int xb, int lane)
 {
     if (y < 0 || y >= k.H) return;
     if (xa < 0) xa = 0;
     if (xb >= k.W) xb = k.W - 1;
-    int ry = y - k.y0;
+    const int ry = y - k.y0;
     if (ry < 0 || ry >= k.h) return;
     int a = xa - k.x0, b = xb - k.x0;
     if (a < 0) a = 0;
     if (b >= k.w) b = k.w - 1;
-    for (int x = a; x <= b; ++x) k.m[ry * k.w + x] = 1;
+    for (int x = a + lane; x <= b; x += 64) k.m[ry * k.w + x] = 1;
 }
 __device__ __forceinline__ void m_point(const tile_mask& k, int x, int y)
 {
     if (x < 0 || x >= k.W || y < 0 || y >= k.H) return;
-    int rx = x - k.x0, ry = y - k.y0;
+    const int rx = x - k.x0, ry = y - k.y0;
     if (rx < 0 || rx >= k.w || ry < 0 || ry >= k.h) return;
     k.m[ry * k.w + rx] = 1;
 }
-__device__ void m_line_thin(const tile_mask& k, int x0, int y0, int x1, int y1)
+// cv::Line (LineIterator, 8-connected, left to right): closed form per step -> one step per lane.
+__device__ void m_line_thin(const tile_mask& k, int x0, int y0, int x1, int y1, int lane)
 {
     if (x1 < x0) { int t = x0; x0 = x1; x1 = t; t = y0; y0 = y1; y1 = t; }
-    int dx = x1 - x0, dy = y1 - y0, sy = dy < 0 ? -1 : 1;
+    int dx = x1 - x0, dy = y1 - y0;
+    const int sy = dy < 0 ? -1 : 1;
     if (dy < 0) dy = -dy;
     if (dx >= dy) {
-        if (dx == 0) { m_point(k, x0, y0); return; }
-        for (int i = 0; i <= dx; ++i) m_point(k, x0 + i, y0 + sy * (int)((2LL * dy * i + dx - 1) / (2LL * dx)));
+        if (dx == 0) { if (lane == 0) m_point(k, x0, y0); return; }
+        for (int i = lane; i <= dx; i += 64) m_point(k, x0 + i, y0 + sy * (int)((2LL * dy * i + dx - 1) / (2LL * dx)));
     } else {
-        for (int i = 0; i <= dy; ++i) m_point(k, x0 + (int)((2LL * dx * i + dy - 1) / (2LL * dy)), y0 + sy * i);
+        for (int i = lane; i <= dy; i += 64) m_point(k, x0 + (int)((2LL * dx * i + dy - 1) / (2LL * dy)), y0 + sy * i);
     }
 }
-__device__ void m_disc(const tile_mask& k, int cx, int cy, int r)
+// cv::Circle(fill): the midpoint recurrence is wave-uniform, each of its spans is filled by the lanes.
+__device__ void m_disc(const tile_mask& k, int cx, int cy, int r, int lane)
 {
     int err = 0, dx = r, dy = 0, plus = 1, minus = (r << 1) - 1;
     while (dx >= dy) {
-        m_hline(k, cy - dy, cx - dx, cx + dx);
-        m_hline(k, cy + dy, cx - dx, cx + dx);
-        m_hline(k, cy - dx, cx - dy, cx + dy);
-        m_hline(k, cy + dx, cx - dy, cx + dy);
+        m_hline(k, cy - dy, cx - dx, cx + dx, lane);
+        m_hline(k, cy + dy, cx - dx, cx + dx, lane);
+        m_hline(k, cy - dx, cx - dy, cx + dy, lane);
+        m_hline(k, cy + dx, cx - dy, cx + dy, lane);
         dy++;
         err += plus; plus += 2;
         int mask = (err <= 0) - 1;
@@ -532,28 +537,30 @@ __device__ void m_disc(const tile_mask& k, int cx, int cy, int r)
 }
 constexpr int XY_SHIFT = 16;
 constexpr int XY_ONE = 1 << XY_SHIFT;
-__device__ void m_line2(const tile_mask& k, int64_t x1, int64_t y1, int64_t x2, int64_t y2)
+// cv::Line2 (16.16 fixed-point DDA): position after j steps is start + j*step -> one step per lane.
+__device__ void m_line2(const tile_mask& k, int64_t x1, int64_t y1, int64_t x2, int64_t y2, int lane)
 {
     int64_t dx = x2 - x1, dy = y2 - y1;
-    int64_t ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
-    m_point(k, (int)((x2 + (XY_ONE >> 1)) >> XY_SHIFT), (int)((y2 + (XY_ONE >> 1)) >> XY_SHIFT));
+    const int64_t ax = dx < 0 ? -dx : dx, ay = dy < 0 ? -dy : dy;
+    if (lane == 0) m_point(k, (int)((x2 + (XY_ONE >> 1)) >> XY_SHIFT), (int)((y2 + (XY_ONE >> 1)) >> XY_SHIFT));
     if (ax > ay) {
         if (dx < 0) { int64_t t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dy = -dy; }
-        int64_t y_step = (dy * XY_ONE) / (ax | 1);
-        int ecount = (int)((x2 - x1) >> XY_SHIFT);
+        const int64_t y_step = (dy * XY_ONE) / (ax | 1);
+        const int ecount = (int)((x2 - x1) >> XY_SHIFT);
         x1 += XY_ONE >> 1; y1 += XY_ONE >> 1;
-        int64_t x = x1 >> XY_SHIFT;
-        while (ecount >= 0) { m_point(k, (int)x, (int)(y1 >> XY_SHIFT)); x++; y1 += y_step; ecount--; }
+        const int64_t xb = x1 >> XY_SHIFT;
+        for (int j = lane; j <= ecount; j += 64) m_point(k, (int)(xb + j), (int)((y1 + j * y_step) >> XY_SHIFT));
     } else {
         if (dy < 0) { int64_t t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dx = -dx; }
-        int64_t x_step = (dx * XY_ONE) / (ay | 1);
-        int ecount = (int)((y2 - y1) >> XY_SHIFT);
+        const int64_t x_step = (dx * XY_ONE) / (ay | 1);
+        const int ecount = (int)((y2 - y1) >> XY_SHIFT);
         x1 += XY_ONE >> 1; y1 += XY_ONE >> 1;
-        int64_t y = y1 >> XY_SHIFT;
-        while (ecount >= 0) { m_point(k, (int)(x1 >> XY_SHIFT), (int)y); y++; x1 += x_step; ecount--; }
+        const int64_t yb = y1 >> XY_SHIFT;
+        for (int j = lane; j <= ecount; j += 64) m_point(k, (int)((x1 + j * x_step) >> XY_SHIFT), (int)(yb + j));
     }
 }
-__device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int64_t* vy)
+// cv::FillConvexPoly for the 4-point thick-line body: wave-uniform edge walk, lane-parallel spans.
+__device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int64_t* vy, int lane)
 {
     const int npts = 4;
     const int64_t delta = XY_ONE >> 1;
@@ -567,7 +574,7 @@ __device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int6
         if (vy[i] > ymax) ymax = vy[i];
         if (vx[i] > xmax) xmax = vx[i];
         if (vx[i] < xmin) xmin = vx[i];
-        m_line2(k, px, py, vx[i], vy[i]);
+        m_line2(k, px, py, vx[i], vy[i], lane);
         px = vx[i]; py = vy[i];
     }
     xmin = (xmin + delta) >> XY_SHIFT; xmax = (xmax + delta) >> XY_SHIFT;
@@ -603,13 +610,13 @@ __device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int6
             if (e_x[0] > e_x[1]) { left = 1; right = 0; }
             int xx1 = (int)((e_x[left] + (XY_ONE >> 1)) >> XY_SHIFT);
             int xx2 = (int)((e_x[right] + (XY_ONE >> 1)) >> XY_SHIFT);
-            if (xx2 >= 0 && xx1 < k.W) m_hline(k, y, xx1, xx2);
+            if (xx2 >= 0 && xx1 < k.W) m_hline(k, y, xx1, xx2, lane);
         }
         e_x[0] += e_dx[0];
         e_x[1] += e_dx[1];
     } while (++y <= (int)ymax);
 }
-__device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1, int thickness)
+__device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1, int thickness, int lane)
 {
     int64_t p0x = (int64_t)x0 << XY_SHIFT, p0y = (int64_t)y0 << XY_SHIFT;
     int64_t p1x = (int64_t)x1 << XY_SHIFT, p1y = (int64_t)y1 << XY_SHIFT;
@@ -623,19 +630,23 @@ __device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1,
         int64_t dpx = (int64_t)rint(dy * r), dpy = (int64_t)rint(dx * r);
         int64_t vx[4] = { p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx };
         int64_t vy[4] = { p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy };
-        m_fill_convex4(k, vx, vy);
+        m_fill_convex4(k, vx, vy, lane);
     }
     int rad = (int)((th + (XY_ONE >> 1)) >> XY_SHIFT);
-    m_disc(k, x0, y0, rad);
-    m_disc(k, x1, y1, rad);
+    m_disc(k, x0, y0, rad, lane);
+    m_disc(k, x1, y1, rad, lane);
 }
 
 // ---------------------------------------------------------------------- A4 rain / A5 snow
-// Tile BTW x BTH, halo R (1 for 3x3, 3 for 7x7).  Stage the float32 pre-blur image (haze /
-// brightness applied, primitives painted) in LDS, then OpenCV's separable blur: row pass over
-// every staged row, column pass over the tile.  Symmetric form k[c]*s0 + sum k[c+j]*(s[-j]+s[j]).
+// Tile 64 x 16, halo R (1 for 3x3, 3 for 7x7).  The float32 pre-blur image (haze / brightness
+// applied through the LUT, primitives painted) is staged in LDS as [row][72 px][3] — the float
+// image of the frame's byte rows, so interior tiles stage with aligned dword loads; then OpenCV's
+// separable blur: row pass over every staged row, column pass over the tile, 4 pixels (12 values)
+// per lane with 16-byte LDS accesses, 12 B / 3 x 16 B global stores.
 constexpr int BTW = 64, BTH = 16, BRMAX = 3;
-constexpr int BSW = BTW + 2 * BRMAX, BSH = BTH + 2 * BRMAX;
+constexpr int BSH = BTH + 2 * BRMAX;            // 22 staged rows
+constexpr int BSW = 72;                         // staged pixels per row (>= 64 + 2*3, multiple of 4)
+constexpr int MAXHIT = 64;
 
 struct blur_taps { float k[2 * BRMAX + 1]; int r; };
 
@@ -645,9 +656,12 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_p
                    const int32_t* __restrict__ prims, blur_taps bt3, blur_taps bt7,
                    uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
 {
-    __shared__ float s_src[BSH * BSW * 3];     // 22 x 70 x 3 floats = 18.5 KB
-    __shared__ float s_row[BSH * BTW * 3];     // 22 x 64 x 3 floats = 16.9 KB
+    __shared__ __attribute__((aligned(16))) float s_src[BSH * BSW * 3];     // 19.0 KB
+    __shared__ __attribute__((aligned(16))) float s_row[BSH * BTW * 3];     // 16.9 KB
     __shared__ uint8_t s_mask[BSH * BSW];
+    __shared__ int s_hits[MAXHIT];
+    __shared__ int s_nhit;
+    __shared__ weather_lut L;
     const awseg_prim_job job = jobs[blockIdx.z];
     const blur_taps bt = (SNOW && job.blur_ksize == 7) ? bt7 : bt3;
     const int R = bt.r;
@@ -655,78 +669,177 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_p
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
     const int x0 = blockIdx.x * BTW, y0 = blockIdx.y * BTH;
     const int sw = BTW + 2 * R, sh = BTH + 2 * R;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
+    // pre-blur value of an input byte: haze (:134-135) or brightness boost + clip (:179-180)
+    float pm, pa;
+    if (SNOW) { pm = 1.f; pa = (float)(job.intensity * 0.2); }
+    else { double haze = job.intensity * 0.3; pm = (float)(1.0 - haze); pa = (float)(haze * 0.7); }
+    for (int i = threadIdx.x; i < 256; i += kThreads) {
+        float v = (float)i / 255.0f;
+        if (SNOW) { v = v + pa; v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+        else { v = v * pm; v = v + pa; }
+        L.in[i] = v;
+        if (norm_out) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) L.nrm[c][i] = norm1((uint8_t)i, nc.mean[c], nc.std[c]);
+        }
+    }
     // coverage mask over the part of tile+halo that lies inside the image
     tile_mask mk;
     mk.m = s_mask; mk.W = W; mk.H = H;
     mk.x0 = x0 - R < 0 ? 0 : x0 - R;
     mk.y0 = y0 - R < 0 ? 0 : y0 - R;
-    int xe = x0 + BTW + R > W ? W : x0 + BTW + R, ye = y0 + BTH + R > H ? H : y0 + BTH + R;
+    const int xe = x0 + BTW + R > W ? W : x0 + BTW + R, ye = y0 + BTH + R > H ? H : y0 + BTH + R;
     mk.w = xe - mk.x0; mk.h = ye - mk.y0;
     for (int i = threadIdx.x; i < mk.w * mk.h; i += kThreads) s_mask[i] = 0;
+    if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
+    // 1. which primitives touch this tile (bounding boxes, all lanes)
     const int32_t* pl = prims + (int64_t)job.prim_offset * (SNOW ? 3 : 5);
     for (int i = threadIdx.x; i < job.prim_count; i += kThreads) {
+        int lx, hx, ly, hy;
         if (SNOW) {
-            int cx = pl[i * 3], cy = pl[i * 3 + 1], r = pl[i * 3 + 2];
-            if (cx + r < mk.x0 || cx - r >= xe || cy + r < mk.y0 || cy - r >= ye) continue;
-            m_disc(mk, cx, cy, r);
+            const int cx = pl[i * 3], cy = pl[i * 3 + 1], r = pl[i * 3 + 2];
+            lx = cx - r; hx = cx + r; ly = cy - r; hy = cy + r;
         } else {
-            int ax = pl[i * 5], ay = pl[i * 5 + 1], bx = pl[i * 5 + 2], by = pl[i * 5 + 3], th = pl[i * 5 + 4];
-            int mg = th <= 1 ? 0 : th + 2;
-            int lx = (ax < bx ? ax : bx) - mg, hx = (ax > bx ? ax : bx) + mg;
-            int ly = (ay < by ? ay : by) - mg, hy = (ay > by ? ay : by) + mg;
-            if (hx < mk.x0 || lx >= xe || hy < mk.y0 || ly >= ye) continue;
-            if (th <= 1) m_line_thin(mk, ax, ay, bx, by);
-            else m_line_thick(mk, ax, ay, bx, by, th);
+            const int ax = pl[i * 5], ay = pl[i * 5 + 1], bx = pl[i * 5 + 2], by = pl[i * 5 + 3], th = pl[i * 5 + 4];
+            const int mg = th <= 1 ? 0 : th + 2;
+            lx = (ax < bx ? ax : bx) - mg; hx = (ax > bx ? ax : bx) + mg;
+            ly = (ay < by ? ay : by) - mg; hy = (ay > by ? ay : by) + mg;
+        }
+        if (!(hx < mk.x0 || lx >= xe || hy < mk.y0 || ly >= ye)) {
+            const int slot = atomicAdd(&s_nhit, 1);
+            if (slot < MAXHIT) s_hits[slot] = i;
         }
     }
     __syncthreads();
-    // pre-blur image: haze (:134-135) or brightness boost + clip (:179-180), then paint
-    float pm, pa;
-    if (SNOW) { pm = 1.f; pa = (float)(job.intensity * 0.2); }
-    else { double haze = job.intensity * 0.3; pm = (float)(1.0 - haze); pa = (float)(haze * 0.7); }
+    // 2. rasterise: one wave per hit (a tile sees a handful at most; more than MAXHIT -> every primitive)
+    const int nhit = s_nhit;
+    const int nwork = nhit <= MAXHIT ? nhit : job.prim_count;
+    for (int hidx = wv; hidx < nwork; hidx += kThreads / 64) {
+        const int i = nhit <= MAXHIT ? s_hits[hidx] : hidx;
+        if (SNOW) m_disc(mk, pl[i * 3], pl[i * 3 + 1], pl[i * 3 + 2], lane);
+        else {
+            const int ax = pl[i * 5], ay = pl[i * 5 + 1], bx = pl[i * 5 + 2], by = pl[i * 5 + 3], th = pl[i * 5 + 4];
+            if (th <= 1) m_line_thin(mk, ax, ay, bx, by, lane);
+            else m_line_thick(mk, ax, ay, bx, by, th, lane);
+        }
+    }
+    __syncthreads();
+    // 3. stage the pre-blur float image of tile + halo
     const float col[3] = { SNOW ? 1.0f : 0.8f, SNOW ? 1.0f : 0.9f, 1.0f };
-    for (int i = threadIdx.x; i < sh * sw; i += kThreads) {
-        int ty = i / sw, tx = i - ty * sw;
-        int gy = reflect_101(y0 - R + ty, H), gx = reflect_101(x0 - R + tx, W);
-        bool inrect = (gy >= mk.y0 && gy < ye && gx >= mk.x0 && gx < xe);
-        bool cov = inrect && s_mask[(gy - mk.y0) * mk.w + (gx - mk.x0)];
-        const uint8_t* px = src + ((int64_t)gy * W + gx) * 3;
+    const bool interior = (x0 - R >= 0) && (x0 + BTW + R <= W) && (y0 - R >= 0) && (y0 + BTH + R <= H) && ((W * 3) % 4 == 0);
+    if (interior) {
+        // byte row segment [(x0-R)*3, (x0+64+R)*3) of each staged row, fetched as aligned dwords
+        const int b0 = (x0 - R) * 3, nbytes = sw * 3;
+        const int d0 = b0 >> 2, nd = ((b0 + nbytes + 3) >> 2) - d0;
+        for (int i = threadIdx.x; i < sh * nd; i += kThreads) {
+            const int ty = i / nd, di = i - ty * nd;
+            const int gy = y0 - R + ty;
+            const uint32_t wd = reinterpret_cast<const uint32_t*>(src + (int64_t)gy * W * 3)[d0 + di];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = (float)px[c] / 255.0f;
-            if (SNOW) { v = v + pa; v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
-            else { v = v * pm; v = v + pa; }
-            s_src[(ty * BSW + tx) * 3 + c] = cov ? col[c] : v;
+            for (int k = 0; k < 4; ++k) {
+                const int tb = (d0 + di) * 4 + k - b0;                  // byte position inside the staged row
+                if (tb >= 0 && tb < nbytes) {
+                    const int px = tb / 3, c = tb - px * 3;
+                    const bool cov = s_mask[(gy - mk.y0) * mk.w + (x0 - R + px - mk.x0)];
+                    s_src[ty * BSW * 3 + tb] = cov ? col[c] : L.in[(wd >> (8 * k)) & 0xFF];
+                }
+            }
+        }
+    } else {
+        for (int i = threadIdx.x; i < sh * sw; i += kThreads) {
+            const int ty = i / sw, tx = i - ty * sw;
+            const int gy = reflect_101(y0 - R + ty, H), gx = reflect_101(x0 - R + tx, W);
+            const bool inrect = (gy >= mk.y0 && gy < ye && gx >= mk.x0 && gx < xe);
+            const bool cov = inrect && s_mask[(gy - mk.y0) * mk.w + (gx - mk.x0)];
+            const uint8_t* px = src + ((int64_t)gy * W + gx) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) s_src[(ty * BSW + tx) * 3 + c] = cov ? col[c] : L.in[px[c]];
         }
     }
     __syncthreads();
-    // row pass
-    for (int i = threadIdx.x; i < sh * BTW * 3; i += kThreads) {
-        int c = i % 3, t = i / 3;
-        int ty = t / BTW, tx = t - ty * BTW;
-        const float* s = s_src + (ty * BSW + tx + R) * 3 + c;
-        float acc = bt.k[R] * s[0];
-        for (int j = 1; j <= R; ++j) { float ab = s[-3 * j] + s[3 * j]; float m = bt.k[R + j] * ab; acc = acc + m; }
-        s_row[(ty * BTW + tx) * 3 + c] = acc;
+    // 4. row pass: lane = (staged row, 4 output pixels); k[c]*s0 + sum k[c+j]*(s[-j] + s[+j])
+    for (int i = threadIdx.x; i < sh * (BTW / 4); i += kThreads) {
+        const int ty = i / (BTW / 4), tq = i - ty * (BTW / 4);
+        const float* s = s_src + (ty * BSW + tq * 4) * 3;               // window starts R pixels left of the outputs
+        float win[32];                                                   // (4 + 2*3) * 3 = 30 used
+        const int nwin = (4 + 2 * R) * 3;
+#pragma unroll
+        for (int k = 0; k < (4 + 2 * BRMAX) * 3 / 4 + 1; ++k) {
+            if (4 * k < nwin) {
+                const float4 t = *reinterpret_cast<const float4*>(s + 4 * k);
+                win[4 * k] = t.x; win[4 * k + 1] = t.y; win[4 * k + 2] = t.z; win[4 * k + 3] = t.w;
+            }
+        }
+        float o[12];
+        if (R == 1) {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) { float ab = win[e] + win[e + 6]; float m = bt.k[2] * ab; o[e] = bt.k[1] * win[e + 3] + m; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 12; ++e) {
+                float acc = bt.k[3] * win[e + 9];
+#pragma unroll
+                for (int j = 1; j <= 3; ++j) { float ab = win[e + 9 - 3 * j] + win[e + 9 + 3 * j]; float m = bt.k[3 + j] * ab; acc = acc + m; }
+                o[e] = acc;
+            }
+        }
+        float4* d = reinterpret_cast<float4*>(s_row + (ty * BTW + tq * 4) * 3);
+        d[0] = make_float4(o[0], o[1], o[2], o[3]); d[1] = make_float4(o[4], o[5], o[6], o[7]); d[2] = make_float4(o[8], o[9], o[10], o[11]);
     }
     __syncthreads();
-    // column pass + quantise
+    // 5. column pass + quantise: lane = (tile row, 4 pixels) — exactly one item per lane
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
-    for (int i = threadIdx.x; i < BTH * BTW * 3; i += kThreads) {
-        int c = i % 3, t = i / 3;
-        int ty = t / BTW, tx = t - ty * BTW;
-        int gy = y0 + ty, gx = x0 + tx;
-        if (gy >= H || gx >= W) continue;
-        const float* s = s_row + ((ty + R) * BTW + tx) * 3 + c;
-        float acc = bt.k[R] * s[0];
-        for (int j = 1; j <= R; ++j) { float ab = s[-3 * BTW * j] + s[3 * BTW * j]; float m = bt.k[R + j] * ab; acc = acc + m; }
-        uint8_t q = quant_f32(acc);
-        int64_t p = (int64_t)gy * W + gx;
-        if (dst) dst[p * 3 + c] = q;
-        if (ndst) ndst[(int64_t)c * hw + p] = norm1(q, nc.mean[c], nc.std[c]);
+    {
+        const int ty = threadIdx.x / (BTW / 4), tq = threadIdx.x - ty * (BTW / 4);
+        const int gy = y0 + ty, gx = x0 + tq * 4;
+        if (gy < H && gx < W) {
+            float acc[12], ctr[12];
+            auto ldrow = [&](int rr, float* v) {
+                const float4* p4 = reinterpret_cast<const float4*>(s_row + (rr * BTW + tq * 4) * 3);
+                float4 a = p4[0], b = p4[1], c = p4[2];
+                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+                v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+            };
+            ldrow(ty + R, ctr);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) acc[e] = bt.k[R] * ctr[e];
+            for (int j = 1; j <= R; ++j) {
+                float up[12], dn[12];
+                ldrow(ty + R - j, up); ldrow(ty + R + j, dn);
+#pragma unroll
+                for (int e = 0; e < 12; ++e) { float ab = up[e] + dn[e]; float m = bt.k[R + j] * ab; acc[e] = acc[e] + m; }
+            }
+            uint8_t res[12];
+#pragma unroll
+            for (int e = 0; e < 12; ++e) res[e] = quant_f32(acc[e]);
+            const int nvalid = (W - gx) < 4 ? (W - gx) : 4;
+            const int64_t p = (int64_t)gy * W + gx;
+            if (dst) {
+                if (nvalid == 4 && ((p * 3) & 3) == 0) {
+                    uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
+#pragma unroll
+                    for (int w = 0; w < 3; ++w)
+                        d4[w] = (uint32_t)res[4 * w] | ((uint32_t)res[4 * w + 1] << 8) | ((uint32_t)res[4 * w + 2] << 16) | ((uint32_t)res[4 * w + 3] << 24);
+                } else {
+                    for (int k = 0; k < nvalid * 3; ++k) dst[p * 3 + k] = res[k];
+                }
+            }
+            if (ndst) {
+                if (nvalid == 4 && (p & 3) == 0 && (hw & 3) == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; ++c)
+                        *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
+                            make_float4(L.nrm[c][res[c]], L.nrm[c][res[3 + c]], L.nrm[c][res[6 + c]], L.nrm[c][res[9 + c]]);
+                } else {
+                    for (int c = 0; c < 3; ++c)
+                        for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = L.nrm[c][res[k * 3 + c]];
+                }
+            }
+        }
     }
 }
 
@@ -888,6 +1001,7 @@ static int streak_common(bool snow, const uint8_t* imgs, int H, int W, const aws
     if (n_jobs == 0) return 0;
     if (n_jobs > 65535) return AWSEG_ERANGE;
     if (out == imgs) return AWSEG_EINVAL;            // the blur reads neighbours: not in-place safe
+    if (((uintptr_t)imgs & 3) || (out && ((uintptr_t)out & 3)) || (norm_out && ((uintptr_t)norm_out & 15))) return AWSEG_EALIGN;
     dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, n_jobs);
     if (grid.y > 65535) return AWSEG_ERANGE;
     norm_consts nc = make_nc(mean_host, std_host);

@@ -131,10 +131,12 @@ def label_dtype(t: torch.Tensor) -> int:
     raise AwsegError(f"label/prediction maps must be uint8 or int64, got {t.dtype}")
 
 
-def jobs_to_device(arr: np.ndarray, device) -> torch.Tensor:
-    """Structured numpy job array -> uint8 device tensor (stream-ordered copy)."""
-    raw = torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1).copy())
-    return raw.to(device, non_blocking=True)
+def host_jobs(arr: np.ndarray):
+    """Structured numpy job array -> host pointer (the launcher copies jobs into kernel arguments)."""
+    arr = np.ascontiguousarray(arr)
+    p = arr.ctypes.data_as(C.c_void_p)
+    p._keepalive = arr
+    return p
 
 
 class Workspace:

@@ -17,6 +17,11 @@ constexpr int kThreads = 256;
 
 struct norm_consts { float mean[3]; float std[3]; };
 
+// Per-image jobs travel in the kernel arguments (<= 16 per launch): no device-side job array, no
+// dependent global load at the top of every block, no host->device copy per call.
+constexpr int kMaxJobs = 16;
+template <typename J> struct job_pack { J j[kMaxJobs]; };
+
 __device__ __forceinline__ uint8_t quant_f64(double v)
 {
     // (np.clip(v,0,1)*255).astype(np.uint8)
@@ -123,16 +128,16 @@ __device__ __forceinline__ double fog_noise_at(const double* __restrict__ noise,
 // MODE 0: depth only (writes depth_out); MODE 1: fused depth + fog.
 template <bool PHILOX, int MODE>
 __global__ __launch_bounds__(kThreads)
-void fog_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_fog_job* __restrict__ jobs,
+void fog_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_fog_job> jobs, int job0,
                 const double* __restrict__ noise_all, gauss_taps taps,
                 uint8_t* __restrict__ out, float* __restrict__ norm_out, double* __restrict__ depth_out,
                 norm_consts nc)
 {
     __shared__ double s_in[FIH * FIW];        // 30 KB
     __shared__ double s_v[FTH * FIW];         // 20 KB
-    const awseg_fog_job job = jobs[blockIdx.z];
+    const awseg_fog_job job = jobs.j[blockIdx.z];
     const int64_t hw = (int64_t)H * W;
-    const double* noise = PHILOX ? nullptr : noise_all + (int64_t)blockIdx.z * hw;
+    const double* noise = PHILOX ? nullptr : noise_all + (int64_t)(job0 + blockIdx.z) * hw;
     const int x0 = blockIdx.x * FTW, y0 = blockIdx.y * FTH;
 
     // phase 1: depth_base + noise for the tile and its halo (scipy reflect at the image border)
@@ -158,7 +163,7 @@ void fog_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_fog_
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
-    double* ddst = depth_out ? depth_out + (int64_t)blockIdx.z * hw : nullptr;
+    double* ddst = depth_out ? depth_out + (int64_t)(job0 + blockIdx.z) * hw : nullptr;
     const double A32 = (double)(float)job.atmos;                   // A*ones_like(f32 image), :118
     for (int q = threadIdx.x; q < FTH * (FTW / 4); q += kThreads) {
         int ty = q / (FTW / 4), tq = q - ty * (FTW / 4);
@@ -228,7 +233,7 @@ constexpr int kFogFastThreads = 320;
 struct gauss_taps_f32 { float w[2 * FR + 1]; };
 
 __global__ __launch_bounds__(kFogFastThreads)
-void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_fog_job* __restrict__ jobs,
+void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_fog_job> jobs, int job0,
                      gauss_taps_f32 taps, uint8_t* __restrict__ out, float* __restrict__ norm_out,
                      double* __restrict__ depth_out, norm_consts nc)
 {
@@ -236,7 +241,7 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg
     __shared__ float s_v[FTH * FIW];          // 10 KB
     __shared__ weather_lut L;
     lut_fill(L, nc, norm_out != nullptr);
-    const awseg_fog_job job = jobs[blockIdx.z];
+    const awseg_fog_job job = jobs.j[blockIdx.z];
     const int64_t hw = (int64_t)H * W;
     const int x0 = blockIdx.x * FTW, y0 = blockIdx.y * FTH;
     const float inv_h = 100.0f / (float)H;
@@ -289,7 +294,7 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
-    double* ddst = depth_out ? depth_out + (int64_t)blockIdx.z * hw : nullptr;
+    double* ddst = depth_out ? depth_out + (int64_t)(job0 + blockIdx.z) * hw : nullptr;
     const float beta = (float)job.beta, A32 = (float)job.atmos;
     for (int q = threadIdx.x; q < FTH * (FTW / 4); q += kFogFastThreads) {
         const int ty = q / (FTW / 4), tq = q - ty * (FTW / 4);
@@ -356,13 +361,13 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg
 
 // fog from a caller-provided depth map (the two-step form of the reference).
 __global__ __launch_bounds__(kThreads)
-void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_fog_job* __restrict__ jobs,
+void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_fog_job> jobs, int job0,
                       const double* __restrict__ depth_all, uint8_t* __restrict__ out, float* __restrict__ norm_out,
                       norm_consts nc)
 {
-    const awseg_fog_job job = jobs[blockIdx.y];
+    const awseg_fog_job job = jobs.j[blockIdx.y];
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
-    const double* depth = depth_all + (int64_t)blockIdx.y * hw;
+    const double* depth = depth_all + (int64_t)(job0 + blockIdx.y) * hw;
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
     const double A32 = (double)(float)job.atmos;
@@ -386,16 +391,16 @@ void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_
 // its 12 normals from three Philox calls; parity mode reads the host's float64 draws.
 template <bool PHILOX>
 __global__ __launch_bounds__(kThreads)
-void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_night_job* __restrict__ jobs,
+void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_night_job> jobs, int job0,
                   const double* __restrict__ noise_all, float g0, float g1, float g2,
                   uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
 {
     __shared__ weather_lut L;
     lut_fill(L, nc, norm_out != nullptr);
     __syncthreads();
-    const awseg_night_job job = jobs[blockIdx.y];
+    const awseg_night_job job = jobs.j[blockIdx.y];
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
-    const double* noise = PHILOX ? nullptr : noise_all + (int64_t)blockIdx.y * hw * 3;
+    const double* noise = PHILOX ? nullptr : noise_all + (int64_t)(job0 + blockIdx.y) * hw * 3;
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
     const float bf = (float)job.brightness;                       // Python float x f32 array -> f32, :213
@@ -652,7 +657,7 @@ struct blur_taps { float k[2 * BRMAX + 1]; int r; };
 
 template <bool SNOW>
 __global__ __launch_bounds__(kThreads)
-void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_prim_job* __restrict__ jobs,
+void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_prim_job> jobs,
                    const int32_t* __restrict__ prims, blur_taps bt3, blur_taps bt7,
                    uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
 {
@@ -662,7 +667,7 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_p
     __shared__ int s_hits[MAXHIT];
     __shared__ int s_nhit;
     __shared__ weather_lut L;
-    const awseg_prim_job job = jobs[blockIdx.z];
+    const awseg_prim_job job = jobs.j[blockIdx.z];
     const blur_taps bt = (SNOW && job.blur_ksize == 7) ? bt7 : bt3;
     const int R = bt.r;
     const int64_t hw = (int64_t)H * W;
@@ -671,6 +676,35 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_p
     const int sw = BTW + 2 * R, sh = BTH + 2 * R;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
+    // Interior tiles: issue the staging loads (aligned dwords of the byte rows) right away; their
+    // latency hides behind the LUT fill, the primitive scan and the rasterisation.
+    const bool interior = (x0 - R >= 0) && (x0 + BTW + R <= W) && (y0 - R >= 0) && (y0 + BTH + R <= H) && ((W * 3) % 4 == 0);
+    const int b0 = (x0 - R) * 3, nbytes = sw * 3;
+    const int d0 = b0 >> 2, nd = ((b0 + nbytes + 3) >> 2) - d0;
+    constexpr int kPre = (BSH * 56 + kThreads - 1) / kThreads;          // <= 56 dwords per staged row
+    uint32_t pre[kPre];
+    if (interior) {
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int i = threadIdx.x + u * kThreads;
+            if (i < sh * nd) {
+                const int ty = i / nd, di = i - ty * nd;
+                pre[u] = reinterpret_cast<const uint32_t*>(src + (int64_t)(y0 - R + ty) * W * 3)[d0 + di];
+            }
+        }
+    }
+    // this lane's primitives for the bounding-box scan (two per lane cover the reference's <= 500 drops)
+    const int32_t* pl = prims + (int64_t)job.prim_offset * (SNOW ? 3 : 5);
+    constexpr int PW = SNOW ? 3 : 5;
+    int pv[2][5];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = threadIdx.x + u * kThreads;
+        if (i < job.prim_count) {
+#pragma unroll
+            for (int f = 0; f < PW; ++f) pv[u][f] = pl[i * PW + f];
+        }
+    }
     // pre-blur value of an input byte: haze (:134-135) or brightness boost + clip (:179-180)
     float pm, pa;
     if (SNOW) { pm = 1.f; pa = (float)(job.intensity * 0.2); }
@@ -696,14 +730,16 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_p
     if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
     // 1. which primitives touch this tile (bounding boxes, all lanes)
-    const int32_t* pl = prims + (int64_t)job.prim_offset * (SNOW ? 3 : 5);
-    for (int i = threadIdx.x; i < job.prim_count; i += kThreads) {
+    for (int i = threadIdx.x, u = 0; i < job.prim_count; i += kThreads, ++u) {
         int lx, hx, ly, hy;
+        int f0, f1, f2, f3 = 0, f4 = 0;
+        if (u < 2) { f0 = pv[u < 1 ? 0 : 1][0]; f1 = pv[u < 1 ? 0 : 1][1]; f2 = pv[u < 1 ? 0 : 1][2]; if (!SNOW) { f3 = pv[u < 1 ? 0 : 1][3]; f4 = pv[u < 1 ? 0 : 1][4]; } }
+        else { f0 = pl[i * PW]; f1 = pl[i * PW + 1]; f2 = pl[i * PW + 2]; if (!SNOW) { f3 = pl[i * PW + 3]; f4 = pl[i * PW + 4]; } }
         if (SNOW) {
-            const int cx = pl[i * 3], cy = pl[i * 3 + 1], r = pl[i * 3 + 2];
+            const int cx = f0, cy = f1, r = f2;
             lx = cx - r; hx = cx + r; ly = cy - r; hy = cy + r;
         } else {
-            const int ax = pl[i * 5], ay = pl[i * 5 + 1], bx = pl[i * 5 + 2], by = pl[i * 5 + 3], th = pl[i * 5 + 4];
+            const int ax = f0, ay = f1, bx = f2, by = f3, th = f4;
             const int mg = th <= 1 ? 0 : th + 2;
             lx = (ax < bx ? ax : bx) - mg; hx = (ax > bx ? ax : bx) + mg;
             ly = (ay < by ? ay : by) - mg; hy = (ay > by ? ay : by) + mg;
@@ -729,15 +765,15 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, const awseg_p
     __syncthreads();
     // 3. stage the pre-blur float image of tile + halo
     const float col[3] = { SNOW ? 1.0f : 0.8f, SNOW ? 1.0f : 0.9f, 1.0f };
-    const bool interior = (x0 - R >= 0) && (x0 + BTW + R <= W) && (y0 - R >= 0) && (y0 + BTH + R <= H) && ((W * 3) % 4 == 0);
     if (interior) {
-        // byte row segment [(x0-R)*3, (x0+64+R)*3) of each staged row, fetched as aligned dwords
-        const int b0 = (x0 - R) * 3, nbytes = sw * 3;
-        const int d0 = b0 >> 2, nd = ((b0 + nbytes + 3) >> 2) - d0;
-        for (int i = threadIdx.x; i < sh * nd; i += kThreads) {
+        // byte row segment [(x0-R)*3, (x0+64+R)*3) of each staged row (prefetched dwords) -> float row
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int i = threadIdx.x + u * kThreads;
+            if (i >= sh * nd) continue;
             const int ty = i / nd, di = i - ty * nd;
             const int gy = y0 - R + ty;
-            const uint32_t wd = reinterpret_cast<const uint32_t*>(src + (int64_t)gy * W * 3)[d0 + di];
+            const uint32_t wd = pre[u];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int tb = (d0 + di) * 4 + k - b0;                  // byte position inside the staged row
@@ -862,6 +898,13 @@ void density_field_kernel(int64_t hw, uint64_t seed, const float* __restrict__ s
     }
 }
 
+template <typename J> job_pack<J> pack_jobs(const J* jobs, int first, int count)
+{
+    job_pack<J> p;
+    for (int i = 0; i < kMaxJobs; ++i) p.j[i] = jobs[first + (i < count ? i : 0)];
+    return p;
+}
+
 norm_consts make_nc(const float* mean, const float* std)
 {
     norm_consts nc;
@@ -917,22 +960,23 @@ static int fog_common(int mode, const uint8_t* imgs, int H, int W, const awseg_f
     if (mode == 1 && !imgs) return AWSEG_EINVAL;
     if (mode == 0 && !depth_out) return AWSEG_EINVAL;
     if (n_jobs == 0) return 0;
-    if (n_jobs > 65535) return AWSEG_ERANGE;
     gauss_taps t;
     for (int i = 0; i < 2 * FR + 1; ++i) t.w[i] = taps_host[i];
-    dim3 grid((W + FTW - 1) / FTW, (H + FTH - 1) / FTH, n_jobs);
-    if (grid.y > 65535) return AWSEG_ERANGE;
+    if ((H + FTH - 1) / FTH > 65535) return AWSEG_ERANGE;
     norm_consts nc = make_nc(mean_host, std_host);
-#define AWSEG_FOG(P, M) hipLaunchKernelGGL((fog_kernel<P, M>), grid, dim3(kThreads), 0, s, imgs, H, W, jobs, noise, t, out, norm_out, depth_out, nc)
-    if (noise) { if (mode) AWSEG_FOG(false, 1); else AWSEG_FOG(false, 0); }
-    else if (mode == 0) AWSEG_FOG(true, 0);          // depth-only request keeps the float64 pipeline
-    else {
-        gauss_taps_f32 tf;
-        for (int i = 0; i < 2 * FR + 1; ++i) tf.w[i] = (float)taps_host[i];
-        hipLaunchKernelGGL(fog_fast_kernel, grid, dim3(kFogFastThreads), 0, s, imgs, H, W, jobs, tf, out, norm_out, depth_out, nc);
-    }
+    gauss_taps_f32 tf;
+    for (int i = 0; i < 2 * FR + 1; ++i) tf.w[i] = (float)taps_host[i];
+    for (int j0 = 0; j0 < n_jobs; j0 += kMaxJobs) {
+        const int cnt = n_jobs - j0 < kMaxJobs ? n_jobs - j0 : kMaxJobs;
+        const job_pack<awseg_fog_job> pk = pack_jobs(jobs, j0, cnt);
+        dim3 grid((W + FTW - 1) / FTW, (H + FTH - 1) / FTH, cnt);
+#define AWSEG_FOG(P, M) hipLaunchKernelGGL((fog_kernel<P, M>), grid, dim3(kThreads), 0, s, imgs, H, W, pk, j0, noise, t, out, norm_out, depth_out, nc)
+        if (noise) { if (mode) AWSEG_FOG(false, 1); else AWSEG_FOG(false, 0); }
+        else if (mode == 0) AWSEG_FOG(true, 0);      // depth-only request keeps the float64 pipeline
+        else hipLaunchKernelGGL(fog_fast_kernel, grid, dim3(kFogFastThreads), 0, s, imgs, H, W, pk, j0, tf, out, norm_out, depth_out, nc);
 #undef AWSEG_FOG
-    AWSEG_LAUNCH_CHECK();
+        AWSEG_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -962,10 +1006,13 @@ AWSEG_API int awseg_fog_apply(const uint8_t* imgs, int height, int width, const 
     if (n_jobs == 0) return 0;
     if (n_jobs > 65535) return AWSEG_ERANGE;
     const int64_t hw = (int64_t)height * width;
-    dim3 grid(grid_for(hw, n_jobs), n_jobs);
-    hipLaunchKernelGGL(fog_apply_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, jobs, depth, out, norm_out,
-                       make_nc(mean_host, std_host));
-    AWSEG_LAUNCH_CHECK();
+    for (int j0 = 0; j0 < n_jobs; j0 += kMaxJobs) {
+        const int cnt = n_jobs - j0 < kMaxJobs ? n_jobs - j0 : kMaxJobs;
+        dim3 grid(grid_for(hw, cnt), cnt);
+        hipLaunchKernelGGL(fog_apply_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, pack_jobs(jobs, j0, cnt), j0, depth,
+                           out, norm_out, make_nc(mean_host, std_host));
+        AWSEG_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -980,15 +1027,19 @@ AWSEG_API int awseg_night_apply(const uint8_t* imgs, int height, int width, cons
     const int64_t hw = (int64_t)height * width;
     if ((hw * 3) & 3) return AWSEG_EALIGN;           // per-image bases must stay 4-byte aligned
     if (((uintptr_t)imgs & 3) || (out && ((uintptr_t)out & 3)) || (noise && ((uintptr_t)noise & 15))) return AWSEG_EALIGN;
-    dim3 grid(grid_for((hw + 3) / 4, n_jobs), n_jobs);
     norm_consts nc = make_nc(mean_host, std_host);
-    if (noise)
-        hipLaunchKernelGGL((night_kernel<false>), grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, jobs, noise,
-                           gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc);
-    else
-        hipLaunchKernelGGL((night_kernel<true>), grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, jobs, noise,
-                           gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc);
-    AWSEG_LAUNCH_CHECK();
+    for (int j0 = 0; j0 < n_jobs; j0 += kMaxJobs) {
+        const int cnt = n_jobs - j0 < kMaxJobs ? n_jobs - j0 : kMaxJobs;
+        const job_pack<awseg_night_job> pk = pack_jobs(jobs, j0, cnt);
+        dim3 grid(grid_for((hw + 3) / 4, cnt), cnt);
+        if (noise)
+            hipLaunchKernelGGL((night_kernel<false>), grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, pk, j0, noise,
+                               gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc);
+        else
+            hipLaunchKernelGGL((night_kernel<true>), grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, pk, j0, noise,
+                               gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc);
+        AWSEG_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -1002,17 +1053,21 @@ static int streak_common(bool snow, const uint8_t* imgs, int H, int W, const aws
     if (n_jobs > 65535) return AWSEG_ERANGE;
     if (out == imgs) return AWSEG_EINVAL;            // the blur reads neighbours: not in-place safe
     if (((uintptr_t)imgs & 3) || (out && ((uintptr_t)out & 3)) || (norm_out && ((uintptr_t)norm_out & 15))) return AWSEG_EALIGN;
-    dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, n_jobs);
-    if (grid.y > 65535) return AWSEG_ERANGE;
+    if ((H + BTH - 1) / BTH > 65535) return AWSEG_ERANGE;
     norm_consts nc = make_nc(mean_host, std_host);
-    if (snow) {
-        hipLaunchKernelGGL((streak_kernel<true>), grid, dim3(kThreads), 0, s, imgs, H, W, jobs, prims, make_blur(3, 1.0),
-                           make_blur(7, 1.0), out, norm_out, nc);
-    } else {
-        blur_taps b = make_blur(3, 0.5);
-        hipLaunchKernelGGL((streak_kernel<false>), grid, dim3(kThreads), 0, s, imgs, H, W, jobs, prims, b, b, out, norm_out, nc);
+    for (int j0 = 0; j0 < n_jobs; j0 += kMaxJobs) {
+        const int cnt = n_jobs - j0 < kMaxJobs ? n_jobs - j0 : kMaxJobs;
+        const job_pack<awseg_prim_job> pk = pack_jobs(jobs, j0, cnt);
+        dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, cnt);
+        if (snow) {
+            hipLaunchKernelGGL((streak_kernel<true>), grid, dim3(kThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 1.0),
+                               make_blur(7, 1.0), out, norm_out, nc);
+        } else {
+            blur_taps b = make_blur(3, 0.5);
+            hipLaunchKernelGGL((streak_kernel<false>), grid, dim3(kThreads), 0, s, imgs, H, W, pk, prims, b, b, out, norm_out, nc);
+        }
+        AWSEG_LAUNCH_CHECK();
     }
-    AWSEG_LAUNCH_CHECK();
     return 0;
 }
 

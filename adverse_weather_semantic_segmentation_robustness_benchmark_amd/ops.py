@@ -187,9 +187,9 @@ def prim_jobs(images, intensities, prim_lists, ksizes=None):
 
 def synthetic_depth(h: int, w: int, jobs: np.ndarray, device, noise: Optional[torch.Tensor] = None) -> torch.Tensor:
     """PKG/data/preprocessing.py:227-248 -> float64 [n_jobs,H,W]."""
-    jd = N.jobs_to_device(jobs, device)
+    jd = N.host_jobs(jobs)
     out = torch.empty(len(jobs), h, w, dtype=torch.float64, device=device)
-    N.call("awseg_synthetic_depth", h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out), N.stream())
+    N.call("awseg_synthetic_depth", h, w, jd, len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out), N.stream())
     return out
 
 
@@ -200,13 +200,13 @@ def fog(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = No
     depth+fog with `noise` (parity mode) or in-kernel Philox (noise None)."""
     imgs = imgs.contiguous()
     _, h, w, _ = imgs.shape
-    jd = N.jobs_to_device(jobs, imgs.device)
+    jd = N.host_jobs(jobs)
     m, s = _mean_std(mean, std)
     if depth is not None:
-        N.call("awseg_fog_apply", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(depth.contiguous()), N.ptr(out),
+        N.call("awseg_fog_apply", N.ptr(imgs), h, w, jd, len(jobs), N.ptr(depth.contiguous()), N.ptr(out),
                                         N.ptr(norm_out), N.host(m), N.host(s), N.stream())
     else:
-        N.call("awseg_fog_fused", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out),
+        N.call("awseg_fog_fused", N.ptr(imgs), h, w, jd, len(jobs), N.ptr(noise), N.host(_TAPS), N.ptr(out),
                                         N.ptr(norm_out), N.ptr(depth_out), N.host(m), N.host(s), N.stream())
 
 
@@ -215,9 +215,9 @@ def night(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = 
     """_apply_night (PKG/data/preprocessing.py:204-225)."""
     imgs = imgs.contiguous()
     _, h, w, _ = imgs.shape
-    jd = N.jobs_to_device(jobs, imgs.device)
+    jd = N.host_jobs(jobs)
     m, s = _mean_std(mean, std)
-    N.call("awseg_night_apply", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(noise), N.host(NIGHT_GAINS), N.ptr(out),
+    N.call("awseg_night_apply", N.ptr(imgs), h, w, jd, len(jobs), N.ptr(noise), N.host(NIGHT_GAINS), N.ptr(out),
                                       N.ptr(norm_out), N.host(m), N.host(s), N.stream())
 
 
@@ -225,10 +225,10 @@ def rain(imgs: torch.Tensor, jobs: np.ndarray, drops: np.ndarray, out=None, norm
     """_apply_rain (PKG/data/preprocessing.py:125-168)."""
     imgs = imgs.contiguous()
     _, h, w, _ = imgs.shape
-    jd = N.jobs_to_device(jobs, imgs.device)
+    jd = N.host_jobs(jobs)
     pd = torch.from_numpy(np.ascontiguousarray(drops, dtype=np.int32)).to(imgs.device, non_blocking=True)
     m, s = _mean_std(mean, std)
-    N.call("awseg_rain_apply", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
+    N.call("awseg_rain_apply", N.ptr(imgs), h, w, jd, len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
                                      N.host(m), N.host(s), N.stream())
 
 
@@ -236,10 +236,10 @@ def snow(imgs: torch.Tensor, jobs: np.ndarray, flakes: np.ndarray, out=None, nor
     """_apply_snow (PKG/data/preprocessing.py:170-202)."""
     imgs = imgs.contiguous()
     _, h, w, _ = imgs.shape
-    jd = N.jobs_to_device(jobs, imgs.device)
+    jd = N.host_jobs(jobs)
     pd = torch.from_numpy(np.ascontiguousarray(flakes, dtype=np.int32)).to(imgs.device, non_blocking=True)
     m, s = _mean_std(mean, std)
-    N.call("awseg_snow_apply", N.ptr(imgs), h, w, N.ptr(jd), len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
+    N.call("awseg_snow_apply", N.ptr(imgs), h, w, jd, len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
                                      N.host(m), N.host(s), N.stream())
 
 

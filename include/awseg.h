@@ -58,9 +58,10 @@ int         awseg_abi_version(void);          /* bumps when a signature changes 
 const char* awseg_error_string(int code);     /* host string for any return code */
 int         awseg_device_count(void);         /* hipGetDeviceCount, 0 when no GPU */
 
-/* Per-image jobs of the batched weather kernels.  `image` indexes the [B,H,W,3] batch for
- * both input and output; the job's own position j indexes the per-job arrays (noise,
- * depth_out).  Plain C layout (numpy dtype with align=True reproduces it). */
+/* Per-image jobs of the batched weather kernels: HOST arrays (they travel in the kernel
+ * arguments, 16 per launch).  `image` indexes the [B,H,W,3] batch for both input and output;
+ * the job's own position j indexes the per-job device arrays (noise, depth_out).  Plain C
+ * layout (numpy dtype with align=True reproduces it). */
 typedef struct awseg_fog_job {
     int32_t  image; int32_t _pad;
     double   beta;            /* preprocessing.py:113 */
@@ -227,7 +228,7 @@ int awseg_night_apply(const uint8_t* imgs, int height, int width,
  * haze: v = v*(1-0.3I) + 0.3I*0.7 (float32); streaks: line segments
  * (x0,y0,x1,y1,thickness) painted with colour (.8,.9,1.0); 3x3 Gaussian blur
  * sigma 0.5, BORDER_REFLECT_101, float32; quantise.  drops: device int32[n,5],
- * jobs[j] names its slice.  OpenCV's rasteriser is not available offline: the
+ * jobs[j] (host) names its slice.  OpenCV's rasteriser is not available offline: the
  * coverage rule is stated in oracle/awseg_oracle.c (parity unpinned).
  * out must not alias imgs.
  */

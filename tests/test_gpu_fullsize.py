@@ -1,0 +1,196 @@
+"""-m gpu: parity at BASELINE.json's full size (1024x2048, B up to 8) through size-independent
+properties, plus the C1 configuration (DeepLabV3+ only, fog only, 256x512) end to end against the
+CPU oracle path."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+H, W, C = 1024, 2048, 19
+
+
+@pytest.fixture(scope="module")
+def ops(native):
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import ops
+    return ops
+
+
+def test_fullsize_confusion_invariants(ops):
+    """counts sum to the number of non-ignored pixels; row sums are the label histogram; column sums
+    the prediction histogram; the fused logits path equals argmax-then-count; slots partition slot 0."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B = 4
+    s1 = torch.randn(B, C, H, W, device="cuda", generator=g)
+    s2 = torch.randn(B, C, H, W, device="cuda", generator=g)
+    lab = torch.randint(0, C, (B, H, W), device="cuda", generator=g)
+    lab[torch.rand(B, H, W, device="cuda", generator=g) < 0.03] = 255
+    lab64 = lab
+    w = torch.tensor([0.25, 0.75], device="cuda"); T = torch.tensor([2.0], device="cuda")
+    counts = ops.new_counts(C, "cuda", 6); oob = torch.zeros(1, dtype=torch.int64, device="cuda")
+    cond = torch.tensor([0, 1, 1, 4], dtype=torch.int32, device="cuda")
+    logits, pred = ops.combine_argmax_confusion(s1, s2, 0, w, T, want_logits=True, want_pred=True, label=lab64, counts=counts,
+                                                oob=oob, cond=cond, wrap_u8=False)
+    ref_logits = (w[0] * s1 + w[1] * s2) / T                                # torch evaluates the same 4 roundings
+    assert torch.equal(logits, ref_logits)
+    assert torch.equal(pred, ref_logits.argmax(dim=1))
+    cm = counts[0].view(C, C)
+    valid = lab64 != 255
+    assert int(cm.sum()) == int(valid.sum()) and oob.item() == 0
+    assert torch.equal(cm.sum(dim=1), torch.bincount(lab64[valid], minlength=C))
+    assert torch.equal(cm.sum(dim=0), torch.bincount(pred[valid], minlength=C))
+    assert torch.equal(counts[1:].sum(dim=0), counts[0])                    # every image has a condition slot here
+    assert int(counts[2].sum()) == int(valid[1:3].sum()) and int(counts[3].sum()) == 0
+    # reference op sequence on the device as the checker (index_add_ of ones)
+    idx = (lab64[valid] * C + pred[valid])
+    ref = torch.zeros(C * C, dtype=torch.int64, device="cuda").index_add_(0, idx, torch.ones_like(idx))
+    assert torch.equal(counts[0], ref)
+    # from-predictions kernel agrees, for both dtypes, and is additive
+    c2 = ops.new_counts(C, "cuda")
+    ops.confusion_accumulate(pred.to(torch.uint8), lab64, C, c2, oob, wrap_u8=False)
+    assert torch.equal(c2[0], ref)
+    ops.confusion_accumulate(pred, lab64, C, c2, oob, wrap_u8=False)
+    assert torch.equal(c2[0], 2 * ref)
+
+
+def test_fullsize_uint8_wrap_is_the_reference_quirk(ops):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    pred = torch.randint(0, C, (2, H, W), device="cuda", generator=g)
+    lab = torch.randint(0, C, (2, H, W), device="cuda", generator=g).to(torch.uint8)
+    counts = ops.new_counts(C, "cuda"); oob = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.confusion_accumulate(pred, lab, C, counts, oob)                     # uint8 labels -> wrap on
+    idx = (lab.view(-1) * C).to(torch.int64) + pred.view(-1)                # uint8 * int wraps mod 256 in torch too
+    ref = torch.zeros(C * C, dtype=torch.int64, device="cuda").index_add_(0, idx, torch.ones_like(idx))
+    assert torch.equal(counts[0], ref)
+
+
+def test_fullsize_weather_properties(ops, oracle):
+    g = torch.Generator(device="cuda").manual_seed(2)
+    B = 5
+    imgs = torch.randint(0, 255, (B, H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data.preprocessing import WeatherDegradationTransforms
+    tf = WeatherDegradationTransforms(seed=3, rng="philox")
+    conds = ["clean", "fog", "rain", "snow", "night"]
+    out = torch.empty_like(imgs)
+    norm = torch.empty(B, 3, H, W, device="cuda")
+    np.random.seed(3)
+    tf.apply_batch(imgs, conds, out=out, norm_out=norm)
+    assert torch.equal(out[0], imgs[0])                                     # clean is the identity (:78-79)
+    # the fused normalised output is exactly Normalize(ToTensor) of the uint8 output, for every condition
+    ref = ops.normalize(out)
+    assert torch.equal(norm, ref)
+    # fog only brightens towards the atmospheric light / night only darkens (on average)
+    assert out[1].float().mean() > imgs[1].float().mean() and out[4].float().mean() < imgs[4].float().mean()
+    # rain / snow: untouched far-from-streak pixels equal the blurred haze image -> compare one frame with the oracle
+    np.random.seed(3)
+    i_r, drops = oracle.draw_rain(H, W, 0.5)
+    jobs, prims = ops.prim_jobs([2], [i_r], [drops])
+    o2 = torch.empty_like(imgs)
+    ops.rain(imgs, jobs, prims, out=o2)
+    assert np.array_equal(o2[2].cpu().numpy(), oracle.rain(imgs[2].cpu().numpy(), i_r, drops))
+    i_s, flakes, k = oracle.draw_snow(H, W, 0.5)
+    jobs, prims = ops.prim_jobs([3], [i_s], [flakes], [7])
+    ops.snow(imgs, jobs, prims, out=o2)
+    assert np.array_equal(o2[3].cpu().numpy(), oracle.snow(imgs[3].cpu().numpy(), i_s, flakes, 7))
+
+
+def test_fullsize_fog_night_parity_mode_vs_oracle(ops, oracle):
+    """One full 1024x2048 frame in parity mode: bit-exact bytes against the (reference-pinned) oracle."""
+    rs = np.random.RandomState(4)
+    img = rs.randint(0, 255, (H, W, 3), dtype=np.uint8)
+    np.random.seed(4)
+    noise, inten = oracle.draw_fog(H, W, None)
+    d = torch.from_numpy(img[None]).cuda()
+    out = torch.empty_like(d)
+    ops.fog(d, ops.fog_jobs([0], [inten]), noise=torch.from_numpy(noise[None]).cuda(), out=out)
+    ref = oracle.fog(img, oracle.synthetic_depth(noise), inten)
+    assert (out[0].cpu().numpy() != ref).sum() == 0
+    i_n, bf, nz = oracle.draw_night(H, W, None)
+    ops.night(d, ops.night_jobs([0], [bf], [i_n]), noise=torch.from_numpy(nz[None]).cuda(), out=out)
+    assert np.array_equal(out[0].cpu().numpy(), oracle.night(img, nz, bf, i_n))
+
+
+def test_fullsize_loss_properties(ops):
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B = 2
+    x = torch.randn(B, C, H, W, device="cuda", generator=g) * 2
+    lab = torch.randint(0, C, (B, H, W), device="cuda", generator=g).to(torch.uint8)
+    dens = torch.rand(B, H, W, device="cuda", generator=g)
+    oob = torch.zeros(1, dtype=torch.int64, device="cuda")
+    mean, pix = ops.fog_ce_forward(x, lab, dens, False, 2.0, oob, want_pixel=True)
+    ref_pix = torch.nn.functional.cross_entropy(x, lab.long(), reduction="none") * (1.0 + 2.0 * dens)
+    assert (pix - ref_pix).abs().max().item() < 1e-4                      # north_star tolerance
+    assert abs(mean.item() - ref_pix.double().mean().item()) < 1e-5
+    grad = ops.fog_ce_backward(x, lab, dens, False, 2.0, torch.ones(1, device="cuda"))
+    assert grad.sum(dim=1).abs().max().item() < 1e-9                      # softmax - onehot sums to zero over classes
+    # linear in the upstream gradient
+    g2 = ops.fog_ce_backward(x, lab, dens, False, 2.0, torch.full((1,), 3.0, device="cuda"))
+    assert torch.allclose(g2, 3.0 * grad, rtol=1e-6, atol=1e-12)
+    xr = x.detach().clone().requires_grad_(True)
+    (torch.nn.functional.cross_entropy(xr, lab.long(), reduction="none") * (1.0 + 2.0 * dens)).mean().backward()
+    assert (grad - xr.grad).abs().max().item() < 1e-9
+
+
+def test_fullsize_head_geometry(ops):
+    """MFMA head at 1024x2048 against torch's as-written op sequence on the same device, on a strip
+    (the as-written op needs 2 GB per frame) and for invariance under translation of the strip."""
+    torch.manual_seed(6)
+    cin, cmid, h, w = 256, 256, 32, 64
+    feat = torch.randn(1, cin, h, w, device="cuda")
+    conv1 = torch.nn.Conv2d(cin, cmid, 3, padding=1).cuda(); bn = torch.nn.BatchNorm2d(cmid).cuda().eval()
+    conv2 = torch.nn.Conv2d(cmid, C, 1).cuda()
+    with torch.no_grad():
+        bn.running_var.uniform_(0.5, 2.0); bn.running_mean.uniform_(-0.2, 0.2)
+        inv = torch.rsqrt(bn.running_var + bn.eps); scale = bn.weight * inv
+        shift = ((conv1.bias - bn.running_mean) * scale + bn.bias).contiguous()
+        g9 = torch.einsum("bchw,ockl->bhwklo", feat, conv1.weight * scale.view(-1, 1, 1, 1)).reshape(1, h, w, 9, cmid).contiguous()
+        got = ops.segformer_head_fused(g9, None, shift, conv2.weight.view(C, cmid).contiguous(), conv2.bias, H, W)
+        up = torch.nn.functional.interpolate(feat, size=(H, W), mode="bilinear", align_corners=False)
+        for (ya, yb) in ((0, 40), (500, 560), (H - 40, H)):              # top border, interior, bottom border
+            lo, hi = max(ya - 1, 0), min(yb + 1, H)
+            ref = conv2(torch.relu(bn(conv1(up[:, :, lo:hi]))))
+            # rows that see the strip's artificial zero padding are dropped, the image's own border rows are kept
+            a = 0 if ya == 0 else 1
+            b = ref.shape[2] if yb == H else ref.shape[2] - 1
+            sl = ref[:, :, a:b]
+            assert (got[:, :, ya:yb] - sl).abs().max().item() < 1e-4 * max(1.0, sl.abs().max().item())
+
+
+def test_c1_config_deeplab_fog_only_end_to_end(ops, oracle):
+    """BASELINE configs[0]: DeepLabV3+ only, fog-only corruption, 256x512 synthetic frames.  GPU path
+    (HIP fog + fused DeepLab + HIP argmax/confusion) vs the CPU oracle path on the same seeded inputs."""
+    import adverse_weather_semantic_segmentation_robustness_benchmark_amd as P
+    from tests.test_gpu_models import calibrate_bn
+    torch.manual_seed(7)
+    h, w, n = 256, 512, 4
+    model = calibrate_bn(P.DeepLabV3PlusModel(num_classes=C, include_depth=False, pretrained=False)).cuda().eval()
+    cpu_model = copy.deepcopy(model).cpu().eval()
+    for m in cpu_model.modules():
+        m.fused_eval = False
+    rs = np.random.RandomState(8)
+    imgs = rs.randint(0, 255, (n, h, w, 3), dtype=np.uint8)
+    labels = rs.randint(0, C, (n, h, w)).astype(np.uint8)
+    tf = P.WeatherDegradationTransforms(rng="numpy")
+    np.random.seed(42)
+    gpu_in = torch.empty(n, 3, h, w, device="cuda")
+    tf.apply_batch(torch.from_numpy(imgs).cuda(), ["fog"] * n, norm_out=gpu_in)
+    np.random.seed(42)
+    cpu_in = np.stack([oracle.normalize(oracle.apply_weather_effect(imgs[i], "fog")) for i in range(n)])
+    assert np.array_equal(gpu_in.cpu().numpy(), cpu_in)                     # bit-exact model inputs
+    counts = ops.new_counts(C, "cuda"); oob = torch.zeros(1, dtype=torch.int64, device="cuda")
+    logits = model(gpu_in)["segmentation"]
+    _, pred = ops.combine_argmax_confusion(logits, None, 3, want_logits=False, want_pred=True, label=torch.from_numpy(labels).cuda(),
+                                           counts=counts, oob=oob)
+    with torch.no_grad():
+        ref_logits = cpu_model(torch.from_numpy(cpu_in))["segmentation"].numpy()
+    scale = max(1.0, np.abs(ref_logits).max())
+    assert np.abs(logits.cpu().numpy() - ref_logits).max() < 2e-4 * scale   # fp32 conv stacks, different summation order
+    ref_pred = oracle.argmax(ref_logits)
+    agree = (pred.cpu().numpy() == ref_pred).mean()
+    assert agree > 0.999                                                    # label flips only on near-ties
+    # kernel-level: counts are exactly the confusion of the GPU's own predictions
+    assert np.array_equal(counts[0].cpu().numpy(), oracle.confusion(pred.cpu().numpy(), labels, C))
+    miou_gpu = oracle.iou_from_counts(counts[0].cpu().numpy(), C)["mean_iou"]
+    miou_cpu = oracle.iou_from_counts(oracle.confusion(ref_pred, labels, C), C)["mean_iou"]
+    assert abs(miou_gpu - miou_cpu) < 1e-3

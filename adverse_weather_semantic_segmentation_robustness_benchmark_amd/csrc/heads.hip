@@ -278,6 +278,167 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// v3: the classifier form with 16-byte LDS accesses.  Row i of o-tile `ot` is channel
+//        o(ot, i) = (ot >> 2) * 128 + 4 * i + (ot & 3)
+// instead of ot*32 + i: a lane then needs the SAME four consecutive floats of a staged cell for four
+// consecutive o-tiles, so the A-operand gather is one ds_read_b128 per (k-slot, tap row) per group
+// of four tiles (lane stride 16 B: conflict-free) — a quarter of the ds_read_b32 + address
+// instructions of v2.  BatchNorm shift (the accumulators' initial value) and the pre-permuted
+// classifier fragments are laid out so that they, too, load as b128.  Everything else is v2.
+// ---------------------------------------------------------------------------------------
+template <int OT>
+__global__ __launch_bounds__(512, 2)
+void head_mfma_classify_kernel(const float* __restrict__ g9, int h, int w, int H, int W, int R,
+                               const float* __restrict__ shift, const float* __restrict__ w2,
+                               const float* __restrict__ b2, int cout, float* __restrict__ out)
+{
+    static_assert(OT % 4 == 0, "groups of four o-tiles");
+    constexpr int CM = OT * 32, NG = OT / 4, kT = 512;
+    extern __shared__ float smem[];
+    float* Gl = smem;                           // [3][4][9][CM]
+    float* s_sh = smem + 108 * CM;              // [OT][2 (hh)][16 (acc reg)]
+    float* s_w2 = s_sh + OT * 32;               // [OT][4 (s2 >> 2)][64 lanes][4 (s2 & 3)]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lo = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, y0 = blockIdx.y * R, x0 = blockIdx.x * 32;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int ibase = bilinear_src(y0 > 0 ? y0 - 1 : 0, sh, h).i0;
+    const int jbase = bilinear_src(x0 > 0 ? x0 - 1 : 0, sw, w).i0;
+    auto chan = [](int ot, int i) { return (ot >> 2) * 128 + 4 * i + (ot & 3); };
+
+    const float* g = g9 + (int64_t)b * h * w * 9 * CM;
+    constexpr int CELL4 = 9 * CM / 4;
+    for (int i = tid; i < 12 * CELL4; i += kT) {
+        int cell = i / CELL4, q = i - cell * CELL4;
+        int ci = ibase + (cell >> 2), cj = jbase + (cell & 3);
+        if (ci > h - 1) ci = h - 1;
+        if (cj > w - 1) cj = w - 1;
+        reinterpret_cast<float4*>(Gl)[i] = reinterpret_cast<const float4*>(g + ((int64_t)ci * w + cj) * 9 * CM)[q];
+    }
+    for (int i = tid; i < OT * 32; i += kT) {
+        const int r = i & 15, h2 = (i >> 4) & 1, ot = i >> 5;
+        s_sh[i] = shift[chan(ot, (r & 3) + 8 * (r >> 2) + 4 * h2)];
+    }
+    for (int i = tid; i < OT * 16 * 64; i += kT) {
+        const int e = i & 3, ln = (i >> 2) & 63, sg = (i >> 8) & 3, ot = i >> 10;
+        const int s2 = sg * 4 + e, cls = ln & 31, kk = ln >> 5;
+        s_w2[i] = (cls < cout) ? w2[(int64_t)cls * CM + chan(ot, (s2 & 3) + 8 * (s2 >> 2) + 4 * kk)] : 0.f;
+    }
+    float cx[6];
+    int lbase[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int k = 2 * s + hh, kx = k >> 2, c = k & 3;
+        const int xx = x0 + lo + kx - 1;
+        float v = 0.f;
+        if (xx >= 0 && xx < W && x0 + lo < W) {
+            src_idx sx = bilinear_src(xx, sw, w);
+            if (sx.i0 - jbase == c) v += sx.l0;
+            if (sx.i1 - jbase == c) v += sx.l1;
+        }
+        cx[s] = v;
+        lbase[s] = (c * 9 + kx) * CM + lo * 4;
+    }
+    float* s_b2 = s_w2 + OT * 16 * 64;          // [32]
+    if (tid < 32) s_b2[tid] = tid < cout ? b2[tid] : 0.f;
+    __syncthreads();
+
+    const int64_t HW = (int64_t)H * W;
+    for (int ry = wv; ry < R; ry += kT / 64) {
+        const int y = y0 + ry;
+        if (y >= H) break;
+        int ub[6]; float lw[6];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            const bool ok = (yy >= 0 && yy < H);
+            src_idx sy = bilinear_src(ok ? yy : 0, sh, h);
+            const int r0 = __builtin_amdgcn_readfirstlane(sy.i0 - ibase), r1 = __builtin_amdgcn_readfirstlane(sy.i1 - ibase);
+            ub[2 * ky] = (r0 * 36 + ky * 3) * CM;
+            ub[2 * ky + 1] = (r1 * 36 + ky * 3) * CM;
+            lw[2 * ky] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ok ? sy.l0 : 0.f)));
+            lw[2 * ky + 1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ok ? sy.l1 : 0.f)));
+        }
+        // A operands of the four tiles of group gi: t[q][s]
+        auto gather4 = [&](int gi, float (*t)[6]) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const float* base = Gl + lbase[s] + gi * 128;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float4 a = *reinterpret_cast<const float4*>(base + ub[j]);
+                    v.x = fmaf(lw[j], a.x, v.x); v.y = fmaf(lw[j], a.y, v.y);
+                    v.z = fmaf(lw[j], a.z, v.z); v.w = fmaf(lw[j], a.w, v.w);
+                }
+                t[0][s] = v.x; t[1][s] = v.y; t[2][s] = v.z; t[3][s] = v.w;
+            }
+        };
+        auto gemm1 = [&](int ot, const float* t) {
+            f32x16 a;
+            const float4* sp = reinterpret_cast<const float4*>(s_sh + (ot * 2 + hh) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float4 v = sp[q]; a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int s = 0; s < 6; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(t[s], cx[s], a, 0, 0, 0);
+            return a;
+        };
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        auto finish = [&](int ot, f32x16& acc) {
+            float wf[16];
+            const float4* wp = reinterpret_cast<const float4*>(s_w2 + (int64_t)ot * 1024 + lane * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float4 v = wp[q * 64]; wf[4 * q] = v.x; wf[4 * q + 1] = v.y; wf[4 * q + 2] = v.z; wf[4 * q + 3] = v.w; }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 16; ++s2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s2], acc[s2], acc2, 0, 0, 0);
+        };
+        // One A-operand buffer: the four tiles' GEMM 1 chains are issued first (their operands are dead
+        // once issued), then the next group's gather runs on the VALU/LDS while the matrix pipe
+        // works through the remaining GEMM 2 chains of this group.
+        float ta[4][6];
+        gather4(0, ta);
+#pragma unroll 1
+        for (int gi = 0; gi < NG; ++gi) {
+            f32x16 accA = gemm1(4 * gi, ta[0]);
+            f32x16 accB = gemm1(4 * gi + 1, ta[1]);
+            finish(4 * gi, accA);
+            accA = gemm1(4 * gi + 2, ta[2]);
+            finish(4 * gi + 1, accB);
+            accB = gemm1(4 * gi + 3, ta[3]);
+            if (gi + 1 < NG) gather4(gi + 1, ta);
+            finish(4 * gi + 2, accA);
+            finish(4 * gi + 3, accB);
+        }
+        if (x0 + lo < W) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cls = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (cls < cout) out[((int64_t)b * cout + cls) * HW + (int64_t)y * W + x0 + lo] = acc2[r] + s_b2[cls];
+            }
+        }
+    }
+}
+
+template <int OT>
+static int launch_head_classify(const float* g9, int64_t batch, int h, int w, int H, int W, int R, const float* shift,
+                                const float* w2, const float* b2, int cout, float* out, hipStream_t s)
+{
+    constexpr int CM = OT * 32;
+    const size_t lds = (size_t)(108 * CM + OT * 32 + OT * 16 * 64 + 32) * sizeof(float);
+    auto kern = head_mfma_classify_kernel<OT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((W + 31) / 32, (H + R - 1) / R, (unsigned)batch);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, g9, h, w, H, W, R, shift, w2, b2, cout, out);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 // host mirror of bilinear_src's i0 / i1 (same float expressions; file is built -ffp-contract=off)
 static void host_src(int dst, float scale, int in_size, int* i0, int* i1)
 {
@@ -392,6 +553,12 @@ static bool force_v1()
     return e && e[0] == '1';
 }
 
+static bool force_v2()
+{
+    const char* e = getenv("AWSEG_HEAD_V2");
+    return e && e[0] == '1';
+}
+
 static int head_dispatch(bool classify, const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
                          const float* scale, const float* shift, const float* w2, const float* b2, int cout,
                          float* out, int out_nhwc, hipStream_t s)
@@ -403,6 +570,10 @@ static int head_dispatch(bool classify, const float* g9, int64_t batch, int cmid
     if ((int64_t)h * w * 9 * cmid > 0x7fffffffLL) return AWSEG_ERANGE;
     const int R = ((cmid % 32) == 0 && cmid <= 256 && (((uintptr_t)g9 & 15) == 0) && !force_v1())
                       ? mfma_tile_rows(h, w, height, width) : 0;
+    if (R > 0 && classify && !scale && !force_v2()) {
+        if (cmid == 256) return launch_head_classify<8>(g9, batch, h, w, height, width, R, shift, w2, b2, cout, out, s);
+        if (cmid == 128) return launch_head_classify<4>(g9, batch, h, w, height, width, R, shift, w2, b2, cout, out, s);
+    }
     if (R > 0) {
 #define AWSEG_HEAD(OTV)                                                                                              \
     case OTV:                                                                                                         \

@@ -357,6 +357,11 @@ def test_segformer_head_mfma_vs_v1_and_torch(ops, cfg, monkeypatch):
         v1 = ops.segformer_head_fused(g9, scale, shift, w2, conv2.bias, H, W)
         monkeypatch.delenv("AWSEG_HEAD_V1")
         assert (got - v1).abs().max().item() < 1e-4 * max(1.0, v1.abs().max().item())
+        # BatchNorm scale folded into g9 (scale=None): the 16-byte-gather kernel (v3) when Cmid is 128 / 256
+        g9f = torch.einsum("bchw,ockl->bhwklo", feat, conv1.weight * scale.view(-1, 1, 1, 1)).reshape(B, h, w, 9, cmid).contiguous()
+        if cmid % 32 == 0 and min(H / h, W / w) >= 17:
+            v3 = ops.segformer_head_fused(g9f, None, shift, w2, conv2.bias, H, W)
+            assert (v3 - v1).abs().max().item() < 1e-4 * max(1.0, v1.abs().max().item())
 
 
 def test_dwconv3x3_nhwc_and_bias_act(ops):

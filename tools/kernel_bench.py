@@ -97,10 +97,10 @@ def main():
     g9 = torch.randn(B, h, w, 9, 256, device=dev)
     sc, sf = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1
     w2, b2 = torch.randn(C, 256, device=dev) * 0.05, torch.zeros(C, device=dev)
-    cases["segformer_head_fused (MFMA)"] = (lambda: ops.segformer_head_fused(g9, sc, sf, w2, b2, H, W), "mfma",
+    cases["segformer_head_fused (MFMA)"] = (lambda: ops.segformer_head_fused(g9, None, sf, w2, b2, H, W), "mfma",
                                              2.0 * (12 * 256 + 256 * 32) * px * B)
     g9d = torch.randn(B, h, w, 9, 128, device=dev)
-    cases["upconv3x3_bn_relu 128ch NHWC (MFMA)"] = (lambda: ops.upconv3x3_bn_relu(g9d, sc[:128].contiguous(), sf[:128].contiguous(), H, W, True),
+    cases["upconv3x3_bn_relu 128ch NHWC (MFMA)"] = (lambda: ops.upconv3x3_bn_relu(g9d, None, sf[:128].contiguous(), H, W, True),
                                                      "mfma", 2.0 * (12 * 128) * px * B)
     xa = torch.randn(B, H // 16, W // 16, 2048, device=dev); wdw = torch.randn(3, 9, 2048, device=dev)
     cases["aspp_depthwise3"] = (lambda: ops.aspp_depthwise3(xa, wdw, (12, 24, 36)), "hbm", 4 * 2048 * 4 * (H // 16) * (W // 16) * B)

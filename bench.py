@@ -86,17 +86,22 @@ def algorithmic_work(name, B, H, W, C, info):
     return "hbm", 0
 
 
-def cpu_baseline(model, H, W, C, seed=0, fwd_div=4):
+def cpu_baseline(model, H, W, C, seed=0, fwd_div=1, max_threads=16):
     """The CPU oracle path ("port") on this box's host cores, on a bounded sample: one full-size
     frame per weather condition through the C oracle transforms + normalise, oracle argmax +
     confusion on one full-size logit map, and the as-written torch-CPU ensemble forward on ONE frame
-    of (H/fwd_div)x(W/fwd_div) whose time is scaled by fwd_div^2 (convolution cost is linear in
-    pixels; the full-size as-written forward takes minutes on the CPU).  A reported baseline, not
-    the optimisation target."""
+    of (H/fwd_div)x(W/fwd_div), time scaled by fwd_div^2 when fwd_div > 1 (convolution cost is
+    linear in pixels).  A reported baseline, not the optimisation target."""
     import copy
     from oracle import cpu_oracle as O
     O.build()
-    cores = os.cpu_count() or 1
+    # a one-GPU box owns a 16-CPU share of the host (more torch threads than that only thrash:
+    # 256 threads ran the same forward 300x slower than 16)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, max_threads))
     torch.set_num_threads(cores)
     rs = np.random.RandomState(seed)
     img = rs.randint(0, 255, (H, W, 3), dtype=np.uint8)

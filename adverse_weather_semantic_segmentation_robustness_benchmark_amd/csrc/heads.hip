@@ -498,53 +498,41 @@ static int launch_head_mfma_nw(const float* g9, int64_t batch, int h, int w, int
 }
 
 // A9: depthwise atrous 3x3 for the three ASPP rates in one pass over x (NHWC, float4 over C).
-// A lane owns four channels and a strip of 4 pixels of one row; per rate the nine weight vectors are
-// loaded once per strip (the taps of a dilated stencil do not overlap inside a strip, so the inputs
-// themselves cannot be reused — the weights can).
+// (A strip-mined variant that hoists the weights was measured 20 % slower: the dilated taps of
+// neighbouring pixels share nothing, and the longer per-lane loop only costs parallelism.)
 __global__ __launch_bounds__(kThreads)
 void aspp_dw3_kernel(const float* __restrict__ x, int64_t batch, int h, int w, int C,
                      const float* __restrict__ wdw, int r0, int r1, int r2, float* __restrict__ out)
 {
-    constexpr int SX = 4;
     const int c4n = C / 4;
-    const int nsx = (w + SX - 1) / SX;
-    const int64_t total = batch * h * nsx * c4n;
+    const int64_t total = batch * h * w * c4n;
     const int64_t plane = batch * (int64_t)h * w * C;
     const int rates[3] = { r0, r1, r2 };
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-        const int c4 = (int)(i % c4n);
-        int64_t t = i / c4n;
-        const int xs = (int)(t % nsx); t /= nsx;
-        const int yy = (int)(t % h);
-        const int64_t b = t / h;
-        const float* xb = x + b * (int64_t)h * w * C + c4 * 4;
+        int c4 = (int)(i % c4n);
+        int64_t p = i / c4n;
+        int xx = (int)(p % w); int64_t t = p / w;
+        int yy = (int)(t % h); int64_t b = t / h;
+        const float* xb = x + b * (int64_t)h * w * C;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int d = rates[r];
-            float4 k[9];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int j = 0; j < 9; ++j) k[j] = *reinterpret_cast<const float4*>(wdw + ((int64_t)r * 9 + j) * C + c4 * 4);
+            for (int ky = 0; ky < 3; ++ky) {
+                int sy = yy + (ky - 1) * d;
+                if (sy < 0 || sy >= h) continue;
 #pragma unroll
-            for (int u = 0; u < SX; ++u) {
-                const int xx = xs * SX + u;
-                if (xx >= w) break;
-                float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int sy = yy + (ky - 1) * d;
-                    if (sy < 0 || sy >= h) continue;
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int sx = xx + (kx - 1) * d;
-                        if (sx < 0 || sx >= w) continue;
-                        const float4 v = *reinterpret_cast<const float4*>(xb + ((int64_t)sy * w + sx) * C);
-                        const float4 kk = k[ky * 3 + kx];
-                        acc.x = fmaf(v.x, kk.x, acc.x); acc.y = fmaf(v.y, kk.y, acc.y);
-                        acc.z = fmaf(v.z, kk.z, acc.z); acc.w = fmaf(v.w, kk.w, acc.w);
-                    }
+                for (int kx = 0; kx < 3; ++kx) {
+                    int sx = xx + (kx - 1) * d;
+                    if (sx < 0 || sx >= w) continue;
+                    float4 v = *reinterpret_cast<const float4*>(xb + ((int64_t)sy * w + sx) * C + c4 * 4);
+                    float4 k = *reinterpret_cast<const float4*>(wdw + ((int64_t)r * 9 + ky * 3 + kx) * C + c4 * 4);
+                    acc.x = fmaf(v.x, k.x, acc.x); acc.y = fmaf(v.y, k.y, acc.y);
+                    acc.z = fmaf(v.z, k.z, acc.z); acc.w = fmaf(v.w, k.w, acc.w);
                 }
-                *reinterpret_cast<float4*>(out + (int64_t)r * plane + ((b * h + yy) * (int64_t)w + xx) * C + c4 * 4) = acc;
             }
+            *reinterpret_cast<float4*>(out + (int64_t)r * plane + p * C + c4 * 4) = acc;
         }
     }
 }
@@ -630,7 +618,7 @@ AWSEG_API int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w,
 {
     if (!x || !wdw || !out || batch < 1 || h < 1 || w < 1 || channels < 4 || (channels & 3)) return AWSEG_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)wdw & 15) || ((uintptr_t)out & 15)) return AWSEG_EALIGN;
-    const int64_t total = batch * h * ((w + 3) / 4) * (channels / 4);
+    const int64_t total = batch * h * w * (channels / 4);
     hipLaunchKernelGGL(aspp_dw3_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, batch,
                        h, w, channels, wdw, rate0, rate1, rate2, out);
     AWSEG_LAUNCH_CHECK();

@@ -159,26 +159,30 @@ void combine_argmax_confusion_kernel(const float* __restrict__ seg1, const float
 }
 
 // Fold the per-block uint32 partial histograms of one image into slot 0 and slot 1+cond[img].
-// grid = (images, ceil(bins/64)); a block owns 64 bins and its 4 waves each sum a quarter of the
-// partials (independent, unrolled loads), then one LDS step combines them: the dependent-load
-// chain is blocks_per_image/4 long and the bins run in parallel across blocks.
-__global__ __launch_bounds__(kThreads)
+// grid = (images, ceil(bins/64)), 1024 threads: a block owns 64 bins and its 16 waves each sum a
+// sixteenth of the partials (independent, unrolled loads), then one LDS step combines them — the
+// dependent-load chain is blocks_per_image/16 long and the bins run in parallel across blocks.
+constexpr int kFoldSlices = 16;
+__global__ __launch_bounds__(kFoldSlices * 64)
 void fold_partials_kernel(const uint32_t* __restrict__ partial, int blocks_per_image, int bins,
                           const int32_t* __restrict__ cond, int n_slots, int64_t* __restrict__ counts)
 {
-    __shared__ unsigned long long s_sum[4][64];
+    __shared__ unsigned long long s_sum[kFoldSlices][64];
     const int img = blockIdx.x;
-    const int k = blockIdx.y * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
+    const int kl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int k = blockIdx.y * 64 + kl;
     const uint32_t* src = partial + (int64_t)img * blocks_per_image * bins;
     unsigned long long s = 0;
     if (k < bins) {
 #pragma unroll 8
-        for (int b = slice; b < blocks_per_image; b += 4) s += src[(int64_t)b * bins + k];
+        for (int b = slice; b < blocks_per_image; b += kFoldSlices) s += src[(int64_t)b * bins + k];
     }
-    s_sum[slice][threadIdx.x & 63] = s;
+    s_sum[slice][kl] = s;
     __syncthreads();
     if (slice == 0 && k < bins) {
-        s = s_sum[0][threadIdx.x] + s_sum[1][threadIdx.x] + s_sum[2][threadIdx.x] + s_sum[3][threadIdx.x];
+        s = 0;
+#pragma unroll
+        for (int j = 0; j < kFoldSlices; ++j) s += s_sum[j][kl];
         if (s) {
             int slot = -1;
             if (cond) { int c = cond[img]; if (c >= 0 && c + 1 < n_slots) slot = c + 1; }
@@ -392,7 +396,7 @@ static int fused_impl(int mode, const float* seg1, const float* seg2, int64_t ba
 #undef AWSEG_MODE
     AWSEG_LAUNCH_CHECK();
     if (label) {
-        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)batch, (C * C + 63) / 64), dim3(kThreads), 0, s, partial, bpi,
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)batch, (C * C + 63) / 64), dim3(kFoldSlices * 64), 0, s, partial, bpi,
                            C * C, cond, n_slots, counts);
         AWSEG_LAUNCH_CHECK();
     }
@@ -455,7 +459,7 @@ AWSEG_API int awseg_confusion_accumulate(const void* pred, int pred_dtype, const
     else return AWSEG_EINVAL;
 #undef AWSEG_CONF
     AWSEG_LAUNCH_CHECK();
-    hipLaunchKernelGGL(fold_partials_kernel, dim3(1, (num_classes * num_classes + 63) / 64), dim3(kThreads), 0, s, partial, nblk,
+    hipLaunchKernelGGL(fold_partials_kernel, dim3(1, (num_classes * num_classes + 63) / 64), dim3(kFoldSlices * 64), 0, s, partial, nblk,
                        num_classes * num_classes, (const int32_t*)nullptr, 1, counts);
     AWSEG_LAUNCH_CHECK();
     return 0;

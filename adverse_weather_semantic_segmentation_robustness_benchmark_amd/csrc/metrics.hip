@@ -54,7 +54,7 @@ template <int PDT> __device__ __forceinline__ void st_pred(void* pred, int64_t i
 // VEC: pixels per lane per step (4 -> float4 path, 1 -> scalar fallback for odd shapes).
 // grid = (blocks_per_image, B); block b of image y writes partial[(y*gridDim.x + b)][C*C].
 // ---------------------------------------------------------------------------------------
-template <int MODE, int VEC, int LDT, int PDT>
+template <int MODE, int VEC, int LDT, int PDT, int CT>
 __global__ __launch_bounds__(kThreads)
 void combine_argmax_confusion_kernel(const float* __restrict__ seg1, const float* __restrict__ seg2,
                                      int C, int64_t hw,
@@ -64,6 +64,7 @@ void combine_argmax_confusion_kernel(const float* __restrict__ seg1, const float
                                      uint32_t* __restrict__ partial, int64_t* __restrict__ oob)
 {
     __shared__ uint32_t hist[kMaxBins];
+    if (CT > 0) C = CT;                      // compile-time class count: the channel walk fully unrolls
     const int bins = C * C;
     const bool do_hist = (label != nullptr);
     if (do_hist) {
@@ -106,7 +107,8 @@ void combine_argmax_confusion_kernel(const float* __restrict__ seg1, const float
 #pragma unroll
             for (int k = 0; k < VEC; ++k) use[k] = (1.0f / s1[k] > 1.0f / s2[k]) ? 1.f : 0.f;
         }
-#pragma unroll 4
+        constexpr int kUnroll = CT > 0 ? CT : 4;
+#pragma unroll kUnroll
         for (int c = 0; c < C; ++c) {
             float x[VEC], y[VEC], r[VEC];
             if constexpr (VEC == 4) {
@@ -342,13 +344,20 @@ int launch_fused(const float* seg1, const float* seg2, int64_t batch, int C, int
                  int bpi, hipStream_t s)
 {
     dim3 grid(bpi, (unsigned)batch), block(kThreads);
-#define AWSEG_FUSED(L, P) \
-    hipLaunchKernelGGL((combine_argmax_confusion_kernel<MODE, VEC, L, P>), grid, block, 0, s, seg1, seg2, C, hw, \
+#define AWSEG_FUSED(L, P, CTV) \
+    hipLaunchKernelGGL((combine_argmax_confusion_kernel<MODE, VEC, L, P, CTV>), grid, block, 0, s, seg1, seg2, C, hw, \
                        weights, temperature, out_logits, pred, label, ignore_index, wrap, partial, oob)
-    if (ldt == AWSEG_U8 && pdt == AWSEG_U8) AWSEG_FUSED(AWSEG_U8, AWSEG_U8);
-    else if (ldt == AWSEG_U8) AWSEG_FUSED(AWSEG_U8, AWSEG_I64);
-    else if (pdt == AWSEG_U8) AWSEG_FUSED(AWSEG_I64, AWSEG_U8);
-    else AWSEG_FUSED(AWSEG_I64, AWSEG_I64);
+    if (C == 19 && VEC == 4 && MODE != 1) {          // Cityscapes: fully unrolled channel walk
+        if (ldt == AWSEG_U8 && pdt == AWSEG_U8) AWSEG_FUSED(AWSEG_U8, AWSEG_U8, 19);
+        else if (ldt == AWSEG_U8) AWSEG_FUSED(AWSEG_U8, AWSEG_I64, 19);
+        else if (pdt == AWSEG_U8) AWSEG_FUSED(AWSEG_I64, AWSEG_U8, 19);
+        else AWSEG_FUSED(AWSEG_I64, AWSEG_I64, 19);
+        return 0;
+    }
+    if (ldt == AWSEG_U8 && pdt == AWSEG_U8) AWSEG_FUSED(AWSEG_U8, AWSEG_U8, 0);
+    else if (ldt == AWSEG_U8) AWSEG_FUSED(AWSEG_U8, AWSEG_I64, 0);
+    else if (pdt == AWSEG_U8) AWSEG_FUSED(AWSEG_I64, AWSEG_U8, 0);
+    else AWSEG_FUSED(AWSEG_I64, AWSEG_I64, 0);
 #undef AWSEG_FUSED
     return 0;
 }

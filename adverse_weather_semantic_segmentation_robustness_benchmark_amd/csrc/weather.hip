@@ -518,9 +518,9 @@ __device__ void m_line_thin(const tile_mask& k, int x0, int y0, int x1, int y1, 
     if (dy < 0) dy = -dy;
     if (dx >= dy) {
         if (dx == 0) { if (lane == 0) m_point(k, x0, y0); return; }
-        for (int i = lane; i <= dx; i += 64) m_point(k, x0 + i, y0 + sy * (int)((2LL * dy * i + dx - 1) / (2LL * dx)));
+        for (int i = lane; i <= dx; i += 64) m_point(k, x0 + i, y0 + sy * ((2 * dy * i + dx - 1) / (2 * dx)));   // |values| < 2^31 for any image
     } else {
-        for (int i = lane; i <= dy; i += 64) m_point(k, x0 + (int)((2LL * dx * i + dy - 1) / (2LL * dy)), y0 + sy * i);
+        for (int i = lane; i <= dy; i += 64) m_point(k, x0 + (2 * dx * i + dy - 1) / (2 * dy), y0 + sy * i);
     }
 }
 // cv::Circle(fill): the midpoint recurrence is wave-uniform, each of its spans is filled by the lanes.
@@ -542,6 +542,10 @@ __device__ void m_disc(const tile_mask& k, int cx, int cy, int r, int lane)
 }
 constexpr int XY_SHIFT = 16;
 constexpr int XY_ONE = 1 << XY_SHIFT;
+// Truncating int64 division for |a| < 2^52: the correctly rounded double quotient truncates to the
+// exact integer quotient (a non-integer quotient is >= 1/b away from an integer, more than its
+// ulp), and costs a fraction of the 64-bit integer division sequence.
+__device__ __forceinline__ int64_t div_trunc(int64_t a, int64_t b) { return (int64_t)((double)a / (double)b); }
 // cv::Line2 (16.16 fixed-point DDA): position after j steps is start + j*step -> one step per lane.
 __device__ void m_line2(const tile_mask& k, int64_t x1, int64_t y1, int64_t x2, int64_t y2, int lane)
 {
@@ -550,14 +554,14 @@ __device__ void m_line2(const tile_mask& k, int64_t x1, int64_t y1, int64_t x2, 
     if (lane == 0) m_point(k, (int)((x2 + (XY_ONE >> 1)) >> XY_SHIFT), (int)((y2 + (XY_ONE >> 1)) >> XY_SHIFT));
     if (ax > ay) {
         if (dx < 0) { int64_t t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dy = -dy; }
-        const int64_t y_step = (dy * XY_ONE) / (ax | 1);
+        const int64_t y_step = div_trunc(dy * XY_ONE, ax | 1);
         const int ecount = (int)((x2 - x1) >> XY_SHIFT);
         x1 += XY_ONE >> 1; y1 += XY_ONE >> 1;
         const int64_t xb = x1 >> XY_SHIFT;
         for (int j = lane; j <= ecount; j += 64) m_point(k, (int)(xb + j), (int)((y1 + j * y_step) >> XY_SHIFT));
     } else {
         if (dy < 0) { int64_t t = x1; x1 = x2; x2 = t; t = y1; y1 = y2; y2 = t; dx = -dx; }
-        const int64_t x_step = (dx * XY_ONE) / (ay | 1);
+        const int64_t x_step = div_trunc(dx * XY_ONE, ay | 1);
         const int ecount = (int)((y2 - y1) >> XY_SHIFT);
         x1 += XY_ONE >> 1; y1 += XY_ONE >> 1;
         const int64_t yb = y1 >> XY_SHIFT;
@@ -565,15 +569,20 @@ __device__ void m_line2(const tile_mask& k, int64_t x1, int64_t y1, int64_t x2, 
     }
 }
 // cv::FillConvexPoly for the 4-point thick-line body: wave-uniform edge walk, lane-parallel spans.
+// Vertices are picked with select chains and the two edge states are plain scalars: a runtime-indexed
+// private array would live in scratch memory (hundreds of cycles per access).
+__device__ __forceinline__ int64_t sel4(const int64_t* v, int i)
+{
+    return i == 0 ? v[0] : (i == 1 ? v[1] : (i == 2 ? v[2] : v[3]));
+}
 __device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int64_t* vy, int lane)
 {
     const int npts = 4;
     const int64_t delta = XY_ONE >> 1;
-    int e_idx[2], e_di[2], e_ye[2];
-    int64_t e_x[2], e_dx[2];
     int imin = 0, edges = npts;
     int64_t xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
-    int64_t px = vx[npts - 1], py = vy[npts - 1];
+    int64_t px = vx[3], py = vy[3];
+#pragma unroll
     for (int i = 0; i < npts; ++i) {
         if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
         if (vy[i] > ymax) ymax = vy[i];
@@ -587,22 +596,27 @@ __device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int6
     if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= k.W || (int)ymin >= k.H) return;
     if (ymax > k.H - 1) ymax = k.H - 1;
     int y = (int)ymin;
-    e_idx[0] = e_idx[1] = imin; e_ye[0] = e_ye[1] = y;
-    e_di[0] = 1; e_di[1] = npts - 1;
-    e_x[0] = e_x[1] = -XY_ONE; e_dx[0] = e_dx[1] = 0;
+    int idxA = imin, idxB = imin, yeA = y, yeB = y;          // edge A walks +1 through the vertices, edge B -1
+    int64_t xA = -XY_ONE, xB = -XY_ONE, dxA = 0, dxB = 0;
     do {
+#pragma unroll
         for (int i = 0; i < 2; ++i) {
-            if (y >= e_ye[i]) {
-                int idx0 = e_idx[i], di = e_di[i];
+            int& e_idx = i == 0 ? idxA : idxB;
+            int& e_ye = i == 0 ? yeA : yeB;
+            int64_t& e_x = i == 0 ? xA : xB;
+            int64_t& e_dx = i == 0 ? dxA : dxB;
+            const int di = i == 0 ? 1 : npts - 1;
+            if (y >= e_ye) {
+                int idx0 = e_idx;
                 int idx = idx0 + di; if (idx >= npts) idx -= npts;
                 for (; edges-- > 0;) {
-                    int ty = (int)((vy[idx] + delta) >> XY_SHIFT);
+                    const int ty = (int)((sel4(vy, idx) + delta) >> XY_SHIFT);
                     if (ty > y) {
-                        int64_t xs = vx[idx0], xe = vx[idx];
-                        e_ye[i] = ty;
-                        e_dx[i] = ((xe - xs) * 2 + (ty - y)) / (2 * (ty - y));
-                        e_x[i] = xs;
-                        e_idx[i] = idx;
+                        const int64_t xs = sel4(vx, idx0), xe = sel4(vx, idx);
+                        e_ye = ty;
+                        e_dx = div_trunc((xe - xs) * 2 + (ty - y), 2 * (ty - y));
+                        e_x = xs;
+                        e_idx = idx;
                         break;
                     }
                     idx0 = idx; idx += di; if (idx >= npts) idx -= npts;
@@ -611,14 +625,13 @@ __device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int6
         }
         if (edges < 0) break;
         if (y >= 0) {
-            int left = 0, right = 1;
-            if (e_x[0] > e_x[1]) { left = 1; right = 0; }
-            int xx1 = (int)((e_x[left] + (XY_ONE >> 1)) >> XY_SHIFT);
-            int xx2 = (int)((e_x[right] + (XY_ONE >> 1)) >> XY_SHIFT);
+            const int64_t xl = xA > xB ? xB : xA, xr = xA > xB ? xA : xB;
+            const int xx1 = (int)((xl + (XY_ONE >> 1)) >> XY_SHIFT);
+            const int xx2 = (int)((xr + (XY_ONE >> 1)) >> XY_SHIFT);
             if (xx2 >= 0 && xx1 < k.W) m_hline(k, y, xx1, xx2, lane);
         }
-        e_x[0] += e_dx[0];
-        e_x[1] += e_dx[1];
+        xA += dxA;
+        xB += dxB;
     } while (++y <= (int)ymax);
 }
 __device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1, int thickness, int lane)
@@ -643,73 +656,74 @@ __device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1,
 }
 
 // ---------------------------------------------------------------------- A4 rain / A5 snow
-// Tile 64 x 16, halo R (1 for 3x3, 3 for 7x7).  The float32 pre-blur image (haze / brightness
+// Tile 64 x 32, halo R (1 for 3x3, 3 for 7x7).  The float32 pre-blur image (haze / brightness
 // applied through the LUT, primitives painted) is staged in LDS as [row][72 px][3] — the float
 // image of the frame's byte rows, so interior tiles stage with aligned dword loads; then OpenCV's
 // separable blur: row pass over every staged row, column pass over the tile, 4 pixels (12 values)
 // per lane with 16-byte LDS accesses, 12 B / 3 x 16 B global stores.
-constexpr int BTW = 64, BTH = 16, BRMAX = 3;
-constexpr int BSH = BTH + 2 * BRMAX;            // 22 staged rows
+constexpr int BTW = 64, BTH = 32, BRMAX = 3;
+constexpr int kSThreads = 512;                 // one lane per (tile row, 4 px) in the column pass
 constexpr int BSW = 72;                         // staged pixels per row (>= 64 + 2*3, multiple of 4)
 constexpr int MAXHIT = 64;
 
 struct blur_taps { float k[2 * BRMAX + 1]; int r; };
 
-template <bool SNOW>
-__global__ __launch_bounds__(kThreads)
+// RR = blur radius (1: 3x3, 3: 7x7).  RR == 1 fuses the row and the column pass in registers
+// (no s_row, 4 blocks per CU); RR == 3 keeps the two LDS passes.
+template <bool SNOW, int RR>
+__global__ __launch_bounds__(kSThreads)
 void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_prim_job> jobs,
-                   const int32_t* __restrict__ prims, blur_taps bt3, blur_taps bt7,
+                   const int32_t* __restrict__ prims, blur_taps bt,
                    uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
 {
-    __shared__ __attribute__((aligned(16))) float s_src[BSH * BSW * 3];     // 19.0 KB
-    __shared__ __attribute__((aligned(16))) float s_row[BSH * BTW * 3];     // 16.9 KB
-    __shared__ uint8_t s_mask[BSH * BSW];
+    constexpr int R = RR;
+    constexpr int sw = BTW + 2 * R, sh = BTH + 2 * R;
+    constexpr int NQ = (sw + 3) / 4;                                        // staged pixel quads per row
+    constexpr int RAWD = 56;                                                // dwords per raw staged row
+    __shared__ __attribute__((aligned(16))) float s_src[sh * BSW * 3];
+    __shared__ __attribute__((aligned(16))) float s_row[RR == 1 ? 4 : sh * BTW * 3];
+    __shared__ uint32_t s_raw[sh * RAWD];
+    __shared__ uint8_t s_mask[sh * BSW];
     __shared__ int s_hits[MAXHIT];
     __shared__ int s_nhit;
     __shared__ weather_lut L;
     const awseg_prim_job job = jobs.j[blockIdx.z];
-    const blur_taps bt = (SNOW && job.blur_ksize == 7) ? bt7 : bt3;
-    const int R = bt.r;
     const int64_t hw = (int64_t)H * W;
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
     const int x0 = blockIdx.x * BTW, y0 = blockIdx.y * BTH;
-    const int sw = BTW + 2 * R, sh = BTH + 2 * R;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 
     // Interior tiles: issue the staging loads (aligned dwords of the byte rows) right away; their
     // latency hides behind the LUT fill, the primitive scan and the rasterisation.
     const bool interior = (x0 - R >= 0) && (x0 + BTW + R <= W) && (y0 - R >= 0) && (y0 + BTH + R <= H) && ((W * 3) % 4 == 0);
-    const int b0 = (x0 - R) * 3, nbytes = sw * 3;
-    const int d0 = b0 >> 2, nd = ((b0 + nbytes + 3) >> 2) - d0;
-    constexpr int kPre = (BSH * 56 + kThreads - 1) / kThreads;          // <= 56 dwords per staged row
+    const int b0 = (x0 - R) * 3;
+    constexpr int nbytes = sw * 3;
+    const int d0 = b0 >> 2, roff = b0 & 3;
+    const int nd = ((b0 + nbytes + 3) >> 2) - d0;                           // <= 55
+    constexpr int kPre = (sh * RAWD + kSThreads - 1) / kSThreads;
     uint32_t pre[kPre];
     if (interior) {
 #pragma unroll
         for (int u = 0; u < kPre; ++u) {
-            const int i = threadIdx.x + u * kThreads;
-            if (i < sh * nd) {
-                const int ty = i / nd, di = i - ty * nd;
-                pre[u] = reinterpret_cast<const uint32_t*>(src + (int64_t)(y0 - R + ty) * W * 3)[d0 + di];
-            }
+            const int i = threadIdx.x + u * kSThreads;
+            const int ty = i / RAWD, di = i - ty * RAWD;
+            if (ty < sh && di < nd) pre[u] = reinterpret_cast<const uint32_t*>(src + (int64_t)(y0 - R + ty) * W * 3)[d0 + di];
+            else pre[u] = 0u;
         }
     }
-    // this lane's primitives for the bounding-box scan (two per lane cover the reference's <= 500 drops)
+    // this lane's primitive for the bounding-box scan
     const int32_t* pl = prims + (int64_t)job.prim_offset * (SNOW ? 3 : 5);
     constexpr int PW = SNOW ? 3 : 5;
-    int pv[2][5];
+    int pv[5] = { 0, 0, 0, 0, 0 };
+    if ((int)threadIdx.x < job.prim_count) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int i = threadIdx.x + u * kThreads;
-        if (i < job.prim_count) {
-#pragma unroll
-            for (int f = 0; f < PW; ++f) pv[u][f] = pl[i * PW + f];
-        }
+        for (int f = 0; f < PW; ++f) pv[f] = pl[threadIdx.x * PW + f];
     }
     // pre-blur value of an input byte: haze (:134-135) or brightness boost + clip (:179-180)
     float pm, pa;
     if (SNOW) { pm = 1.f; pa = (float)(job.intensity * 0.2); }
     else { double haze = job.intensity * 0.3; pm = (float)(1.0 - haze); pa = (float)(haze * 0.7); }
-    for (int i = threadIdx.x; i < 256; i += kThreads) {
+    for (int i = threadIdx.x; i < 256; i += kSThreads) {
         float v = (float)i / 255.0f;
         if (SNOW) { v = v + pa; v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
         else { v = v * pm; v = v + pa; }
@@ -719,6 +733,13 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
             for (int c = 0; c < 3; ++c) L.nrm[c][i] = norm1((uint8_t)i, nc.mean[c], nc.std[c]);
         }
     }
+    if (interior) {
+#pragma unroll
+        for (int u = 0; u < kPre; ++u) {
+            const int i = threadIdx.x + u * kSThreads;
+            if (i < sh * RAWD) s_raw[i] = pre[u];
+        }
+    }
     // coverage mask over the part of tile+halo that lies inside the image
     tile_mask mk;
     mk.m = s_mask; mk.W = W; mk.H = H;
@@ -726,14 +747,14 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
     mk.y0 = y0 - R < 0 ? 0 : y0 - R;
     const int xe = x0 + BTW + R > W ? W : x0 + BTW + R, ye = y0 + BTH + R > H ? H : y0 + BTH + R;
     mk.w = xe - mk.x0; mk.h = ye - mk.y0;
-    for (int i = threadIdx.x; i < mk.w * mk.h; i += kThreads) s_mask[i] = 0;
+    for (int i = threadIdx.x; i < mk.w * mk.h; i += kSThreads) s_mask[i] = 0;
     if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
     // 1. which primitives touch this tile (bounding boxes, all lanes)
-    for (int i = threadIdx.x, u = 0; i < job.prim_count; i += kThreads, ++u) {
+    for (int i = threadIdx.x, u = 0; i < job.prim_count; i += kSThreads, ++u) {
         int lx, hx, ly, hy;
         int f0, f1, f2, f3 = 0, f4 = 0;
-        if (u < 2) { f0 = pv[u < 1 ? 0 : 1][0]; f1 = pv[u < 1 ? 0 : 1][1]; f2 = pv[u < 1 ? 0 : 1][2]; if (!SNOW) { f3 = pv[u < 1 ? 0 : 1][3]; f4 = pv[u < 1 ? 0 : 1][4]; } }
+        if (u == 0) { f0 = pv[0]; f1 = pv[1]; f2 = pv[2]; f3 = pv[3]; f4 = pv[4]; }
         else { f0 = pl[i * PW]; f1 = pl[i * PW + 1]; f2 = pl[i * PW + 2]; if (!SNOW) { f3 = pl[i * PW + 3]; f4 = pl[i * PW + 4]; } }
         if (SNOW) {
             const int cx = f0, cy = f1, r = f2;
@@ -753,7 +774,7 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
     // 2. rasterise: one wave per hit (a tile sees a handful at most; more than MAXHIT -> every primitive)
     const int nhit = s_nhit;
     const int nwork = nhit <= MAXHIT ? nhit : job.prim_count;
-    for (int hidx = wv; hidx < nwork; hidx += kThreads / 64) {
+    for (int hidx = wv; hidx < nwork; hidx += kSThreads / 64) {
         const int i = nhit <= MAXHIT ? s_hits[hidx] : hidx;
         if (SNOW) m_disc(mk, pl[i * 3], pl[i * 3 + 1], pl[i * 3 + 2], lane);
         else {
@@ -763,29 +784,33 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
         }
     }
     __syncthreads();
-    // 3. stage the pre-blur float image of tile + halo
+    // 3. stage the pre-blur float image of tile + halo: one lane per (row, pixel quad)
     const float col[3] = { SNOW ? 1.0f : 0.8f, SNOW ? 1.0f : 0.9f, 1.0f };
     if (interior) {
-        // byte row segment [(x0-R)*3, (x0+64+R)*3) of each staged row (prefetched dwords) -> float row
+        for (int i = threadIdx.x; i < sh * NQ; i += kSThreads) {
+            const int ty = i / NQ, tq = i - ty * NQ;
+            // 12 bytes of 4 pixels, unaligned by roff inside the raw dword row: 4 dword reads + byte-align
+            const int bo = tq * 12 + roff;
+            const uint32_t* rw = s_raw + ty * RAWD + (bo >> 2);
+            const uint32_t w0 = rw[0], w1 = rw[1], w2 = rw[2], w3 = rw[3];
+            const int sft = (bo & 3) * 8;
+            uint32_t d[3];
+            d[0] = sft ? (w0 >> sft) | (w1 << (32 - sft)) : w0;
+            d[1] = sft ? (w1 >> sft) | (w2 << (32 - sft)) : w1;
+            d[2] = sft ? (w2 >> sft) | (w3 << (32 - sft)) : w2;
+            const uint8_t* mrow = s_mask + (y0 - R + ty - mk.y0) * mk.w + (x0 - R + tq * 4 - mk.x0);
+            float v[12];
 #pragma unroll
-        for (int u = 0; u < kPre; ++u) {
-            const int i = threadIdx.x + u * kThreads;
-            if (i >= sh * nd) continue;
-            const int ty = i / nd, di = i - ty * nd;
-            const int gy = y0 - R + ty;
-            const uint32_t wd = pre[u];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int tb = (d0 + di) * 4 + k - b0;                  // byte position inside the staged row
-                if (tb >= 0 && tb < nbytes) {
-                    const int px = tb / 3, c = tb - px * 3;
-                    const bool cov = s_mask[(gy - mk.y0) * mk.w + (x0 - R + px - mk.x0)];
-                    s_src[ty * BSW * 3 + tb] = cov ? col[c] : L.in[(wd >> (8 * k)) & 0xFF];
-                }
+            for (int e = 0; e < 12; ++e) {
+                const int k = e / 3, c = e - k * 3;
+                const bool cov = (tq * 4 + k < sw) && mrow[k];
+                v[e] = cov ? col[c] : L.in[(d[e >> 2] >> ((e & 3) * 8)) & 0xFF];
             }
+            float4* o4 = reinterpret_cast<float4*>(s_src + (ty * BSW + tq * 4) * 3);
+            o4[0] = make_float4(v[0], v[1], v[2], v[3]); o4[1] = make_float4(v[4], v[5], v[6], v[7]); o4[2] = make_float4(v[8], v[9], v[10], v[11]);
         }
     } else {
-        for (int i = threadIdx.x; i < sh * sw; i += kThreads) {
+        for (int i = threadIdx.x; i < sh * sw; i += kSThreads) {
             const int ty = i / sw, tx = i - ty * sw;
             const int gy = reflect_101(y0 - R + ty, H), gx = reflect_101(x0 - R + tx, W);
             const bool inrect = (gy >= mk.y0 && gy < ye && gx >= mk.x0 && gx < xe);
@@ -796,84 +821,88 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
         }
     }
     __syncthreads();
-    // 4. row pass: lane = (staged row, 4 output pixels); k[c]*s0 + sum k[c+j]*(s[-j] + s[+j])
-    for (int i = threadIdx.x; i < sh * (BTW / 4); i += kThreads) {
-        const int ty = i / (BTW / 4), tq = i - ty * (BTW / 4);
-        const float* s = s_src + (ty * BSW + tq * 4) * 3;               // window starts R pixels left of the outputs
-        float win[32];                                                   // (4 + 2*3) * 3 = 30 used
-        const int nwin = (4 + 2 * R) * 3;
+    // row pass of one staged row for 4 output pixels: k[c]*s0 + sum k[c+j]*(s[-j] + s[+j])
+    auto row_pass = [&](int ty, int tq, float* o) {
+        const float* sp = s_src + (ty * BSW + tq * 4) * 3;              // window starts R pixels left of the outputs
+        constexpr int nwin = (4 + 2 * R) * 3;
+        float win[(nwin + 3) / 4 * 4];
 #pragma unroll
-        for (int k = 0; k < (4 + 2 * BRMAX) * 3 / 4 + 1; ++k) {
-            if (4 * k < nwin) {
-                const float4 t = *reinterpret_cast<const float4*>(s + 4 * k);
-                win[4 * k] = t.x; win[4 * k + 1] = t.y; win[4 * k + 2] = t.z; win[4 * k + 3] = t.w;
-            }
+        for (int k = 0; k < (nwin + 3) / 4; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(sp + 4 * k);
+            win[4 * k] = t.x; win[4 * k + 1] = t.y; win[4 * k + 2] = t.z; win[4 * k + 3] = t.w;
         }
-        float o[12];
-        if (R == 1) {
 #pragma unroll
-            for (int e = 0; e < 12; ++e) { float ab = win[e] + win[e + 6]; float m = bt.k[2] * ab; o[e] = bt.k[1] * win[e + 3] + m; }
-        } else {
+        for (int e = 0; e < 12; ++e) {
+            float acc = bt.k[R] * win[e + 3 * R];
 #pragma unroll
-            for (int e = 0; e < 12; ++e) {
-                float acc = bt.k[3] * win[e + 9];
-#pragma unroll
-                for (int j = 1; j <= 3; ++j) { float ab = win[e + 9 - 3 * j] + win[e + 9 + 3 * j]; float m = bt.k[3 + j] * ab; acc = acc + m; }
-                o[e] = acc;
-            }
+            for (int j = 1; j <= R; ++j) { float ab = win[e + 3 * R - 3 * j] + win[e + 3 * R + 3 * j]; float m = bt.k[R + j] * ab; acc = acc + m; }
+            o[e] = acc;
         }
-        float4* d = reinterpret_cast<float4*>(s_row + (ty * BTW + tq * 4) * 3);
-        d[0] = make_float4(o[0], o[1], o[2], o[3]); d[1] = make_float4(o[4], o[5], o[6], o[7]); d[2] = make_float4(o[8], o[9], o[10], o[11]);
-    }
-    __syncthreads();
-    // 5. column pass + quantise: lane = (tile row, 4 pixels) — exactly one item per lane
+    };
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
-    {
-        const int ty = threadIdx.x / (BTW / 4), tq = threadIdx.x - ty * (BTW / 4);
-        const int gy = y0 + ty, gx = x0 + tq * 4;
-        if (gy < H && gx < W) {
-            float acc[12], ctr[12];
-            auto ldrow = [&](int rr, float* v) {
-                const float4* p4 = reinterpret_cast<const float4*>(s_row + (rr * BTW + tq * 4) * 3);
-                float4 a = p4[0], b = p4[1], c = p4[2];
-                v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-                v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
-            };
-            ldrow(ty + R, ctr);
+    const int ty = threadIdx.x / (BTW / 4), tq = threadIdx.x - ty * (BTW / 4);   // one (tile row, 4 px) per lane
+    const int gy = y0 + ty, gx = x0 + tq * 4;
+    float acc[12];
+    if (RR == 1) {
+        // 4. + 5. fused: the three row-pass results this lane's column pass needs are recomputed in
+        // registers (same operations, same order as the two-pass form)
+        float up[12], ctr[12], dn[12];
+        row_pass(ty, tq, up); row_pass(ty + 1, tq, ctr); row_pass(ty + 2, tq, dn);
 #pragma unroll
-            for (int e = 0; e < 12; ++e) acc[e] = bt.k[R] * ctr[e];
-            for (int j = 1; j <= R; ++j) {
-                float up[12], dn[12];
-                ldrow(ty + R - j, up); ldrow(ty + R + j, dn);
+        for (int e = 0; e < 12; ++e) { float a0 = bt.k[1] * ctr[e]; float ab = up[e] + dn[e]; float m = bt.k[2] * ab; acc[e] = a0 + m; }
+    } else {
+        for (int i = threadIdx.x; i < sh * (BTW / 4); i += kSThreads) {
+            const int ry = i / (BTW / 4), rq = i - ry * (BTW / 4);
+            float o[12];
+            row_pass(ry, rq, o);
+            float4* d = reinterpret_cast<float4*>(s_row + (ry * BTW + rq * 4) * 3);
+            d[0] = make_float4(o[0], o[1], o[2], o[3]); d[1] = make_float4(o[4], o[5], o[6], o[7]); d[2] = make_float4(o[8], o[9], o[10], o[11]);
+        }
+        __syncthreads();
+        auto ldrow = [&](int rr, float* v) {
+            const float4* p4 = reinterpret_cast<const float4*>(s_row + (rr * BTW + tq * 4) * 3);
+            float4 a = p4[0], b = p4[1], c = p4[2];
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+            v[8] = c.x; v[9] = c.y; v[10] = c.z; v[11] = c.w;
+        };
+        float ctr[12];
+        ldrow(ty + R, ctr);
 #pragma unroll
-                for (int e = 0; e < 12; ++e) { float ab = up[e] + dn[e]; float m = bt.k[R + j] * ab; acc[e] = acc[e] + m; }
+        for (int e = 0; e < 12; ++e) acc[e] = bt.k[R] * ctr[e];
+#pragma unroll
+        for (int j = 1; j <= R; ++j) {
+            float up[12], dn[12];
+            ldrow(ty + R - j, up); ldrow(ty + R + j, dn);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) { float ab = up[e] + dn[e]; float m = bt.k[R + j] * ab; acc[e] = acc[e] + m; }
+        }
+    }
+    if (gy < H && gx < W) {
+        uint8_t res[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) res[e] = quant_f32(acc[e]);
+        const int nvalid = (W - gx) < 4 ? (W - gx) : 4;
+        const int64_t p = (int64_t)gy * W + gx;
+        if (dst) {
+            if (nvalid == 4 && ((p * 3) & 3) == 0) {
+                uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
+#pragma unroll
+                for (int w = 0; w < 3; ++w)
+                    d4[w] = (uint32_t)res[4 * w] | ((uint32_t)res[4 * w + 1] << 8) | ((uint32_t)res[4 * w + 2] << 16) | ((uint32_t)res[4 * w + 3] << 24);
+            } else {
+                for (int k = 0; k < nvalid * 3; ++k) dst[p * 3 + k] = res[k];
             }
-            uint8_t res[12];
+        }
+        if (ndst) {
+            if (nvalid == 4 && (p & 3) == 0 && (hw & 3) == 0) {
 #pragma unroll
-            for (int e = 0; e < 12; ++e) res[e] = quant_f32(acc[e]);
-            const int nvalid = (W - gx) < 4 ? (W - gx) : 4;
-            const int64_t p = (int64_t)gy * W + gx;
-            if (dst) {
-                if (nvalid == 4 && ((p * 3) & 3) == 0) {
-                    uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
-#pragma unroll
-                    for (int w = 0; w < 3; ++w)
-                        d4[w] = (uint32_t)res[4 * w] | ((uint32_t)res[4 * w + 1] << 8) | ((uint32_t)res[4 * w + 2] << 16) | ((uint32_t)res[4 * w + 3] << 24);
-                } else {
-                    for (int k = 0; k < nvalid * 3; ++k) dst[p * 3 + k] = res[k];
-                }
-            }
-            if (ndst) {
-                if (nvalid == 4 && (p & 3) == 0 && (hw & 3) == 0) {
-#pragma unroll
-                    for (int c = 0; c < 3; ++c)
-                        *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
-                            make_float4(L.nrm[c][res[c]], L.nrm[c][res[3 + c]], L.nrm[c][res[6 + c]], L.nrm[c][res[9 + c]]);
-                } else {
-                    for (int c = 0; c < 3; ++c)
-                        for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = L.nrm[c][res[k * 3 + c]];
-                }
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
+                        make_float4(L.nrm[c][res[c]], L.nrm[c][res[3 + c]], L.nrm[c][res[6 + c]], L.nrm[c][res[9 + c]]);
+            } else {
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = L.nrm[c][res[k * 3 + c]];
             }
         }
     }
@@ -1055,18 +1084,25 @@ static int streak_common(bool snow, const uint8_t* imgs, int H, int W, const aws
     if (((uintptr_t)imgs & 3) || (out && ((uintptr_t)out & 3)) || (norm_out && ((uintptr_t)norm_out & 15))) return AWSEG_EALIGN;
     if ((H + BTH - 1) / BTH > 65535) return AWSEG_ERANGE;
     norm_consts nc = make_nc(mean_host, std_host);
-    for (int j0 = 0; j0 < n_jobs; j0 += kMaxJobs) {
-        const int cnt = n_jobs - j0 < kMaxJobs ? n_jobs - j0 : kMaxJobs;
-        const job_pack<awseg_prim_job> pk = pack_jobs(jobs, j0, cnt);
-        dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, cnt);
-        if (snow) {
-            hipLaunchKernelGGL((streak_kernel<true>), grid, dim3(kThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 1.0),
-                               make_blur(7, 1.0), out, norm_out, nc);
-        } else {
-            blur_taps b = make_blur(3, 0.5);
-            hipLaunchKernelGGL((streak_kernel<false>), grid, dim3(kThreads), 0, s, imgs, H, W, pk, prims, b, b, out, norm_out, nc);
+    // jobs are grouped by blur radius (snow draws 3x3 or 7x7 per frame, preprocessing.py:197)
+    for (int pass = 0; pass < 2; ++pass) {
+        const int want7 = pass;
+        if (!snow && want7) break;
+        awseg_prim_job sel[kMaxJobs];
+        int cnt = 0;
+        for (int j = 0; j <= n_jobs; ++j) {
+            const bool take = j < n_jobs && ((snow && jobs[j].blur_ksize == 7) ? 1 : 0) == want7;
+            if (take) sel[cnt++] = jobs[j];
+            if (cnt == kMaxJobs || (j == n_jobs && cnt > 0)) {
+                const job_pack<awseg_prim_job> pk = pack_jobs(sel, 0, cnt);
+                dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, cnt);
+                if (!snow) hipLaunchKernelGGL((streak_kernel<false, 1>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 0.5), out, norm_out, nc);
+                else if (!want7) hipLaunchKernelGGL((streak_kernel<true, 1>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 1.0), out, norm_out, nc);
+                else hipLaunchKernelGGL((streak_kernel<true, 3>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(7, 1.0), out, norm_out, nc);
+                AWSEG_LAUNCH_CHECK();
+                cnt = 0;
+            }
         }
-        AWSEG_LAUNCH_CHECK();
     }
     return 0;
 }

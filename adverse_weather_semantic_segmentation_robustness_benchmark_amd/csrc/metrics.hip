@@ -446,9 +446,9 @@ AWSEG_API int awseg_confusion_accumulate(const void* pred, int pred_dtype, const
                                          int64_t n, int num_classes, int ignore_index, int label_wrap_u8,
                                          int64_t* counts, int64_t* oob, void* workspace, awseg_stream_t stream)
 {
+    if (n == 0) return 0;                            // empty input (all pointers may be NULL): nothing to count
     if (!pred || !label || !counts || !oob || !workspace || n < 0) return AWSEG_EINVAL;
     if (num_classes < 1 || num_classes > AWSEG_MAX_CLASSES) return AWSEG_EINVAL;
-    if (n == 0) return 0;
     hipStream_t s = awseg_s(stream);
     // never more blocks than the workspace query assumed (blocks_per_image(n, 1, 1)); one block
     // covers 4096 pixels per sweep, 1024 blocks keep every CU busy

@@ -429,3 +429,58 @@ def test_layernorm_rows(ops, shape):
     g, b = torch.randn(shape[1], device="cuda"), torch.randn(shape[1], device="cuda")
     ref = torch.nn.functional.layer_norm(x, (shape[1],), g, b, 1e-5)
     assert (ops.layernorm_rows(x, g, b, 1e-5) - ref).abs().max().item() < 2e-5
+
+
+def test_abi_argument_checks_and_edge_shapes(ops, native):
+    """Error conventions of the C ABI (negative AWSEG_E* codes -> AwsegError, nothing launched) and the
+    smallest / ragged shapes."""
+    N = native
+    lib = N.lib()
+    # empty pixel list: a no-op, not an error
+    counts = ops.new_counts(19, "cuda"); oob = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ops.confusion_accumulate(torch.zeros(0, dtype=torch.int64, device="cuda"), torch.zeros(0, dtype=torch.int64, device="cuda"), 19, counts, oob)
+    assert counts.sum().item() == 0
+    # one pixel, one class
+    c1 = ops.new_counts(1, "cuda")
+    ops.confusion_accumulate(torch.zeros(1, dtype=torch.uint8, device="cuda"), torch.zeros(1, dtype=torch.uint8, device="cuda").contiguous(), 1, c1, oob)
+    assert c1.item() == 1
+    # more classes than the register budget
+    with pytest.raises(N.AwsegError, match="invalid argument"):
+        ops.argmax(torch.zeros(1, 33, 4, 4, device="cuda"))
+    # odd H*W: kernels that need 4-pixel alignment refuse loudly instead of mis-indexing
+    with pytest.raises(N.AwsegError):
+        ops.normalize(torch.zeros(1, 3, 5, 3, dtype=torch.uint8, device="cuda"))
+    # ... while the scalar fall-back paths of the logit kernels accept them
+    x = torch.randn(1, 19, 3, 5, device="cuda")
+    assert torch.equal(ops.argmax(x), x.argmax(dim=1))
+    # non-contiguous / wrong dtype labels
+    with pytest.raises(N.AwsegError, match="uint8 or int64"):
+        ops.confusion_accumulate(torch.zeros(4, dtype=torch.int32, device="cuda"), torch.zeros(4, dtype=torch.int64, device="cuda"), 19, counts, oob)
+    # rain must not run in place (the blur reads neighbours)
+    imgs = torch.zeros(1, 32, 64, 3, dtype=torch.uint8, device="cuda")
+    jobs, prims = ops.prim_jobs([0], [0.5], [np.zeros((0, 5), np.int32)])
+    with pytest.raises(N.AwsegError, match="invalid argument"):
+        ops.rain(imgs, jobs, prims, out=imgs)
+    # zero primitives = haze + blur only, identical to the oracle
+    assert lib.awseg_abi_version() == 1 and lib.awseg_device_count() >= 1
+
+
+def test_rain_zero_primitives_and_many_jobs(ops, oracle):
+    rs = np.random.RandomState(1)
+    B, h, w = 20, 32, 64                                   # more jobs than one kernel-argument pack (16)
+    imgs = rs.randint(0, 255, (B, h, w, 3), dtype=np.uint8)
+    jobs, prims = ops.prim_jobs(list(range(B)), [0.3 + 0.02 * i for i in range(B)], [np.zeros((0, 5), np.int32)] * B)
+    out = torch.zeros(B, h, w, 3, dtype=torch.uint8, device="cuda")
+    ops.rain(dev(imgs), jobs, prims, out=out)
+    for b in (0, 15, 16, 19):
+        assert np.array_equal(out[b].cpu().numpy(), oracle.rain(imgs[b], 0.3 + 0.02 * b, np.zeros((0, 5), np.int32)))
+    nz = rs.normal(0, 5 / 255, (B, h, w, 3))
+    nj = ops.night_jobs(list(range(B)), [0.8] * B, [0.5] * B)
+    ops.night(dev(imgs), nj, noise=dev(nz), out=out)
+    for b in (0, 16, 19):
+        assert np.array_equal(out[b].cpu().numpy(), oracle.night(imgs[b], nz[b], 0.8, 0.5))
+    fz = rs.normal(0, 10, (B, h, w))
+    fj = ops.fog_jobs(list(range(B)), [0.5] * B)
+    ops.fog(dev(imgs), fj, noise=dev(fz), out=out)
+    for b in (0, 16, 19):
+        assert np.array_equal(out[b].cpu().numpy(), oracle.fog(imgs[b], oracle.synthetic_depth(fz[b]), 0.5))

@@ -204,15 +204,14 @@ class SegFormerModel(nn.Module):
 
     @torch.no_grad()
     def _forward_hip(self, feats, H, W):
-        if True:
-            head = self.segmentation_head
-            g9, shift = _head_g9(feats, head[0], head[1])
-            w2 = head[4].weight.view(self.num_classes, -1)
-            seg = ops.segformer_head_fused(g9, None, shift, w2, head[4].bias, H, W)
-            results = {"segmentation": seg}
-            if self.include_depth:
-                results["depth"] = self.depth_head.forward_from_lowres(feats, H, W)
-            return results
+        """feats: encoder output as NHWC tokens [B,h,w,C]."""
+        head = self.segmentation_head
+        g9, shift = _head_g9(feats, head[0], head[1])
+        w2 = head[4].weight.view(self.num_classes, -1)
+        results = {"segmentation": ops.segformer_head_fused(g9, None, shift, w2, head[4].bias, H, W)}
+        if self.include_depth:
+            results["depth"] = self.depth_head.forward_from_lowres(feats, H, W)
+        return results
 
 
 class DeepLabV3PlusModel(nn.Module):
@@ -248,16 +247,15 @@ class DeepLabV3PlusModel(nn.Module):
     def _forward_hip(self, x):
         if not x.is_cuda:
             raise N.AwsegError("eval-mode forward runs HIP kernels: it needs CUDA (HIP) tensors; no CPU fallback exists")
-        if True:
-            xc = x.contiguous(memory_format=torch.channels_last)
-            seg, enc = self.model.forward_fused(xc, return_features=True)
-            results = {"segmentation": seg.contiguous()}
-            if self.include_depth:
-                # the reference runs the encoder a second time here (model.py:358); in eval mode the
-                # result is identical, so the features of the first pass are reused
-                d = self.depth_head.forward_fused(enc)
-                results["depth"] = F.interpolate(d, size=x.shape[2:], mode="bilinear", align_corners=False).contiguous()
-            return results
+        xc = x.contiguous(memory_format=torch.channels_last)
+        seg, enc = self.model.forward_fused(xc, return_features=True)
+        results = {"segmentation": seg.contiguous()}
+        if self.include_depth:
+            # the reference runs the encoder a second time here (model.py:358); in eval mode the
+            # result is identical, so the features of the first pass are reused
+            d = self.depth_head.forward_fused(enc)
+            results["depth"] = F.interpolate(d, size=x.shape[2:], mode="bilinear", align_corners=False).contiguous()
+        return results
 
 
 _STRATEGY = {"weighted_average": N.COMBINE_WEIGHTED, "max_confidence": N.COMBINE_MAXCONF}

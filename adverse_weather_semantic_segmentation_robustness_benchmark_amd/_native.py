@@ -60,6 +60,8 @@ SIGNATURES = {
     "awseg_dwconv3x3_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
     "awseg_bias_act_nhwc": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_i, c_p]),
     "awseg_layernorm_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_f, c_p, c_p]),
+    "awseg_ensemble_eval_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i,
+                                       c_f, c_f, c_p, c_p]),
     "awseg_ece_accumulate": (c_i, [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
 }
 

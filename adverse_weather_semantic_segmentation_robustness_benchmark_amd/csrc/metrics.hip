@@ -326,6 +326,105 @@ __global__ void ece_fold_kernel(const ece_cell* __restrict__ partial, int blocks
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Ensemble calibration + disagreement statistics in ONE pass over the two member logit maps
+// (next #1: REF/scripts/evaluate.py:230-255).  Per pixel with label != 255:
+//   ECE        r = combine(s1, s2)/T (same four roundings as the combine kernel), conf = max softmax(r),
+//              pred = argmax r, bin (lo, hi] -> {count, correct, sum conf}      (metrics.py:161-194)
+//   AUROC      p_i = softmax(s_i), m = (p1 + p2)/2, score = H(m) - (H(p1) + H(p2))/2 with the reference's
+//              +1e-8 inside the logs (metrics.py:353-367), error = argmax(m) != label (:414-419);
+//              the score is histogrammed by error flag (2 x n_hist int64 bins, global atomics) — AUROC is
+//              then a rank statistic of the two histograms, additive over batches and ranks.
+// C = 19 only (2 x 19 x 4 logits live in registers); 4 pixels per lane.
+// ---------------------------------------------------------------------------------------
+template <int MODE, int LDT>
+__global__ __launch_bounds__(kThreads)
+void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restrict__ seg2, int64_t hw,
+                           const float* __restrict__ weights, const float* __restrict__ temperature,
+                           const void* __restrict__ label, const float* __restrict__ edges, int n_bins,
+                           ece_cell* __restrict__ partial, unsigned long long* __restrict__ hist, int n_hist,
+                           float h_lo, float h_scale)
+{
+    constexpr int C = 19;
+    __shared__ uint32_t s_cnt[64], s_cor[64];
+    __shared__ float s_sum[64];
+    __shared__ float s_edges[65];
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0.f; }
+    for (int i = threadIdx.x; i <= n_bins; i += kThreads) s_edges[i] = edges[i];
+    __syncthreads();
+    const int64_t img = blockIdx.y;
+    const float* a = seg1 + img * C * hw;
+    const float* d = seg2 + img * C * hw;
+    float w0 = 0.f, w1 = 0.f, T = 1.f;
+    const bool has_t = (temperature != nullptr);
+    if (MODE == 0) { w0 = weights[0]; w1 = weights[1]; }
+    if (has_t) T = temperature[0];
+    const int64_t nvec = hw / 4;
+    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = v * 4;
+        float x[C][4], y[C][4];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float4 xv = *reinterpret_cast<const float4*>(a + (int64_t)c * hw + p);
+            const float4 yv = *reinterpret_cast<const float4*>(d + (int64_t)c * hw + p);
+            x[c][0] = xv.x; x[c][1] = xv.y; x[c][2] = xv.z; x[c][3] = xv.w;
+            y[c][0] = yv.x; y[c][1] = yv.y; y[c][2] = yv.z; y[c][3] = yv.w;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int64_t t = awseg_ld_label<LDT>(label, img * hw + p + k);
+            if (t == 255) continue;                               // metrics.py:170, :426
+            float m1 = x[0][k], m2 = y[0][k];
+#pragma unroll
+            for (int c = 1; c < C; ++c) { m1 = fmaxf(m1, x[c][k]); m2 = fmaxf(m2, y[c][k]); }
+            float z1 = 0.f, z2 = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) { z1 += __expf(x[c][k] - m1); z2 += __expf(y[c][k] - m2); }
+            const float i1 = 1.0f / z1, i2 = 1.0f / z2;
+            // ensemble logits r, their max / argmax / sum-exp for the calibration part
+            float rmax = -INFINITY, rsum = 0.f; int rarg = 0;
+            float r[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                float rv;
+                if (MODE == 0) { float u = w0 * x[c][k]; float q = w1 * y[c][k]; rv = u + q; }
+                else { float u = x[c][k] + y[c][k]; rv = u / 2.f; }
+                if (has_t) rv = rv / T;
+                r[c] = rv;
+                if (c == 0 || rv > rmax) { rmax = rv; rarg = c; }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) rsum += __expf(r[c] - rmax);
+            const float conf = 1.0f / rsum;
+            for (int b = 0; b < n_bins; ++b)
+                if (conf > s_edges[b] && conf <= s_edges[b + 1]) {
+                    atomicAdd(&s_cnt[b], 1u);
+                    if (rarg == (int)t) atomicAdd(&s_cor[b], 1u);
+                    atomicAdd(&s_sum[b], conf);
+                    break;
+                }
+            // disagreement (mutual information) and the error flag of the mean-probability prediction
+            float hm = 0.f, h1 = 0.f, h2 = 0.f, mbest = -1.f; int marg = 0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float p1 = __expf(x[c][k] - m1) * i1, p2 = __expf(y[c][k] - m2) * i2;
+                const float mp = (p1 + p2) * 0.5f;
+                hm -= mp * __logf(mp + 1e-8f);
+                h1 -= p1 * __logf(p1 + 1e-8f);
+                h2 -= p2 * __logf(p2 + 1e-8f);
+                if (mp > mbest) { mbest = mp; marg = c; }
+            }
+            const float score = hm - (h1 + h2) * 0.5f;
+            int hb = (int)((score - h_lo) * h_scale);
+            hb = hb < 0 ? 0 : (hb >= n_hist ? n_hist - 1 : hb);
+            atomicAdd(&hist[(marg != (int)t ? n_hist : 0) + hb], 1ull);
+        }
+    }
+    __syncthreads();
+    ece_cell* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_bins;
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = (double)s_sum[i]; }
+}
+
 int blocks_per_image(int64_t hw, int64_t batch, int vec)
 {
     // enough blocks to fill 256 CUs x 8 resident blocks across the whole batch, grid-stride beyond
@@ -492,6 +591,35 @@ AWSEG_API int awseg_ece_accumulate(const float* logits, int64_t batch, int num_c
     AWSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(ece_fold_kernel, dim3((unsigned)batch), dim3(64), 0, s, (const ece_cell*)workspace, bpi, n_bins, cond,
                        n_slots, (ece_out*)bins);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_ensemble_eval_stats(const float* seg1, const float* seg2, int64_t batch, int num_classes, int64_t hw,
+                                        int mode, const float* weights, const float* temperature, const void* label,
+                                        int label_dtype, const int32_t* cond, const float* edges, int n_bins, void* ece_bins,
+                                        int n_slots, int64_t* auroc_hist, int n_hist, float hist_lo, float hist_hi,
+                                        void* workspace, awseg_stream_t stream)
+{
+    if (!seg1 || !seg2 || !label || !edges || !ece_bins || !auroc_hist || !workspace) return AWSEG_EINVAL;
+    if (num_classes != 19) return AWSEG_ERANGE;                  // register-resident 2 x 19 x 4 logits
+    if (mode != AWSEG_COMBINE_WEIGHTED && mode != AWSEG_COMBINE_MEAN) return AWSEG_ERANGE;
+    if (mode == AWSEG_COMBINE_WEIGHTED && !weights) return AWSEG_EINVAL;
+    if (n_bins < 1 || n_bins > 64 || n_slots < 1 || n_hist < 2 || batch < 1 || batch > 65535 || hw < 4 || !(hist_hi > hist_lo)) return AWSEG_EINVAL;
+    if ((hw & 3) || ((uintptr_t)seg1 & 15) || ((uintptr_t)seg2 & 15)) return AWSEG_EALIGN;
+    hipStream_t s = awseg_s(stream);
+    const int bpi = blocks_per_image(hw, batch, 1);
+    dim3 grid(bpi, (unsigned)batch), block(kThreads);
+    const float scale = (float)n_hist / (hist_hi - hist_lo);
+    unsigned long long* hist = (unsigned long long*)auroc_hist;
+#define AWSEG_ES(M, L) hipLaunchKernelGGL((ensemble_stats_kernel<M, L>), grid, block, 0, s, seg1, seg2, hw, weights, temperature, label, \
+                                          edges, n_bins, (ece_cell*)workspace, hist, n_hist, hist_lo, scale)
+    if (mode == AWSEG_COMBINE_WEIGHTED) { if (label_dtype == AWSEG_U8) AWSEG_ES(0, AWSEG_U8); else if (label_dtype == AWSEG_I64) AWSEG_ES(0, AWSEG_I64); else return AWSEG_EINVAL; }
+    else { if (label_dtype == AWSEG_U8) AWSEG_ES(2, AWSEG_U8); else if (label_dtype == AWSEG_I64) AWSEG_ES(2, AWSEG_I64); else return AWSEG_EINVAL; }
+#undef AWSEG_ES
+    AWSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(ece_fold_kernel, dim3((unsigned)batch), dim3(64), 0, s, (const ece_cell*)workspace, bpi, n_bins, cond,
+                       n_slots, (ece_out*)ece_bins);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

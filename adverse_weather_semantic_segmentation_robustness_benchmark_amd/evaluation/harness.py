@@ -23,6 +23,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import _native as N
 from .. import ops, parallel
 from .metrics import ConfidenceCalibration, RobustnessMetrics
 
@@ -64,8 +65,9 @@ class EvalState:
         err = (m.argmax(dim=1).reshape(-1) != lab)
         valid = lab != 255
         b = ((dis - AUROC_LO) * (AUROC_BINS / (AUROC_HI - AUROC_LO))).long().clamp_(0, AUROC_BINS - 1)
-        idx = (b + err.long() * AUROC_BINS)[valid]
-        self.auroc.view(-1).add_(torch.bincount(idx, minlength=2 * AUROC_BINS))
+        idx = b + err.long() * AUROC_BINS
+        # no boolean indexing / bincount here: both would synchronise the host with the device every batch
+        self.auroc.view(-1).index_add_(0, idx, valid.to(torch.int64))
 
     def all_reduce(self):
         ts = [self.acc.counts, self.acc.oob, self.ece]
@@ -103,14 +105,25 @@ def evaluate_model(model: torch.nn.Module, test_loader, metrics: RobustnessMetri
         conds = batch.get("weather_condition", ["clean"] * images.size(0))
         cond = st.acc.cond_ids(conds)
         if is_ensemble:
-            res = model.forward_eval(images, labels, st.acc.counts, st.acc.oob, cond, want_logits=True, want_pred=False)
-            logits = res["segmentation"]
-            st.update_auroc(res["segformer_seg"], res["deeplabv3plus_seg"], labels)
+            strategy = getattr(model, "ensemble_strategy", "weighted_average")
+            fused_stats = metrics.num_classes == 19 and strategy != "max_confidence" and images[0, 0].numel() % 4 == 0
+            res = model.forward_eval(images, labels, st.acc.counts, st.acc.oob, cond, want_logits=not fused_stats, want_pred=False)
+            if fused_stats:
+                # ECE of the combined logits + disagreement histogram in ONE pass over the member logits:
+                # the ensemble logits are never materialised
+                mode = N.COMBINE_WEIGHTED if strategy == "weighted_average" else N.COMBINE_MEAN
+                w = F.softmax(model.ensemble_weights, dim=0) if mode == N.COMBINE_WEIGHTED else None
+                T = model.temperature if getattr(model, "temperature_scaling", False) else None
+                ops.ensemble_eval_stats(res["segformer_seg"], res["deeplabv3plus_seg"], mode, w, T, labels, cond, st.edges, st.ece,
+                                        st.auroc, AUROC_LO, AUROC_HI)
+            else:
+                st.update_auroc(res["segformer_seg"], res["deeplabv3plus_seg"], labels)
+                ops.ece_accumulate(res["segmentation"], labels, st.ece, st.edges, cond)
         else:
             logits = model(images)["segmentation"].float().contiguous()
             ops.combine_argmax_confusion(logits, None, 3, want_logits=False, label=labels.contiguous(), counts=st.acc.counts,
                                          oob=st.acc.oob, cond=cond)
-        ops.ece_accumulate(logits, labels, st.ece, st.edges, cond)
+            ops.ece_accumulate(logits, labels, st.ece, st.edges, cond)
         st.samples += images.size(0)
     return finalize(st, metrics)
 

@@ -121,6 +121,19 @@ def ece_accumulate(logits: torch.Tensor, label: torch.Tensor, bins: torch.Tensor
                                          N.ptr(edges), bins.shape[1], N.ptr(bins), bins.shape[0], N.ptr(ws), N.stream())
 
 
+def ensemble_eval_stats(seg1: torch.Tensor, seg2: torch.Tensor, mode: int, weights, temperature, label: torch.Tensor,
+                        cond, edges: torch.Tensor, ece_bins: torch.Tensor, auroc_hist: torch.Tensor, lo: float, hi: float) -> None:
+    """ECE accumulators of the combined logits + disagreement-score histogram by error flag, one pass
+    over the member logits (REF/scripts/evaluate.py:230-255)."""
+    seg1, seg2, label = seg1.contiguous(), seg2.contiguous(), label.contiguous()
+    b, c = seg1.shape[0], seg1.shape[1]
+    hw = seg1[0, 0].numel()
+    ws = N.workspace.get(seg1.device, N.lib().awseg_metrics_workspace(b, c, hw))
+    N.call("awseg_ensemble_eval_stats", N.ptr(seg1), N.ptr(seg2), b, c, hw, mode, N.ptr(weights), N.ptr(temperature), N.ptr(label),
+           N.label_dtype(label), N.ptr(cond), N.ptr(edges), ece_bins.shape[1], N.ptr(ece_bins), ece_bins.shape[0],
+           N.ptr(auroc_hist), auroc_hist.shape[1], float(lo), float(hi), N.ptr(ws), N.stream())
+
+
 def ece_bins_to_numpy(bins: torch.Tensor) -> np.ndarray:
     return bins.cpu().numpy().view(np.uint8).reshape(bins.shape[0], bins.shape[1], 24).view(ECE_BIN_DTYPE)[..., 0]
 

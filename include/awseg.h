@@ -381,6 +381,22 @@ int awseg_ece_accumulate(const float* logits, int64_t batch, int num_classes, in
                          const float* edges, int n_bins,
                          void* bins, int n_slots, void* workspace, awseg_stream_t stream);
 
+/* Ensemble calibration + disagreement statistics in one pass over the two member logit maps
+ * (replaces REF/scripts/evaluate.py:230-255 = ConfidenceCalibration.compute_ece on the ensemble logits,
+ * PKG/evaluation/metrics.py:161-194, and the per-pixel part of
+ * EnsembleDisagreementMetrics.compute_disagreement_auroc, :353-367, :414-426).  ECE bins as in
+ * awseg_ece_accumulate, computed from r = combine(seg1, seg2)/T (mode WEIGHTED or MEAN).  The
+ * disagreement score (mutual information) of every pixel with label != 255 is counted into
+ * auroc_hist int64 [2][n_hist]: row 0 = correctly predicted (argmax of the mean probability == label),
+ * row 1 = errors; bin = (score - hist_lo) * n_hist / (hist_hi - hist_lo), clamped.  C must be 19,
+ * H*W a multiple of 4.  workspace as awseg_metrics_workspace. */
+int awseg_ensemble_eval_stats(const float* seg1, const float* seg2, int64_t batch, int num_classes, int64_t hw,
+                              int mode, const float* weights, const float* temperature,
+                              const void* label, int label_dtype, const int32_t* cond,
+                              const float* edges, int n_bins, void* ece_bins, int n_slots,
+                              int64_t* auroc_hist, int n_hist, float hist_lo, float hist_hi,
+                              void* workspace, awseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

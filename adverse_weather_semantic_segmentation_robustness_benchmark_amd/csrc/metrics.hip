@@ -349,6 +349,11 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
     __shared__ uint32_t s_cnt[64], s_cor[64];
     __shared__ float s_sum[64];
     __shared__ float s_edges[65];
+    // Score histogram of this block in LDS (2 x n_hist uint32, n_hist <= kHistMax): pixels of one frame
+    // have similar scores, so counting straight into global memory is same-address atomic traffic
+    // (measured 45 ms per batch); the block flushes only its non-zero bins at the end.
+    extern __shared__ uint32_t s_hist[];
+    for (int i = threadIdx.x; i < 2 * n_hist; i += kThreads) s_hist[i] = 0u;
     for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0.f; }
     for (int i = threadIdx.x; i <= n_bins; i += kThreads) s_edges[i] = edges[i];
     __syncthreads();
@@ -417,13 +422,19 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
             const float score = hm - (h1 + h2) * 0.5f;
             int hb = (int)((score - h_lo) * h_scale);
             hb = hb < 0 ? 0 : (hb >= n_hist ? n_hist - 1 : hb);
-            atomicAdd(&hist[(marg != (int)t ? n_hist : 0) + hb], 1ull);
+            atomicAdd(&s_hist[(marg != (int)t ? n_hist : 0) + hb], 1u);
         }
     }
     __syncthreads();
     ece_cell* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_bins;
     for (int i = threadIdx.x; i < n_bins; i += kThreads) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = (double)s_sum[i]; }
+    for (int i = threadIdx.x; i < 2 * n_hist; i += kThreads) {
+        const uint32_t v = s_hist[i];
+        if (v) atomicAdd(&hist[i], (unsigned long long)v);
+    }
 }
+
+constexpr int kHistMax = 8192;
 
 int blocks_per_image(int64_t hw, int64_t batch, int vec)
 {
@@ -605,17 +616,22 @@ AWSEG_API int awseg_ensemble_eval_stats(const float* seg1, const float* seg2, in
     if (num_classes != 19) return AWSEG_ERANGE;                  // register-resident 2 x 19 x 4 logits
     if (mode != AWSEG_COMBINE_WEIGHTED && mode != AWSEG_COMBINE_MEAN) return AWSEG_ERANGE;
     if (mode == AWSEG_COMBINE_WEIGHTED && !weights) return AWSEG_EINVAL;
-    if (n_bins < 1 || n_bins > 64 || n_slots < 1 || n_hist < 2 || batch < 1 || batch > 65535 || hw < 4 || !(hist_hi > hist_lo)) return AWSEG_EINVAL;
+    if (n_bins < 1 || n_bins > 64 || n_slots < 1 || n_hist < 2 || n_hist > kHistMax || batch < 1 || batch > 65535 || hw < 4 || !(hist_hi > hist_lo)) return AWSEG_EINVAL;
     if ((hw & 3) || ((uintptr_t)seg1 & 15) || ((uintptr_t)seg2 & 15)) return AWSEG_EALIGN;
     hipStream_t s = awseg_s(stream);
-    const int bpi = blocks_per_image(hw, batch, 1);
+    int bpi = blocks_per_image(hw, batch, 1);
+    const int cap = (int)((AWSEG_CUS * 2 + batch - 1) / batch);   // 64 KB of LDS per block: two blocks per CU
+    if (bpi > cap) bpi = cap < 1 ? 1 : cap;
     dim3 grid(bpi, (unsigned)batch), block(kThreads);
     const float scale = (float)n_hist / (hist_hi - hist_lo);
+    const size_t lds = (size_t)2 * n_hist * sizeof(uint32_t);
     unsigned long long* hist = (unsigned long long*)auroc_hist;
-#define AWSEG_ES(M, L) hipLaunchKernelGGL((ensemble_stats_kernel<M, L>), grid, block, 0, s, seg1, seg2, hw, weights, temperature, label, \
-                                          edges, n_bins, (ece_cell*)workspace, hist, n_hist, hist_lo, scale)
-    if (mode == AWSEG_COMBINE_WEIGHTED) { if (label_dtype == AWSEG_U8) AWSEG_ES(0, AWSEG_U8); else if (label_dtype == AWSEG_I64) AWSEG_ES(0, AWSEG_I64); else return AWSEG_EINVAL; }
-    else { if (label_dtype == AWSEG_U8) AWSEG_ES(2, AWSEG_U8); else if (label_dtype == AWSEG_I64) AWSEG_ES(2, AWSEG_I64); else return AWSEG_EINVAL; }
+#define AWSEG_ES(M, L) { \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ensemble_stats_kernel<M, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AWSEG_EINVAL; \
+        hipLaunchKernelGGL((ensemble_stats_kernel<M, L>), grid, block, lds, s, seg1, seg2, hw, weights, temperature, label, \
+                           edges, n_bins, (ece_cell*)workspace, hist, n_hist, hist_lo, scale); }
+    if (mode == AWSEG_COMBINE_WEIGHTED) { if (label_dtype == AWSEG_U8) AWSEG_ES(0, AWSEG_U8) else if (label_dtype == AWSEG_I64) AWSEG_ES(0, AWSEG_I64) else return AWSEG_EINVAL; }
+    else { if (label_dtype == AWSEG_U8) AWSEG_ES(2, AWSEG_U8) else if (label_dtype == AWSEG_I64) AWSEG_ES(2, AWSEG_I64) else return AWSEG_EINVAL; }
 #undef AWSEG_ES
     AWSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(ece_fold_kernel, dim3((unsigned)batch), dim3(64), 0, s, (const ece_cell*)workspace, bpi, n_bins, cond,

@@ -8,7 +8,7 @@ once at the end.  Here each batch updates additive device counters and nothing e
   * confusion  int64[1+K, C*C]   slot 0 overall, slot 1+k weather condition k  (HIP, fused with
                                   combine / temperature / argmax)
   * ECE bins   [1+K, 15] x {count, sum conf, sum correct}                      (HIP)
-  * AUROC      int64[2, 2^16] histogram of the disagreement score by error/non-error
+  * AUROC      int64[2, 2^13] histogram of the disagreement score by error/non-error
 
 Counters are SUM-all-reduced over ranks once (RCCL), then rank-agnostic host math finishes:
 the 19-element IoU divide/mean uses the reference's own torch expressions, so identical counts
@@ -29,7 +29,7 @@ from .metrics import ConfidenceCalibration, RobustnessMetrics
 
 logger = logging.getLogger(__name__)
 
-AUROC_BINS = 1 << 16
+AUROC_BINS = 1 << 13                      # per-block LDS histogram (2 x 8192 x 4 B = 64 KB)
 AUROC_LO, AUROC_HI = -1e-3, 0.70          # mutual information of two members lies in [0, ln 2]
 
 

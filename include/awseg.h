@@ -388,7 +388,8 @@ int awseg_ece_accumulate(const float* logits, int64_t batch, int num_classes, in
  * awseg_ece_accumulate, computed from r = combine(seg1, seg2)/T (mode WEIGHTED or MEAN).  The
  * disagreement score (mutual information) of every pixel with label != 255 is counted into
  * auroc_hist int64 [2][n_hist]: row 0 = correctly predicted (argmax of the mean probability == label),
- * row 1 = errors; bin = (score - hist_lo) * n_hist / (hist_hi - hist_lo), clamped.  C must be 19,
+ * row 1 = errors; bin = (score - hist_lo) * n_hist / (hist_hi - hist_lo), clamped; n_hist <= 8192 (the
+ * histogram is aggregated per block in LDS before it touches global memory).  C must be 19,
  * H*W a multiple of 4.  workspace as awseg_metrics_workspace. */
 int awseg_ensemble_eval_stats(const float* seg1, const float* seg2, int64_t batch, int num_classes, int64_t hw,
                               int mode, const float* weights, const float* temperature,

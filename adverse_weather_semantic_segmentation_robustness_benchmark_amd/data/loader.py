@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from .preprocessing import WeatherDegradationTransforms
+from .preprocessing import DepthEstimationPreprocessor, WeatherDegradationTransforms
 
 logger = logging.getLogger(__name__)
 
@@ -24,7 +24,8 @@ logger = logging.getLogger(__name__)
 class CityscapesKITTIDataset:
     """Batch source with the reference dataset's constructor arguments.  Iterate it through
     `create_dataloader` (or `.batches()`): each batch is the reference's collated dict
-    {'image' f32[B,3,H,W], 'label' u8[B,H,W], 'weather_condition' list[str], 'dataset' list[str]}
+    {'image' f32[B,3,H,W], 'label' u8[B,H,W], 'weather_condition' list[str], 'dataset' list[str],
+    'depth' f32[B,H,W] when include_depth}
     on the GPU."""
 
     def __init__(self, data_root: str = "data", split: str = "train", image_size: Tuple[int, int] = (512, 1024),
@@ -38,6 +39,7 @@ class CityscapesKITTIDataset:
         self.weather_schedule = weather_schedule          # 'random' (loader.py:265) or 'round_robin' (bench)
         self.num_samples = num_samples if num_samples is not None else (100 if split == "train" else 20)
         self.weather_transforms = WeatherDegradationTransforms(rng=rng, device=self.device)
+        self.depth_preprocessor = DepthEstimationPreprocessor(self.device) if include_depth else None   # loader.py:68-69
         self._gen = torch.Generator(device=self.device)
         self._gen.manual_seed(seed)
         self._host_rng = np.random.RandomState(seed)
@@ -63,8 +65,16 @@ class CityscapesKITTIDataset:
         conds = self.choose_conditions(start, n)
         h, w = self.image_size
         image = torch.empty(n, 3, h, w, dtype=torch.float32, device=self.device)
-        self.weather_transforms.apply_batch(imgs, conds, norm_out=image)
-        return {"image": image, "label": labels, "weather_condition": conds, "dataset": ["synthetic"] * n}
+        batch = {"image": image, "label": labels, "weather_condition": conds, "dataset": ["synthetic"] * n}
+        if self.depth_preprocessor is None:
+            self.weather_transforms.apply_batch(imgs, conds, norm_out=image)
+        else:
+            # the depth target is estimated from the CORRUPTED uint8 frame (loader.py:264-272), so
+            # the transforms also write their uint8 output
+            frames = torch.empty_like(imgs)
+            self.weather_transforms.apply_batch(imgs, conds, out=frames, norm_out=image)
+            batch["depth"] = self.depth_preprocessor.estimate_depth_batch(frames)
+        return batch
 
     def batches(self, batch_size: int, drop_last: bool = False, rank: int = 0, world_size: int = 1) -> Iterator[Dict[str, object]]:
         """Contiguous block sharding of the sample index range over ranks."""

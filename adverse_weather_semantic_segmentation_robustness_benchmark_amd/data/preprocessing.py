@@ -206,3 +206,41 @@ class WeatherDegradationTransforms:
         if isinstance(image, np.ndarray) and image.dtype != np.uint8:
             return np.rint(image.astype(np.float64) * 255.0).astype(np.uint8)
         return image
+
+
+class DepthEstimationPreprocessor:
+    """PKG/data/preprocessing.py:291-411.  `estimate_depth` keeps the reference convention (one
+    uint8 HWC numpy frame -> float64 [H,W] numpy); `estimate_depth_batch` is the device form the
+    loader uses ([B,H,W,3] uint8 on the GPU -> float32 [B,H,W], no host round trip)."""
+
+    def __init__(self, device: Union[str, torch.device] = "cuda") -> None:
+        self.depth_model = None                                                      # :302
+        self.device = torch.device(device)
+
+    def estimate_depth(self, image):
+        is_np = isinstance(image, np.ndarray)
+        dev = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(self.device) if is_np else image
+        out = ops.depth_estimate(dev.unsqueeze(0), dtype=torch.float64)[0]
+        return out.cpu().numpy() if is_np else out
+
+    _geometric_depth_estimation = estimate_depth                                      # :325
+
+    def estimate_depth_batch(self, imgs: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return ops.depth_estimate(imgs, out=out, dtype=torch.float32)
+
+    def depth_to_disparity(self, depth, baseline: float = 0.54):
+        """:369-385."""
+        if isinstance(depth, torch.Tensor):
+            return baseline / torch.clamp(depth, min=1e-6)
+        return baseline / np.maximum(depth, 1e-6)
+
+    def preprocess_depth_for_training(self, depth, target_size) -> torch.Tensor:
+        """:387-411: min-max normalise to [0,1] -> float32 tensor.  The reference resizes with
+        cv2.resize (bilinear) when the shape differs; here that is torch's bilinear interpolation
+        (align_corners=False, the same half-pixel sampling)."""
+        t = torch.as_tensor(depth)
+        if tuple(t.shape) != tuple(target_size):
+            t = torch.nn.functional.interpolate(t[None, None].to(torch.float64), size=tuple(target_size), mode="bilinear",
+                                                align_corners=False)[0, 0]
+        t = (t - t.min()) / (t.max() - t.min() + 1e-8)
+        return t.float()

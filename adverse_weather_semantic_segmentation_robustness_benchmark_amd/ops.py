@@ -206,6 +206,21 @@ def synthetic_depth(h: int, w: int, jobs: np.ndarray, device, noise: Optional[to
     return out
 
 
+def depth_estimate(imgs: torch.Tensor, out: Optional[torch.Tensor] = None, dtype=torch.float32) -> torch.Tensor:
+    """DepthEstimationPreprocessor.estimate_depth (PKG/data/preprocessing.py:304-367) for a uint8
+    [B,H,W,3] batch -> [B,H,W] depth target in [0,1]; float64 (reference dtype) or float32 (what
+    the loader hands on, loader.py:290)."""
+    imgs = imgs.contiguous()
+    b, h, w, _ = imgs.shape
+    if out is None:
+        out = torch.empty(b, h, w, dtype=dtype, device=imgs.device)
+    ws = torch.empty(max(1, b), dtype=torch.int32, device=imgs.device)
+    o64 = out if out.dtype == torch.float64 else None
+    o32 = out if out.dtype == torch.float32 else None
+    N.call("awseg_depth_estimate", N.ptr(imgs), b, h, w, N.host(_TAPS), N.ptr(ws), N.ptr(o64), N.ptr(o32), N.stream())
+    return out
+
+
 def fog(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = None, depth: Optional[torch.Tensor] = None,
         out: Optional[torch.Tensor] = None, norm_out: Optional[torch.Tensor] = None, depth_out: Optional[torch.Tensor] = None,
         mean=None, std=None) -> None:

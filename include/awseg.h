@@ -25,6 +25,7 @@
 #ifndef AWSEG_H
 #define AWSEG_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -182,6 +183,26 @@ int awseg_synthetic_depth(int height, int width,
                           const awseg_fog_job* jobs, int n_jobs,
                           const double* noise, const double* taps_host,
                           double* depth_out, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
+ *  next #2  DepthEstimationPreprocessor.estimate_depth
+ *       replaces PKG/data/preprocessing.py:304-367 (called per sample by
+ *       PKG/data/loader.py:270-272 when include_depth is set)
+ * ------------------------------------------------------------------------- *
+ * imgs uint8 [batch,H,W,3] (the weather-corrupted frames).  Per image:
+ * gray = 8-bit RGB2GRAY, tex = 3x3 Laplacian (BORDER_REFLECT_101), depth =
+ * clip(base(y) - 0.3*|tex|/(max|tex| + 1e-8), 0, 1) in float64 with base =
+ * (y/H)*0.8+0.2, rows < H/3 -> 1, rows >= H/2 -> *0.5, then the sigma=2
+ * Gaussian of A2 (taps_host: host double[17]).  Outputs float64 [batch,H,W]
+ * (what the reference returns) and/or float32 (what the loader hands the model,
+ * loader.py:290); either may be NULL, not both.  workspace: device memory of
+ * awseg_depth_estimate_workspace(batch) bytes (per-image max |tex|, cleared
+ * by the call).  Two launches, stream-ordered.
+ */
+size_t awseg_depth_estimate_workspace(int batch);
+int awseg_depth_estimate(const uint8_t* imgs, int batch, int height, int width,
+                         const double* taps_host, void* workspace,
+                         double* depth_f64, float* depth_f32, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A3  _apply_fog            replaces PKG/data/preprocessing.py:113-123

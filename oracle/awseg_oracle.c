@@ -698,4 +698,57 @@ ORC_API void orc_ece_bins(const float* logits, const void* label, int label_is_u
         }
 }
 
+
+/* ------------------------------------------------------------- next #2 --- */
+/* DepthEstimationPreprocessor._geometric_depth_estimation, PKG/data/
+ * preprocessing.py:325-367, on a uint8 RGB frame:
+ *   gray  = cv2.cvtColor(image, COLOR_RGB2GRAY)               (:338)
+ *   base  = (y/h)*0.8 + 0.2; rows < h//3 -> 1.0; rows >= h//2 -> *0.5   (:340-354)
+ *   tex   = cv2.Laplacian(gray, CV_64F)                       (:358)
+ *   depth = clip(base - 0.3*|tex|/(max|tex| + 1e-8), 0, 1)    (:359-363)
+ *   depth = scipy gaussian_filter(depth, sigma=2)             (:366)
+ * cv2 is absent from this image, so the two OpenCV steps restate OpenCV 4.x's published
+ * arithmetic and are PARITY UNPINNED: RGB2GRAY on 8-bit data is the 15-bit fixed-point
+ * (R*9798 + G*19235 + B*3735 + 16384) >> 15 (imgproc color.hpp RY15/GY15/BY15, gray_shift);
+ * Laplacian with the default ksize=1 is the 3x3 aperture [0 1 0; 1 -4 1; 0 1 0] with
+ * BORDER_REFLECT_101, exact in float64.  The float64 ladder and the Gaussian are numpy/scipy
+ * and are pinned (tests/golden: depth_estimate_* made with scipy.ndimage itself). */
+static inline int orc_gray15(const uint8_t* px)
+{
+    return (px[0] * 9798 + px[1] * 19235 + px[2] * 3735 + (1 << 14)) >> 15;
+}
+
+ORC_API void orc_depth_estimate(const uint8_t* img, int H, int W, const double* taps, double* depth)
+{
+    int64_t hw = (int64_t)H * W;
+    int* gray = (int*)malloc(sizeof(int) * (size_t)hw);
+    int* lap = (int*)malloc(sizeof(int) * (size_t)hw);
+    double* d = (double*)malloc(sizeof(double) * (size_t)hw);
+    for (int64_t i = 0; i < hw; ++i) gray[i] = orc_gray15(img + i * 3);
+    int mx = 0;
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            int ym = orc_reflect101(y - 1, H), yp = orc_reflect101(y + 1, H);
+            int xm = orc_reflect101(x - 1, W), xp = orc_reflect101(x + 1, W);
+            int v = gray[(int64_t)ym * W + x] + gray[(int64_t)yp * W + x] + gray[(int64_t)y * W + xm]
+                  + gray[(int64_t)y * W + xp] - 4 * gray[(int64_t)y * W + x];
+            v = v < 0 ? -v : v;
+            lap[(int64_t)y * W + x] = v;
+            if (v > mx) mx = v;
+        }
+    double denom = (double)mx + 1e-8;
+    for (int y = 0; y < H; ++y) {
+        double base = ((double)y / (double)H) * 0.8 + 0.2;
+        if (y < H / 3) base = 1.0;
+        if (y >= H / 2) base = base * 0.5;
+        for (int x = 0; x < W; ++x) {
+            double ts = (double)lap[(int64_t)y * W + x] / denom;
+            double v = base + (-0.3 * ts);
+            d[(int64_t)y * W + x] = v < 0.0 ? 0.0 : (v > 1.0 ? 1.0 : v);
+        }
+    }
+    orc_gauss17(d, H, W, taps, depth);
+    free(gray); free(lap); free(d);
+}
+
 ORC_API int orc_version(void) { return 1; }

@@ -27,6 +27,11 @@ def golden_metrics():
 
 
 @pytest.fixture(scope="session")
+def golden_depth():
+    return np.load(GOLDEN / "depth.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_model():
     return np.load(GOLDEN / "model.npz")
 

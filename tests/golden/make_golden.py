@@ -249,10 +249,44 @@ def gen_model(model):
     np.savez_compressed(OUT / "model.npz", **out)
 
 
+def gen_depth_estimate():
+    """DepthEstimationPreprocessor (preprocessing.py:325-367) needs the real cv2 for its first two
+    steps, so the reference function cannot run here (PARITY UNPINNED for those steps).  These
+    fixtures are NOT produced by the reference: gray / Laplacian restate OpenCV 4.x's published
+    integer arithmetic in numpy; the float64 ladder of :340-363 is written with the reference's own
+    numpy expressions and the smoothing is scipy.ndimage.gaussian_filter itself (:366), i.e. the
+    libraries the reference calls.  They pin the C oracle's float64 ladder + Gaussian."""
+    from scipy.ndimage import gaussian_filter
+    out = {}
+    for k, (h, w, seed) in enumerate([(32, 64, 1), (17, 23, 2), (64, 128, 3), (5, 9, 4)]):
+        rs = np.random.RandomState(7000 + seed)
+        img = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        if k == 2:
+            img[: h // 2] = 200                                    # flat sky: zero texture rows
+        i32 = img.astype(np.int64)
+        gray = (i32[..., 0] * 9798 + i32[..., 1] * 19235 + i32[..., 2] * 3735 + (1 << 14)) >> 15
+        g = np.pad(gray, 1, mode="reflect")                       # numpy 'reflect' == BORDER_REFLECT_101
+        texture = (g[:-2, 1:-1] + g[2:, 1:-1] + g[1:-1, :-2] + g[1:-1, 2:] - 4 * gray).astype(np.float64)
+        sky_mask = np.zeros((h, w), dtype=np.float32); sky_mask[: h // 3, :] = 1.0
+        road_mask = np.zeros((h, w), dtype=np.float32); road_mask[h // 2:, :] = 1.0
+        y_coords = np.arange(h)[:, np.newaxis] / h
+        base_depth = np.tile(y_coords * 0.8 + 0.2, (1, w))
+        depth = base_depth.copy()
+        depth[sky_mask > 0] = 1.0
+        depth[road_mask > 0] *= 0.5
+        texture_strength = np.abs(texture) / (np.max(np.abs(texture)) + 1e-8)
+        depth = np.clip(depth + (-0.3 * texture_strength), 0, 1)
+        depth = gaussian_filter(depth, sigma=2)
+        out[f"img{k}"] = img
+        out[f"depth{k}"] = depth
+    np.savez_compressed(OUT / "depth.npz", **out)
+
+
 if __name__ == "__main__":
     metrics, pre, model = load_reference()
     gen_weather(pre)
     gen_metrics(metrics)
     gen_model(model)
+    gen_depth_estimate()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

@@ -194,3 +194,23 @@ def test_c1_config_deeplab_fog_only_end_to_end(ops, oracle):
     miou_gpu = oracle.iou_from_counts(counts[0].cpu().numpy(), C)["mean_iou"]
     miou_cpu = oracle.iou_from_counts(oracle.confusion(ref_pred, labels, C), C)["mean_iou"]
     assert abs(miou_gpu - miou_cpu) < 1e-3
+
+
+def test_fullsize_depth_estimate(ops):
+    """1024x2048 depth targets: one frame bit-exact against the C oracle; over the batch the
+    properties of preprocessing.py:340-366 — values in [0,1], a textureless frame gives the smoothed
+    positional prior (1.0 deep inside the sky third, half the ramp on the road half), batch entries
+    are independent of their neighbours."""
+    from oracle import cpu_oracle as O
+    g = torch.Generator(device="cuda").manual_seed(3)
+    imgs = torch.randint(0, 256, (4, H, W, 3), dtype=torch.uint8, device="cuda", generator=g)
+    imgs[1] = 77                                                         # flat frame: zero Laplacian
+    d = ops.depth_estimate(imgs, dtype=torch.float64)
+    assert d.min().item() >= 0.0 and d.max().item() <= 1.0 + 1e-12
+    assert np.array_equal(d[0].cpu().numpy(), O.depth_estimate(imgs[0].cpu().numpy()))
+    flat = d[1]
+    assert (flat[: H // 3 - 9] - 1.0).abs().max().item() < 1e-12
+    y = torch.arange(H // 2 + 9, H - 9, device="cuda", dtype=torch.float64)
+    assert (flat[H // 2 + 9: H - 9, 5] - ((y / H) * 0.8 + 0.2) * 0.5).abs().max().item() < 1e-9   # linear ramp is a Gaussian fixed point
+    alone = ops.depth_estimate(imgs[2:3], dtype=torch.float64)
+    assert torch.equal(alone[0], d[2])

@@ -285,6 +285,39 @@ def test_loss_label_out_of_range_flag(ops):
     assert oob.item() == 16
 
 
+def test_depth_estimate_golden_and_ragged(ops, oracle, golden_depth):
+    """DepthEstimationPreprocessor.estimate_depth: float64 bit-exact against the scipy-made
+    fixtures and the C oracle (tile edges, images smaller than the 8-pixel halo, batch > 1)."""
+    g = golden_depth
+    for k in range(4):
+        got = ops.depth_estimate(dev(g[f"img{k}"][None]), dtype=torch.float64)[0].cpu().numpy()
+        assert np.array_equal(got, g[f"depth{k}"]), f"case {k}"
+    rs = np.random.RandomState(5)
+    for (b, h, w) in [(3, 33, 65), (2, 70, 130), (1, 3, 4), (2, 31, 64), (1, 97, 61)]:
+        imgs = rs.randint(0, 256, (b, h, w, 3), dtype=np.uint8)
+        d64 = ops.depth_estimate(dev(imgs), dtype=torch.float64).cpu().numpy()
+        d32 = ops.depth_estimate(dev(imgs), dtype=torch.float32).cpu().numpy()
+        for i in range(b):
+            want = oracle.depth_estimate(imgs[i])
+            assert np.array_equal(d64[i], want), (b, h, w, i)
+            assert np.array_equal(d32[i], want.astype(np.float32))               # loader.py:290 .float()
+
+
+def test_depth_estimate_abi_edges(ops, native):
+    N = native
+    imgs = torch.zeros(1, 8, 8, 3, dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(4, dtype=torch.int32, device="cuda")
+    out = torch.zeros(1, 8, 8, dtype=torch.float32, device="cuda")
+    taps = N.host(np.full(17, 1.0 / 17))
+    f = N.lib().awseg_depth_estimate
+    assert f(N.ptr(imgs), 0, 8, 8, taps, N.ptr(ws), None, N.ptr(out), N.stream()) == 0    # empty batch
+    assert f(N.ptr(imgs), 1, 8, 8, taps, N.ptr(ws), None, None, N.stream()) == -1          # no output: AWSEG_EINVAL
+    assert f(N.ptr(imgs), 1, 0, 8, taps, N.ptr(ws), None, N.ptr(out), N.stream()) == -1
+    assert f(None, 1, 8, 8, taps, N.ptr(ws), None, N.ptr(out), N.stream()) == -1
+    assert N.lib().awseg_depth_estimate_workspace(5) == 20
+    assert ops.depth_estimate(torch.zeros(0, 8, 8, 3, dtype=torch.uint8, device="cuda")).shape == (0, 8, 8)
+
+
 def test_density_from_depth(ops, golden_model):
     g = golden_model
     got = ops.fog_density_from_depth(dev(g["loss_dpred"][:, 0])).cpu().numpy()

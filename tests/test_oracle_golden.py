@@ -150,3 +150,14 @@ def test_segformer_head_as_written(oracle, golden_model):
     H, W = [int(v) for v in g["head_size"]]
     out = oracle.segformer_head(g["head_feat"][0], g["head_w1"], scale, shift, g["head_w2"], g["head_b2"], H, W)
     assert np.abs(out - g["head_out"][0]).max() < 1e-4
+
+
+def test_depth_estimate_ladder_and_gaussian(oracle, golden_depth):
+    """SURVEY §8(f) #2.  The fixtures come from numpy + scipy.ndimage.gaussian_filter (the libraries
+    the reference calls at preprocessing.py:340-366); the two cv2 steps are restated (parity unpinned)."""
+    g = golden_depth
+    for k in range(4):
+        d = oracle.depth_estimate(g[f"img{k}"])
+        assert d.dtype == np.float64 and np.array_equal(d, g[f"depth{k}"])
+        assert d.min() >= 0.0 and d.max() <= 1.0 + 1e-12
+

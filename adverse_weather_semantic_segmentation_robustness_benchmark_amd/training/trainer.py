@@ -29,6 +29,7 @@ from .. import ops, parallel
 from ..data.preprocessing import WeatherDegradationTransforms
 from ..evaluation.metrics import RobustnessMetrics
 from ..models.model import FogDensityAwareLoss
+from ..utils.checkpoint import load_model_state
 
 logger = logging.getLogger(__name__)
 
@@ -256,7 +257,7 @@ class AdverseWeatherTrainer:
 
     def load_checkpoint(self, checkpoint_path: str) -> None:
         ckpt = torch.load(checkpoint_path, map_location=self.device, weights_only=False)
-        self.model.load_state_dict(ckpt["model_state_dict"])
+        load_model_state(self.model, ckpt)
         self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
         if self.scheduler and ckpt["scheduler_state_dict"]:
             self.scheduler.load_state_dict(ckpt["scheduler_state_dict"])

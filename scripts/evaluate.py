@@ -22,6 +22,8 @@ from adverse_weather_semantic_segmentation_robustness_benchmark_amd import paral
 from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data.loader import CityscapesKITTIDataset, create_dataloader
 from adverse_weather_semantic_segmentation_robustness_benchmark_amd.evaluation.harness import evaluate_model
 from adverse_weather_semantic_segmentation_robustness_benchmark_amd.evaluation.metrics import RobustnessMetrics
+from adverse_weather_semantic_segmentation_robustness_benchmark_amd.evaluation.report import generate_evaluation_report
+from adverse_weather_semantic_segmentation_robustness_benchmark_amd.utils.checkpoint import load_model_state
 from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import DeepLabV3PlusModel, EnsembleModel, SegFormerModel
 from adverse_weather_semantic_segmentation_robustness_benchmark_amd.utils.config import (create_default_config, get_device_config, load_config,
                                                                                     setup_logging)
@@ -44,7 +46,7 @@ def load_model(config, checkpoint_path, device):
         raise ValueError(f"Unknown model type: {kind}")
     if checkpoint_path and str(checkpoint_path).lower() != "none":
         ckpt = torch.load(checkpoint_path, map_location=device, weights_only=False)
-        model.load_state_dict(ckpt["model_state_dict"])
+        load_model_state(model, ckpt)            # incl. the transformers-version key translation
     return model.to(device).eval()
 
 
@@ -70,9 +72,7 @@ def main():
         metrics = RobustnessMetrics(num_classes=config.get("model.num_classes", 19), weather_conditions=config.get("data.weather_conditions"))
         results = evaluate_model(model, loader, metrics, device, config)
         if rank == 0:
-            out = Path(args.output_dir)
-            out.mkdir(parents=True, exist_ok=True)
-            (out / "evaluation_results.json").write_text(json.dumps({k: float(v) for k, v in results.items()}, indent=2))
+            generate_evaluation_report({k: float(v) for k, v in results.items()}, Path(args.output_dir))   # json + markdown, :277-392
             for k, v in results.items():
                 logger.info("%s: %.4f", k, v)
     except Exception as e:  # noqa: BLE001 - the reference converts failures to exit code 1 (evaluate.py:506-508)

@@ -266,3 +266,74 @@ def test_two_rank_gloo_counter_allreduce_matches_single_process(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()[-2000:]
+
+
+def test_checkpoint_key_translation_between_transformers_spellings():
+    """`segformer.segformer.*` keys are transformers-version dependent; a checkpoint in
+    the legacy spelling (the releases REF/requirements.txt pins) must load into the live model."""
+    import torch
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.utils import checkpoint as K
+    cur = ["segformer.segformer.stages.0.patch_embeddings.proj.weight", "segformer.segformer.stages.1.patch_embeddings.layer_norm.bias",
+           "segformer.segformer.stages.2.blocks.1.layernorm_before.weight", "segformer.segformer.stages.0.blocks.0.attention.q_proj.bias",
+           "segformer.segformer.stages.0.blocks.0.attention.k_proj.weight", "segformer.segformer.stages.0.blocks.0.attention.v_proj.weight",
+           "segformer.segformer.stages.0.blocks.0.attention.o_proj.weight",
+           "segformer.segformer.stages.0.blocks.0.attention.sequence_reduction.sequence_reduction.weight",
+           "segformer.segformer.stages.0.blocks.0.attention.sequence_reduction.layer_norm.weight",
+           "segformer.segformer.stages.3.blocks.1.layernorm_after.bias", "segformer.segformer.stages.3.blocks.1.mlp.fc1.weight",
+           "segformer.segformer.stages.3.blocks.1.mlp.dwconv.dwconv.weight", "segformer.segformer.stages.3.blocks.1.mlp.fc2.bias",
+           "segformer.segformer.stages.3.layer_norm.weight", "segformer.segmentation_head.0.weight", "ensemble_weights", "temperature"]
+    legacy = ["segformer.segformer.encoder.patch_embeddings.0.proj.weight", "segformer.segformer.encoder.patch_embeddings.1.layer_norm.bias",
+              "segformer.segformer.encoder.block.2.1.layer_norm_1.weight", "segformer.segformer.encoder.block.0.0.attention.self.query.bias",
+              "segformer.segformer.encoder.block.0.0.attention.self.key.weight", "segformer.segformer.encoder.block.0.0.attention.self.value.weight",
+              "segformer.segformer.encoder.block.0.0.attention.output.dense.weight", "segformer.segformer.encoder.block.0.0.attention.self.sr.weight",
+              "segformer.segformer.encoder.block.0.0.attention.self.layer_norm.weight", "segformer.segformer.encoder.block.3.1.layer_norm_2.bias",
+              "segformer.segformer.encoder.block.3.1.mlp.dense1.weight", "segformer.segformer.encoder.block.3.1.mlp.dwconv.dwconv.weight",
+              "segformer.segformer.encoder.block.3.1.mlp.dense2.bias", "segformer.segformer.encoder.layer_norm.3.weight",
+              "segformer.segmentation_head.0.weight", "ensemble_weights", "temperature"]
+    sd_legacy = {k: torch.full((1,), float(i)) for i, k in enumerate(legacy)}
+    got = K.remap_segformer_keys(sd_legacy, cur)
+    assert list(got.keys()) == cur and all(got[k].item() == i for i, k in enumerate(cur))
+    back = K.remap_segformer_keys(got, legacy)                         # and the other direction
+    assert list(back.keys()) == legacy
+    same = K.remap_segformer_keys(got, cur)                            # already matching: untouched
+    assert list(same.keys()) == cur
+    stray = K.remap_segformer_keys({"foo.encoder.block.0.0.unknown.weight": torch.zeros(1)}, cur)
+    assert list(stray.keys()) == ["foo.encoder.block.0.0.unknown.weight"]   # unknown entries pass through (strict load reports them)
+
+
+def test_checkpoint_loads_legacy_spelling_into_live_segformer():
+    import torch
+    from transformers import SegformerConfig, SegformerModel
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.utils import checkpoint as K
+    cfg = SegformerConfig(num_encoder_blocks=4, depths=[1, 1, 1, 1], sr_ratios=[8, 4, 2, 1], hidden_sizes=[8, 16, 24, 32],
+                          num_attention_heads=[1, 2, 3, 4])
+    torch.manual_seed(0)
+    a, b = SegformerModel(cfg), SegformerModel(cfg)
+    other = [k.replace("stages.0.", "STAGE0.") for k in a.state_dict()]      # force the translation direction
+    legacy_names = {}
+    for k in a.state_dict():
+        nk = K._current_to_legacy(k)
+        assert nk is not None and K._legacy_to_current(nk) == k, k            # every MiT entry has both spellings
+        legacy_names[nk] = a.state_dict()[k]
+    K.load_model_state(b, {"model_state_dict": legacy_names})
+    for k, v in a.state_dict().items():
+        assert torch.equal(v, b.state_dict()[k])
+    del other
+
+
+def test_evaluation_report_files(tmp_path):
+    """REF/scripts/evaluate.py:277-392: json + markdown with the reference's sections and formats."""
+    import json
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.evaluation.report import generate_evaluation_report
+    res = {"overall_miou": 0.5, "miou_clean": 0.8, "miou_fog": 0.6, "miou_night": 0.4, "robustness_degradation_fog": 0.25,
+           "robustness_degradation_ratio": 0.2, "expected_calibration_error": 0.04, "ensemble_disagreement_auroc": 0.9}
+    generate_evaluation_report(res, tmp_path / "out")
+    assert json.loads((tmp_path / "out" / "evaluation_results.json").read_text()) == res
+    md = (tmp_path / "out" / "evaluation_report.md").read_text().splitlines()
+    assert md[0] == "# Adverse Weather Semantic Segmentation Evaluation Report"
+    assert "| miou_clean | 0.780 | 0.800 | ✓ |" in md and "| miou_fog | 0.650 | 0.600 | ✗ |" in md
+    assert "| miou_rain | 0.620 | 0.000 | ✗ |" in md                          # missing metric counts as 0.0
+    assert "| expected_calibration_error | 0.050 | 0.040 | ✗ |" in md          # the reference marks with >= for every row
+    assert "- **Fog**: mIoU = 0.600" in md and "- **Night**: mIoU = 0.400" in md and not any("Rain**: mIoU" in l for l in md)
+    assert "- **Overall Degradation Ratio**: 0.200" in md and "- **Fog Degradation**: 0.250" in md
+    assert "- **Expected Calibration Error**: 0.040" in md and "- **Disagreement AUROC**: 0.900" in md

@@ -17,6 +17,7 @@ _LAZY = {
     "ConfidenceCalibration": ".evaluation.metrics", "EnsembleDisagreementMetrics": ".evaluation.metrics",
     "AdverseWeatherTrainer": ".training.trainer", "EarlyStopping": ".training.trainer",
     "WeatherDegradationTransforms": ".data.preprocessing", "CityscapesKITTIDataset": ".data.loader",
+    "WeatherAugmentationPipeline": ".data.loader", "DepthEstimationPreprocessor": ".data.preprocessing",
 }
 __all__ = sorted(_LAZY)
 

@@ -102,6 +102,43 @@ void normalize_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const int32_
     }
 }
 
+// ------------------------------------------------------------------------- next #4 (style LUT)
+// WeatherAugmentationPipeline._apply_style_transfer (PKG/data/loader.py:360-387) is a per-channel
+// uint8 -> uint8 map (cv2.convertScaleAbs, then an optional gain on channel 2), so the host builds
+// the 3 x 256 table with the reference's arithmetic and the device applies it: 12 B in, 12 B out
+// per lane, table in LDS.  lut_of[b] < 0 leaves frame b unchanged.
+__global__ __launch_bounds__(kThreads)
+void lut3_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const uint8_t* __restrict__ luts,
+                 const int32_t* __restrict__ lut_of, uint8_t* __restrict__ out)
+{
+    __shared__ uint8_t s_lut[3 * 256];
+    const int which = lut_of[blockIdx.y];
+    const uint8_t* src = imgs + (int64_t)blockIdx.y * hw * 3;
+    uint8_t* dst = out + (int64_t)blockIdx.y * hw * 3;
+    if (which < 0 && src == dst) return;
+    for (int i = threadIdx.x; i < 768; i += kThreads) s_lut[i] = which < 0 ? (uint8_t)(i & 255) : luts[(int64_t)which * 768 + i];
+    __syncthreads();
+    const int64_t nquad = hw / 4;                                  // 4 pixels = 3 dwords
+    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(src + q * 12);
+        uint32_t w[3] = {p[0], p[1], p[2]}, r[3];
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            uint32_t o = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c = (d * 4 + k) % 3;                     // byte index within the 12-byte group -> channel
+                o |= (uint32_t)s_lut[c * 256 + ((w[d] >> (8 * k)) & 0xFF)] << (8 * k);
+            }
+            r[d] = o;
+        }
+        uint32_t* o4 = reinterpret_cast<uint32_t*>(dst + q * 12);
+        o4[0] = r[0]; o4[1] = r[1]; o4[2] = r[2];
+    }
+    if (blockIdx.x == 0)
+        for (int64_t i = nquad * 12 + threadIdx.x; i < hw * 3; i += kThreads) dst[i] = s_lut[(i % 3) * 256 + src[i]];
+}
+
 // ------------------------------------------------------------------------- A2 + A3 (fog)
 // Tile TW x TH outputs; the 17-tap separable float64 Gaussian needs an 8-pixel halo, staged
 // in LDS.  Pass order and summation order are scipy's (axis 0 first; centre tap, then the
@@ -977,6 +1014,20 @@ AWSEG_API int awseg_normalize(const uint8_t* imgs, int64_t batch, int height, in
     if ((hw & 3) != 0) return AWSEG_EALIGN;
     dim3 grid(grid_for(hw / 4, n), (unsigned)n);
     hipLaunchKernelGGL(normalize_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, sel, make_nc(mean_host, std_host), out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_lut3_apply(const uint8_t* imgs, int batch, int height, int width, const uint8_t* luts, int n_luts,
+                               const int32_t* lut_of, uint8_t* out, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!imgs || !out || !lut_of || (n_luts > 0 && !luts) || batch < 0 || n_luts < 0 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (batch > 65535) return AWSEG_ERANGE;
+    const int64_t hw = (int64_t)height * width;
+    if (((hw * 3) & 3) || ((uintptr_t)imgs & 3) || ((uintptr_t)out & 3)) return AWSEG_EALIGN;
+    dim3 grid(grid_for(hw / 4 > 0 ? hw / 4 : 1, batch), (unsigned)batch);
+    hipLaunchKernelGGL(lut3_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, luts, lut_of, out);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

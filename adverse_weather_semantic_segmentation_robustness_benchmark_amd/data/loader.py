@@ -89,6 +89,65 @@ class CityscapesKITTIDataset:
             i += n
 
 
+# (alpha, beta, channel-2 gain) of _apply_style_transfer, PKG/data/loader.py:372-385
+STYLE_PARAMS = {"fog": (0.8, 30.0, None), "rain": (1.2, -10.0, 1.1), "snow": (0.9, 20.0, None), "night": (0.4, -20.0, 1.3)}
+
+
+def style_lut(weather_type: str) -> np.ndarray:
+    """uint8 [3,256] table of `_apply_style_transfer` for one weather type: cv2.convertScaleAbs on
+    8-bit data is saturate_cast<uchar>(|v*(float)alpha + (float)beta|) (float32 arithmetic, round
+    half to even), then `image[:,:,2] = np.clip(image[:,:,2]*gain, 0, 255)` is a float64 product
+    truncated by the uint8 store.  Identity for types the reference does not style."""
+    v = np.arange(256, dtype=np.float32)
+    if weather_type not in STYLE_PARAMS:
+        return np.tile(np.arange(256, dtype=np.uint8), (3, 1))
+    alpha, beta, gain = STYLE_PARAMS[weather_type]
+    base = np.clip(np.rint(np.abs(v * np.float32(alpha) + np.float32(beta))), 0, 255).astype(np.uint8)
+    lut = np.tile(base, (3, 1))
+    if gain is not None:
+        lut[2] = np.clip(base * gain, 0, 255).astype(np.uint8)
+    return lut
+
+
+class WeatherAugmentationPipeline:
+    """PKG/data/loader.py:296-387: fixed-intensity weather followed, with probability
+    `style_transfer_prob`, by the colour 'style transfer'.  Frames may be numpy HWC uint8 (reference
+    convention, returned as numpy) or uint8 device tensors [H,W,3] / [B,H,W,3]."""
+
+    def __init__(self, weather_intensities: Optional[Dict[str, float]] = None, style_transfer_prob: float = 0.3,
+                 device="cuda", rng: str = "numpy", **kwargs) -> None:
+        self.weather_intensities = weather_intensities or {"fog": 0.7, "rain": 0.5, "snow": 0.6, "night": 0.8}
+        self.style_transfer_prob = style_transfer_prob
+        self.device = torch.device(device)
+        self.weather_transforms = WeatherDegradationTransforms(rng=rng, device=self.device)
+        self._types = list(STYLE_PARAMS)
+        self._luts = None
+
+    def _device_luts(self) -> torch.Tensor:
+        if self._luts is None:
+            self._luts = torch.from_numpy(np.stack([style_lut(t) for t in self._types])).to(self.device)
+        return self._luts
+
+    def apply_domain_adaptation_augmentation(self, image, target_weather: Optional[str] = None):
+        if target_weather is None:
+            target_weather = str(np.random.choice(list(self.weather_intensities.keys())))          # :347
+        out = self.weather_transforms.apply_weather_effect(image, target_weather, intensity=self.weather_intensities[target_weather])
+        if np.random.random() < self.style_transfer_prob:                                           # :355
+            out = self._apply_style_transfer(out, target_weather)
+        return out
+
+    def _apply_style_transfer(self, image, weather_type: str):
+        if weather_type not in STYLE_PARAMS:
+            return image
+        is_np = isinstance(image, np.ndarray)
+        dev = torch.from_numpy(np.ascontiguousarray(image, dtype=np.uint8)).to(self.device) if is_np else image
+        batch = dev.unsqueeze(0) if dev.dim() == 3 else dev
+        which = torch.full((batch.shape[0],), self._types.index(weather_type), dtype=torch.int32, device=self.device)
+        out = ops.lut3_apply(batch, self._device_luts(), which)
+        out = out[0] if dev.dim() == 3 else out
+        return out.cpu().numpy() if is_np else out
+
+
 class _Loader:
     def __init__(self, dataset, batch_size, drop_last, rank, world_size):
         self.dataset, self.batch_size, self.drop_last, self.rank, self.world_size = dataset, batch_size, drop_last, rank, world_size

@@ -206,6 +206,16 @@ def synthetic_depth(h: int, w: int, jobs: np.ndarray, device, noise: Optional[to
     return out
 
 
+def lut3_apply(imgs: torch.Tensor, luts: torch.Tensor, lut_of: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[b,...,c] = luts[lut_of[b], c, imgs[b,...,c]] for uint8 [B,H,W,3] frames (lut_of < 0: unchanged)."""
+    imgs = imgs.contiguous()
+    b, h, w, _ = imgs.shape
+    if out is None:
+        out = torch.empty_like(imgs)
+    N.call("awseg_lut3_apply", N.ptr(imgs), b, h, w, N.ptr(luts.contiguous()), int(luts.shape[0]), N.ptr(lut_of), N.ptr(out), N.stream())
+    return out
+
+
 def depth_estimate(imgs: torch.Tensor, out: Optional[torch.Tensor] = None, dtype=torch.float32) -> torch.Tensor:
     """DepthEstimationPreprocessor.estimate_depth (PKG/data/preprocessing.py:304-367) for a uint8
     [B,H,W,3] batch -> [B,H,W] depth target in [0,1]; float64 (reference dtype) or float32 (what

@@ -169,6 +169,19 @@ int awseg_normalize(const uint8_t* imgs, int64_t batch, int height, int width,
                     float* out, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ *  next #4  WeatherAugmentationPipeline._apply_style_transfer
+ *       replaces PKG/data/loader.py:360-387
+ * ------------------------------------------------------------------------- *
+ * Per-channel uint8 -> uint8 lookup: out[b,y,x,c] = luts[lut_of[b]][c][imgs[b,y,x,c]].
+ * luts: device uint8 [n_luts,3,256]; lut_of: device int32 [batch], an index into luts or
+ * < 0 to pass frame b through unchanged (a value >= n_luts is the caller's error, unchecked).
+ * In place (out == imgs) is allowed.  H*W*3 must be a multiple of 4.
+ */
+int awseg_lut3_apply(const uint8_t* imgs, int batch, int height, int width,
+                     const uint8_t* luts, int n_luts, const int32_t* lut_of,
+                     uint8_t* out, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  *  A2  _generate_synthetic_depth
  *       replaces PKG/data/preprocessing.py:227-248
  * ------------------------------------------------------------------------- *

@@ -318,6 +318,26 @@ def test_depth_estimate_abi_edges(ops, native):
     assert ops.depth_estimate(torch.zeros(0, 8, 8, 3, dtype=torch.uint8, device="cuda")).shape == (0, 8, 8)
 
 
+def test_style_transfer_lut(ops, oracle):
+    """WeatherAugmentationPipeline._apply_style_transfer as a device LUT, byte-exact against the
+    per-pixel numpy restatement; mixed batch with a pass-through frame, ragged size, in place."""
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data.loader import WeatherAugmentationPipeline, style_lut
+    rs = np.random.RandomState(11)
+    pipe = WeatherAugmentationPipeline()
+    for (h, w) in [(16, 32), (7, 12), (33, 20)]:
+        img = rs.randint(0, 256, (h, w, 3), dtype=np.uint8)
+        for t in ("fog", "rain", "snow", "night", "clean"):
+            got = pipe._apply_style_transfer(img, t)
+            assert np.array_equal(got, oracle.style_transfer(img, t)), (h, w, t)
+    imgs = rs.randint(0, 256, (3, 16, 32, 3), dtype=np.uint8)
+    luts = torch.from_numpy(np.stack([style_lut("rain"), style_lut("night")])).cuda()
+    d = dev(imgs)
+    ops.lut3_apply(d, luts, torch.tensor([1, -1, 0], dtype=torch.int32, device="cuda"), out=d)       # in place
+    got = d.cpu().numpy()
+    assert np.array_equal(got[0], oracle.style_transfer(imgs[0], "night")) and np.array_equal(got[1], imgs[1])
+    assert np.array_equal(got[2], oracle.style_transfer(imgs[2], "rain"))
+
+
 def test_density_from_depth(ops, golden_model):
     g = golden_model
     got = ops.fog_density_from_depth(dev(g["loss_dpred"][:, 0])).cpu().numpy()

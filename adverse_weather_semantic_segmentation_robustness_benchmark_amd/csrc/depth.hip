@@ -43,6 +43,12 @@ __device__ __forceinline__ int reflect_101(int i, int n)          // BORDER_REFL
     if (i >= n) return 2 * n - 2 - i;
     return i;
 }
+__device__ __forceinline__ int reflect_101n(int i, int n)         // BORDER_REFLECT_101, any offset (cv::borderInterpolate)
+{
+    if (n == 1) return 0;
+    while (i < 0 || i >= n) i = i < 0 ? -i : 2 * n - 2 - i;
+    return i;
+}
 __device__ __forceinline__ int gray15(const uint8_t* __restrict__ px)
 {
     return ((int)px[0] * 9798 + (int)px[1] * 19235 + (int)px[2] * 3735 + (1 << 14)) >> 15;
@@ -187,6 +193,71 @@ void depth_estimate_kernel(const uint8_t* __restrict__ imgs, int H, int W, const
     }
 }
 
+// get_fog_density_map's local contrast (PKG/data/preprocessing.py:270-278): gray float32 in [0,1],
+// local_mean = 5x5 box (cv2.filter2D, kernel ones/25, BORDER_REFLECT_101), local_variance = 5x5 box
+// of (gray - local_mean)^2, contrast = sqrt(variance).  One tile kernel: gray for tile + 4-pixel
+// halo, mean and squared deviation for tile + 2-pixel halo, variance for the tile, all in LDS.
+// Taps are accumulated row-major as k*v with k = 1/25 in float32 (OpenCV's own SIMD order is not
+// specified, so this step is parity-unpinned to ~1e-6).
+constexpr int CT = 32;                         // 32 x 32 outputs per block
+constexpr int CG = CT + 8, CM = CT + 4;
+__global__ __launch_bounds__(kThreads)
+void local_contrast_kernel(const uint8_t* __restrict__ imgs, int H, int W, float* __restrict__ out)
+{
+    __shared__ float s_g[CG * CG];
+    __shared__ float s_d[CM * CM];
+    const int64_t hw = (int64_t)H * W;
+    const uint8_t* src = imgs + (int64_t)blockIdx.z * hw * 3;
+    const int x0 = blockIdx.x * CT, y0 = blockIdx.y * CT;
+    // gray at the positions a REFLECT_101 border maps the window onto (two nested 2-pixel filters:
+    // the outer filter reflects positions first, the inner one reflects around those)
+    for (int i = threadIdx.x; i < CG * CG; i += kThreads) {
+        int ty = i / CG, tx = i - ty * CG;
+        int gy = y0 - 4 + ty, gx = x0 - 4 + tx;
+        float v = 0.f;
+        if (gy >= -2 && gy < H + 2 && gx >= -2 && gx < W + 2) {        // only positions some in-image mean needs
+            const int ry = reflect_101n(gy, H), rx = reflect_101n(gx, W);
+            v = (float)gray15(src + ((int64_t)ry * W + rx) * 3) / 255.0f;   // :271-272
+        }
+        s_g[i] = v;
+    }
+    __syncthreads();
+    const float k = 1.0f / 25.0f;
+    // squared deviation at in-image positions of tile + 2 halo
+    for (int i = threadIdx.x; i < CM * CM; i += kThreads) {
+        int ty = i / CM, tx = i - ty * CM;
+        int gy = y0 - 2 + ty, gx = x0 - 2 + tx;
+        float d = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            float m = 0.f;
+#pragma unroll
+            for (int dy = 0; dy < 5; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 5; ++dx) { float t = k * s_g[(ty + dy) * CG + tx + dx]; m = m + t; }
+            float c = s_g[(ty + 2) * CG + tx + 2] - m;
+            d = c * c;                                                       // :277
+        }
+        s_d[i] = d;
+    }
+    __syncthreads();
+    float* dst = out + (int64_t)blockIdx.z * hw;
+    for (int i = threadIdx.x; i < CT * CT; i += kThreads) {
+        int ty = i / CT, tx = i - ty * CT;
+        int gy = y0 + ty, gx = x0 + tx;
+        if (gy >= H || gx >= W) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int dy = -2; dy <= 2; ++dy)
+#pragma unroll
+            for (int dx = -2; dx <= 2; ++dx) {
+                const int ry = reflect_101n(gy + dy, H), rx = reflect_101n(gx + dx, W);   // REFLECT_101 of the deviation map
+                float t = k * s_d[(ry - y0 + 2) * CM + (rx - x0 + 2)];
+                v = v + t;
+            }
+        dst[(int64_t)gy * W + gx] = sqrtf(v);                                // :278
+    }
+}
+
 }  // namespace
 
 AWSEG_API size_t awseg_depth_estimate_workspace(int batch)
@@ -210,6 +281,17 @@ AWSEG_API int awseg_depth_estimate(const uint8_t* imgs, int batch, int height, i
     hipLaunchKernelGGL(texture_max_kernel, grid, dim3(kThreads), 0, s, imgs, height, width, (int*)workspace);
     AWSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(depth_estimate_kernel, grid, dim3(kThreads), 0, s, imgs, height, width, (const int*)workspace, t, depth_f64, depth_f32);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_local_contrast(const uint8_t* imgs, int batch, int height, int width, float* contrast, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!imgs || !contrast || batch < 0 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (batch > 65535 || (height + CT - 1) / CT > 65535) return AWSEG_ERANGE;
+    dim3 grid((width + CT - 1) / CT, (height + CT - 1) / CT, (unsigned)batch);
+    hipLaunchKernelGGL(local_contrast_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, height, width, contrast);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

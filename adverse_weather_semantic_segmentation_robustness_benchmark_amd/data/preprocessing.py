@@ -187,6 +187,26 @@ class WeatherDegradationTransforms:
         jobs = ops.fog_jobs([0], [0.5], [self._next_seed()])
         return ops.synthetic_depth(height, width, jobs, self.device, noise)[0].cpu().numpy()
 
+    def get_fog_density_map(self, image, depth=None):
+        """preprocessing.py:250-288: (1 - contrast/p95(contrast)) * (0.3 + 0.7*depth/max(depth)),
+        clipped to [0,1].  `image` float in [0,1] (the reference quantises it with (image*255)
+        .astype(uint8), :270) or uint8; numpy in -> numpy out, device tensor in -> device tensor out."""
+        is_np = isinstance(image, np.ndarray)
+        t = torch.from_numpy(np.ascontiguousarray(image)).to(self.device) if is_np else image
+        if t.dtype != torch.uint8:
+            t = (t * 255).to(torch.uint8)                                              # truncating cast, as numpy's astype
+        h, w = t.shape[:2]
+        if depth is None:
+            depth = self._generate_synthetic_depth(h, w)
+        d = torch.as_tensor(depth).to(self.device)
+        contrast = ops.local_contrast(t.unsqueeze(0))[0]
+        p95 = torch.quantile(contrast.flatten().double(), 0.95)                        # np.percentile's linear interpolation
+        density = 1.0 - contrast.double() / (p95 + 1e-8)
+        density = density * (0.3 + 0.7 * (d.double() / d.max().double()))
+        out = density.clamp(0, 1)
+        return out.cpu().numpy() if is_np else out
+
+
     def _apply_fog(self, image, intensity=None):
         return self.apply_weather_effect(self._as_u8(image), "fog", intensity)
 

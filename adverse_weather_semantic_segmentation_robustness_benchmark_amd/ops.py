@@ -216,6 +216,16 @@ def lut3_apply(imgs: torch.Tensor, luts: torch.Tensor, lut_of: torch.Tensor, out
     return out
 
 
+def local_contrast(imgs: torch.Tensor) -> torch.Tensor:
+    """sqrt(box5((gray - box5(gray))^2)) of uint8 [B,H,W,3] frames -> float32 [B,H,W]
+    (PKG/data/preprocessing.py:270-278)."""
+    imgs = imgs.contiguous()
+    b, h, w, _ = imgs.shape
+    out = torch.empty(b, h, w, dtype=torch.float32, device=imgs.device)
+    N.call("awseg_local_contrast", N.ptr(imgs), b, h, w, N.ptr(out), N.stream())
+    return out
+
+
 def depth_estimate(imgs: torch.Tensor, out: Optional[torch.Tensor] = None, dtype=torch.float32) -> torch.Tensor:
     """DepthEstimationPreprocessor.estimate_depth (PKG/data/preprocessing.py:304-367) for a uint8
     [B,H,W,3] batch -> [B,H,W] depth target in [0,1]; float64 (reference dtype) or float32 (what

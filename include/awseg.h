@@ -182,6 +182,18 @@ int awseg_lut3_apply(const uint8_t* imgs, int batch, int height, int width,
                      uint8_t* out, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
+ *  next #4  WeatherDegradationTransforms.get_fog_density_map — local contrast
+ *       replaces PKG/data/preprocessing.py:270-278
+ * ------------------------------------------------------------------------- *
+ * imgs uint8 [batch,H,W,3] -> contrast float32 [batch,H,W] =
+ * sqrt(box5((gray - box5(gray))^2)), gray = RGB2GRAY/255 in float32, box5 = the
+ * 5x5 mean filter with BORDER_REFLECT_101.  The percentile / depth weighting of
+ * :281-288 are three reductions the caller does on the result.
+ */
+int awseg_local_contrast(const uint8_t* imgs, int batch, int height, int width,
+                         float* contrast, awseg_stream_t stream);
+
+/* ------------------------------------------------------------------------- *
  *  A2  _generate_synthetic_depth
  *       replaces PKG/data/preprocessing.py:227-248
  * ------------------------------------------------------------------------- *

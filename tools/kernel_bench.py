@@ -115,6 +115,16 @@ def main():
     xe = torch.randn(B, H // 4, W // 4, 256, device=dev); re_ = torch.randn_like(xe); b256 = torch.randn(256, device=dev)
     cases["bias_act_nhwc +res 256ch @1/4"] = (lambda: ops.bias_act_nhwc_(xe, b256, re_, 1), "hbm", 3 * 256 * 4 * (H // 4) * (W // 4) * B)
 
+    cases["depth_estimate ->f32 (f64 ladder)"] = (lambda: ops.depth_estimate(imgs, dtype=torch.float32), "hbm", (3 + 4) * px * B)
+    luts = torch.randint(0, 256, (4, 3, 256), dtype=torch.uint8, device=dev); lut_of = torch.tensor([i % 4 for i in range(B)], dtype=torch.int32, device=dev)
+    cases["style lut3 u8->u8"] = (lambda: ops.lut3_apply(imgs, luts, lut_of, out=out), "hbm", 6 * px * B)
+    cases["local_contrast (fog density map)"] = (lambda: ops.local_contrast(imgs), "hbm", (3 + 4) * px * B)
+    hist = torch.zeros(2, 8192, dtype=torch.int64, device=dev)
+    cases["ensemble eval stats (ECE + disagreement hist)"] = (
+        lambda: ops.ensemble_eval_stats(s1, s2, 0, wts, T, labels, cond, edges, bins, hist, 0.0, 3.0), "hbm", (2 * C * 4 + 1) * px * B)
+    xl = torch.randn(B * (H // 4) * (W // 4), 32, device=dev); lw = torch.randn(32, device=dev); lb = torch.randn(32, device=dev)
+    cases["layernorm_rows C=32 @1/4"] = (lambda: ops.layernorm_rows(xl, lw, lb, 1e-6), "hbm", 2 * 32 * 4 * xl.shape[0])
+
     only = [s for s in a.only.split(",") if s]
     rows = []
     for name, (fn, bound, work) in cases.items():

@@ -71,9 +71,35 @@ def nhwc_view(t: torch.Tensor) -> torch.Tensor:
     return v if v.is_contiguous() else v.contiguous()
 
 
-def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, residual: torch.Tensor = None) -> torch.Tensor:
-    """act(bn(conv(x)) [+ residual]) with x / result logically NCHW in channels_last memory."""
+def _is_pointwise(conv: nn.Conv2d) -> bool:
+    return conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+
+
+def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, residual: torch.Tensor = None,
+                residual_is_scratch: bool = False) -> torch.Tensor:
+    """act(bn(conv(x)) [+ residual]) with x / result logically NCHW in channels_last memory.
+
+    A 1x1 stride-1 convolution of an NHWC tensor IS a row-major GEMM [B*H*W, Cin] x [Cin, Cout], so
+    it goes to hipBLASLt with the epilogue doing the work of the separate passes: `+shift -> ReLU`
+    rides on the GEMM (torch._addmm_activation), and a residual is the GEMM's beta*C operand —
+    accumulated IN PLACE into the residual's buffer when the caller says it is dead afterwards
+    (`residual_is_scratch`), leaving one in-place `+shift -> ReLU` pass.  Everything else (3x3, 7x7,
+    strided 1x1) stays on MIOpen with the one-pass HIP epilogue."""
     w, shift = folded_conv_bn(conv, bn)
+    if _is_pointwise(conv) and x.is_contiguous(memory_format=CL):
+        B, Cin, H, W = x.shape
+        Cout = w.shape[0]
+        x2 = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
+        w2t = w.view(Cout, Cin).t()
+        if residual is None:
+            y2 = torch._addmm_activation(shift, x2, w2t) if act == N.ACT_RELU else torch.addmm(shift, x2, w2t)
+            if act not in (N.ACT_RELU, N.ACT_NONE):
+                ops.bias_act_nhwc_(y2, torch.zeros_like(shift), None, act)
+        else:
+            r2 = nhwc_view(residual).reshape(B * H * W, Cout)
+            y2 = r2.addmm_(x2, w2t) if residual_is_scratch else torch.addmm(r2, x2, w2t)
+            ops.bias_act_nhwc_(y2, shift, None, act)
+        return y2.view(B, H, W, Cout).permute(0, 3, 1, 2)
     y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if not y.is_contiguous(memory_format=CL):
         y = y.contiguous(memory_format=CL)
@@ -95,7 +121,9 @@ def resnet_features(enc, x: torch.Tensor) -> List[torch.Tensor]:
             out = conv_bn_act(y, blk.conv1, blk.bn1, N.ACT_RELU)
             out = conv_bn_act(out, blk.conv2, blk.bn2, N.ACT_RELU)
             idn = y if blk.downsample is None else conv_bn_act(y, blk.downsample[0], blk.downsample[1], N.ACT_NONE)
-            y = conv_bn_act(out, blk.conv3, blk.bn3, N.ACT_RELU, residual=idn)
+            # the identity is dead after this block unless it is a tensor handed out in `feats`
+            scratch = not any(idn is f for f in feats)
+            y = conv_bn_act(out, blk.conv3, blk.bn3, N.ACT_RELU, residual=idn, residual_is_scratch=scratch)
         feats.append(y)
     return feats
 

@@ -166,7 +166,10 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-depth", action="store_true", help="build the ensemble with include_depth=False")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-search", type=int, default=int(os.environ.get("AWSEG_CONV_SEARCH", "0")),
+                    help="1: let MIOpen time its solvers per convolution shape during warm-up (torch.backends.cudnn.benchmark)")
     args = ap.parse_args()
+    torch.backends.cudnn.benchmark = bool(args.conv_search)
 
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd import ops, parallel
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import EnsembleModel

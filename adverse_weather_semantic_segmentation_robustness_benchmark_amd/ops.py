@@ -404,6 +404,31 @@ def bias_act_nhwc_(x_nhwc: torch.Tensor, bias: Optional[torch.Tensor], residual:
     return x_nhwc
 
 
+def winograd_weights(weight: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[Cout,Cin,3,3] filters (times an optional per-Cout scale) -> U [16,Cin,Cout] = G g G^T,
+    computed in float64 and rounded once."""
+    g = weight.double()
+    if scale is not None:
+        g = g * scale.double().view(-1, 1, 1, 1)
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=weight.device)
+    u = torch.einsum("ik,ockl,jl->ijco", G, g, G)                      # [4,4,Cin,Cout]
+    return u.reshape(16, weight.shape[1], weight.shape[0]).float().contiguous()
+
+
+def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, shift: torch.Tensor, act: int = 0, dilation: int = 1,
+                     residual: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
+                     b2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x float32 [B,H,W,Cin] NHWC -> [B,H,W,Cout] (or [B,H,W] with the fused 1x1 + sigmoid head)."""
+    x = x.contiguous()
+    b, h, w, cin = x.shape
+    cout = u.shape[2]
+    out = torch.empty((b, h, w) if w2 is not None else (b, h, w, cout), dtype=torch.float32, device=x.device)
+    N.call("awseg_conv3x3_winograd_nhwc", N.ptr(x), b, h, w, cin, cout, dilation, N.ptr(u), N.ptr(shift.contiguous()),
+           N.ptr(None if residual is None else residual.contiguous()), act, N.ptr(None if w2 is None else w2.contiguous()),
+           N.ptr(None if b2 is None else b2.contiguous()), N.ptr(out), N.stream())
+    return out
+
+
 def layernorm_rows(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     """torch.nn.functional.layer_norm over the last dimension for small channel counts (MiT tokens)."""
     x = x.contiguous()

@@ -399,6 +399,21 @@ int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int chann
 int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, int width, int channels, int dilation,
                          const float* w9, const float* bias, int act, float* out, awseg_stream_t stream);
 
+/* awseg_conv3x3_winograd_nhwc: 3x3, stride 1, dilation d, zero padding d convolution of float32
+ * [B,H,W,Cin] -> [B,H,W,Cout] as Winograd F(2x2,3x3) on the fp32 matrix cores, with the eval-mode
+ * BatchNorm folded in.  u: device float32 [16][Cin][Cout] = (G g G^T) of the (scale-folded) 3x3
+ * filters, position-major; shift float32 [Cout].  Cin % 16 == 0, Cout % 64 == 0.
+ *   w2 == NULL: out[b,y,x,n] = act(conv + shift[n] (+ residual[b,y,x,n])), act 0 none / 1 ReLU;
+ *   w2 != NULL (Cout == 64, residual NULL): the whole tail of DepthEstimationHead
+ *       (PKG/models/model.py:47-51: Conv3x3 -> BN -> ReLU -> Conv1x1 -> Sigmoid) in one launch:
+ *       out[b,y,x] = sigmoid(b2[0] + sum_n w2[n] * relu(conv + shift[n])), float32 [B,H,W].
+ * Replaces the depth-head 3x3s at PKG/models/model.py:42-52 (called from :219-221, :358-371) and
+ * the 3x3 convolutions of the ResNet-50 bottlenecks behind :349 in the eval forward.
+ * Result differs from a direct fp32 convolution by the Winograd transforms' rounding (~1e-6 rel). */
+int awseg_conv3x3_winograd_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
+                                const float* u, const float* shift, const float* residual, int act,
+                                const float* w2, const float* b2, float* out, awseg_stream_t stream);
+
 /* awseg_bias_act_nhwc: x = act(x + bias[c] (+ residual)) in place on float32 [n_pixels, C]:
  * the epilogue of a convolution whose eval-mode BatchNorm scale was folded into its weights
  * (Conv -> BN -> [+identity] -> ReLU of the ResNet bottlenecks behind PKG/models/model.py:349). */

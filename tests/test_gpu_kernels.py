@@ -382,6 +382,45 @@ def test_segformer_head_fused_golden(ops, golden_model):
     assert np.abs(out.cpu().numpy() - g["head_out"]).max() < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 36, 32, 64, 1), (1, 16, 16, 16, 64, 1), (2, 37, 29, 64, 128, 1), (1, 24, 40, 48, 64, 2),
+                                   (1, 33, 47, 32, 128, 2), (1, 50, 34, 16, 64, 3)])
+def test_conv3x3_winograd_matches_direct(ops, shape):
+    """Winograd F(2x2,3x3) MFMA convolution vs torch's direct conv (fp64 reference): bias, ReLU,
+    residual, dilation, ragged edges.  Tolerance 1e-4 abs on O(1) outputs (transform rounding)."""
+    B, H, W, Cin, Cout, d = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    wt = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (3.0 * Cin ** 0.5)
+    scale = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    shift = torch.randn(Cout, device="cuda", generator=g)
+    res = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+    u = ops.winograd_weights(wt, scale)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), (wt * scale.view(-1, 1, 1, 1)).double(), None, 1, d, d)
+    ref = ref.permute(0, 2, 3, 1) + shift.double()
+    got = ops.conv3x3_winograd(x, u, shift, act=0, dilation=d)
+    assert (got.double() - ref).abs().max().item() < 1e-4
+    got = ops.conv3x3_winograd(x, u, shift, act=1, dilation=d, residual=res)
+    assert (got.double() - (ref + res.double()).clamp_min(0)).abs().max().item() < 1e-4
+    if Cout == 64:
+        w2 = torch.randn(64, device="cuda", generator=g) * 0.2
+        b2 = torch.randn(1, device="cuda", generator=g)
+        got = ops.conv3x3_winograd(x, u, shift, dilation=d, w2=w2, b2=b2)
+        want = torch.sigmoid((ref.clamp_min(0) * w2.double()).sum(-1) + b2.double())
+        assert got.shape == (B, H, W) and (got.double() - want).abs().max().item() < 1e-5
+
+
+def test_conv3x3_winograd_abi_checks(ops, native):
+    N = native
+    x = torch.zeros(1, 8, 8, 16, device="cuda"); u = torch.zeros(16, 16, 64, device="cuda"); sh = torch.zeros(64, device="cuda")
+    with pytest.raises(N.AwsegError):
+        ops.conv3x3_winograd(torch.zeros(1, 8, 8, 8, device="cuda"), torch.zeros(16, 8, 64, device="cuda"), sh)      # Cin % 16
+    with pytest.raises(N.AwsegError):
+        ops.conv3x3_winograd(x, torch.zeros(16, 16, 32, device="cuda"), sh[:32])                                        # Cout % 64
+    with pytest.raises(N.AwsegError):
+        ops.conv3x3_winograd(x, u, sh, w2=torch.zeros(64, device="cuda"))                                               # w2 without b2
+    assert ops.conv3x3_winograd(x[:0], u, sh).shape == (0, 8, 8, 64)
+
+
 def test_aspp_depthwise3(ops):
     torch.manual_seed(0)
     B, h, w, Cc = 2, 20, 28, 16

@@ -125,6 +125,21 @@ def main():
     xl = torch.randn(B * (H // 4) * (W // 4), 32, device=dev); lw = torch.randn(32, device=dev); lb = torch.randn(32, device=dev)
     cases["layernorm_rows C=32 @1/4"] = (lambda: ops.layernorm_rows(xl, lw, lb, 1e-6), "hbm", 2 * 32 * 4 * xl.shape[0])
 
+    # Winograd F(2x2,3x3): MFMA flops actually issued = 16 multiplies per 2x2 outputs (2.25x fewer than direct)
+    def wino_case(name, b, hh, ww, cin, cout, dil, head):
+        xw = torch.randn(b, hh, ww, cin, device=dev)
+        u = ops.winograd_weights(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
+        shw = torch.randn(cout, device=dev)
+        w2w = torch.randn(64, device=dev) if head else None
+        b2w = torch.zeros(1, device=dev) if head else None
+        fl = 2.0 * 16 * cin * cout * b * ((hh + 1) // 2) * ((ww + 1) // 2)
+        cases[name] = (lambda: ops.conv3x3_winograd(xw, u, shw, act=1, dilation=dil, w2=w2w, b2=b2w), "mfma", fl)
+    wino_case("winograd 128->64 +1x1+sigmoid @full (segformer depth)", B, H, W, 128, 64, 1, True)
+    wino_case("winograd 64->64 @1/4 (resnet l1)", B, H // 4, W // 4, 64, 64, 1, False)
+    wino_case("winograd 256->256 @1/16 (resnet l3)", B, H // 16, W // 16, 256, 256, 1, False)
+    wino_case("winograd 512->512 d2 @1/16 (resnet l4)", B, H // 16, W // 16, 512, 512, 2, False)
+    wino_case("winograd 2048->256 @1/16 (deeplab depth)", B, H // 16, W // 16, 2048, 256, 1, False)
+
     only = [s for s in a.only.split(",") if s]
     rows = []
     for name, (fn, bound, work) in cases.items():

@@ -71,6 +71,27 @@ def nhwc_view(t: torch.Tensor) -> torch.Tensor:
     return v if v.is_contiguous() else v.contiguous()
 
 
+WINOGRAD_MIN_CIN = 128     # below this the direct MIOpen kernel is as fast (tools/kernel_bench.py, 64->64 @1/4)
+
+
+def _is_winograd(conv: nn.Conv2d) -> bool:
+    return (conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.groups == 1 and conv.padding == conv.dilation
+            and conv.dilation[0] == conv.dilation[1] and conv.in_channels % 16 == 0 and conv.out_channels % 64 == 0
+            and conv.in_channels >= WINOGRAD_MIN_CIN)
+
+
+def winograd_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """(U [16,Cin,Cout] = G (w * bn_scale) G^T, shift) for eval-mode Conv3x3 -> BN; cached like folded_conv_bn."""
+    def build():
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        scale = bn.weight * inv
+        shift = bn.bias - bn.running_mean * scale
+        if conv.bias is not None:
+            shift = shift + conv.bias * scale
+        return ops.winograd_weights(conv.weight, scale), shift.contiguous()
+    return cached(conv, "wino", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+
+
 def _is_pointwise(conv: nn.Conv2d) -> bool:
     return conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
 
@@ -100,6 +121,12 @@ def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, 
             y2 = r2.addmm_(x2, w2t) if residual_is_scratch else torch.addmm(r2, x2, w2t)
             ops.bias_act_nhwc_(y2, shift, None, act)
         return y2.view(B, H, W, Cout).permute(0, 3, 1, 2)
+    if _is_winograd(conv) and act in (N.ACT_NONE, N.ACT_RELU):
+        # 3x3 stride-1 "same" convolution: Winograd F(2x2,3x3) on the fp32 matrix cores, epilogue fused
+        u, shift = winograd_conv_bn(conv, bn)
+        y = ops.conv3x3_winograd(nhwc_view(x), u, shift, act=act, dilation=conv.dilation[0],
+                                 residual=None if residual is None else nhwc_view(residual))
+        return y.permute(0, 3, 1, 2)
     y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if not y.is_contiguous(memory_format=CL):
         y = y.contiguous(memory_format=CL)

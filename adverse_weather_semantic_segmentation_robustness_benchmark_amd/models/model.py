@@ -109,7 +109,12 @@ class DepthEstimationHead(nn.Module):
         the first 3x3: that conv goes through the same linearity trick as the seg head (HIP), the
         rest (3x3 on the hidden map, 1x1, sigmoid) stays on MIOpen."""
         h = self.depth_head
-        mid = upconv3x3_bn_relu(feats, h[0], h[1], height, width)            # [B,hidden,H,W]
+        mid = upconv3x3_bn_relu(feats, h[0], h[1], height, width)            # [B,hidden,H,W], channels_last memory
+        if fused._is_winograd(h[4]) and h[4].out_channels == 64 and h[7].kernel_size == (1, 1):
+            # Conv3x3 -> BN -> ReLU -> Conv1x1 -> Sigmoid in one Winograd/MFMA launch (no 64-channel map in HBM)
+            u, shift = fused.winograd_conv_bn(h[4], h[5])
+            d = ops.conv3x3_winograd(fused.nhwc_view(mid), u, shift, w2=h[7].weight.view(-1), b2=h[7].bias)
+            return d.unsqueeze(1)
         y = fused.conv_bn_act(mid, h[4], h[5], N.ACT_RELU)
         return torch.sigmoid(h[7](y)).contiguous()
 

@@ -31,9 +31,11 @@ constexpr int NB = 64;             // output channels per block
 constexpr int V_FLOATS = 16 * KC * NTILE;   // 32 KB per buffer
 constexpr int U_FLOATS = 16 * KC * NB;      // 32 KB per buffer
 constexpr int PW = 2 * TB + 2;                // 18 x 18 input pixels feed the block's 8 x 8 tiles
-constexpr int P_UNITS = 11 * 64;              // 16-byte units per patch buffer: 18*18 px x (KC*4/16) = 648, rounded up to whole wave instructions
-constexpr int P_FLOATS = P_UNITS * 4;         // 11 KB per buffer
-constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * U_FLOATS + 2 * P_FLOATS;   // 150 KB: operands and the raw patch double-buffered
+constexpr int PRS = 24;                       // patch row stride in 16-byte slots (18 used)
+constexpr int PH1 = 440;                      // slot offset of the second channel quad (== 8 mod 16: see patch layout)
+constexpr int P_UNITS = 14 * 64;              // slots per patch buffer (440 + 18*24 = 872, whole wave instructions)
+constexpr int P_FLOATS = P_UNITS * 4;         // 14 KB per buffer
+constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * P_FLOATS;   // 92 KB: transformed input and the raw patch, double-buffered
 
 struct wino_args {
     const float* x; const float* U; const float* shift; const float* residual; const float* w2; const float* b2;
@@ -47,25 +49,56 @@ __device__ __forceinline__ float act_apply(float v, int act)
     return v;
 }
 
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): lane l's bytes land at lds_base + 16*l.
+// Issued through inline asm on purpose: the builtin makes hipcc treat every later ds_read as possibly
+// aliasing the DMA's LDS write and wait vmcnt(0) right after the first MFMA of a step, which
+// serialises the copy with the math.  The kernel orders the copy itself: glds_wait() before the
+// barrier that ends the step in which the copy was issued.
+__device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "m0");
+}
+__device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+// the four youngest vector-memory operations (the next chunk's first weight fragments, issued after
+// the step's LDS-DMAs) may stay in flight across the barrier
+__device__ __forceinline__ void glds_wait_keep4() { asm volatile("s_waitcnt vmcnt(4)" : : : "memory"); }
+__device__ __forceinline__ uint32_t lds_addr(const float* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
 __device__ __forceinline__ float2 f2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 f2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
-// V = B^T d B of one (tile, channel pair) in two stages so the work can be spread between the MFMA
-// groups of a step: rows first (t = B^T d, pixels outside the image masked to zero), then one output
-// row i of (t B) -> positions 4i..4i+3, written as sV[p][2*pair + comp][tile'] where odd channel
-// rows are rotated by 32 tiles: an MFMA A-fragment read takes rows k and k+1 in the two wave halves,
-// and the rotation puts them on disjoint LDS banks.
-__device__ __forceinline__ void xform_rows(const float* __restrict__ patch, uint32_t mask, float2 (&t)[16])
+// LDS images.  Operands: sV[p][hk][tile][s], sU[p][hk][cout][s]: k-step s pairs the chunk's input
+// channels c(s,0), c(s,1) with c(s,hk) = 4*(s>>1) + 2*hk + (s&1) (lane l of the 32x32x2 MFMA takes
+// half hk = l>>5), so a lane's four k-steps of one position are ONE conflict-free ds_read_b128 and
+// a transform thread's two channels are adjacent in memory.  Raw patch: 16-byte slots (4 channels of one
+// pixel), slot = quad*PH1 + py*PRS + (px ^ ((py>>1)&1)): the column flip on every other row pair and
+// PH1 == 8 (mod 16) make the 16 lanes of every ds_read_b128 lane group land on 16 distinct slots.
+//
+// V = B^T d B of one (tile, 2 adjacent channels) in two stages so the work can ride between the MFMA groups
+// of a step: rows first (t = B^T d, pixels outside the image masked to zero), then one output row i
+// of (t B) -> positions 4i..4i+3, stored as float2 (k-steps 2*cp, 2*cp+1 of half hk).
+struct patch_ptrs { const float* e_lo; const float* o_lo; const float* e_hi; const float* o_hi; };
+
+__device__ __forceinline__ void patch_read(const patch_ptrs& pp, float2 (&r)[16])
 {
-    float2 r[16];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float2 v = *reinterpret_cast<const float2*>(patch + (i * PW + j) * KC);
-            const bool ok = (mask >> (i * 4 + j)) & 1u;
-            r[i * 4 + j] = make_float2(ok ? v.x : 0.f, ok ? v.y : 0.f);
+            const float* base = i < 2 ? ((j & 1) ? pp.o_lo : pp.e_lo) : ((j & 1) ? pp.o_hi : pp.e_hi);
+            r[i * 4 + j] = *reinterpret_cast<const float2*>(base + (i * PRS + j) * 4);
         }
+}
+__device__ __forceinline__ void xform_rows(float2 (&r)[16], uint32_t mask, float2 (&t)[16])
+{
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const bool ok = (mask >> q) & 1u;
+        r[q] = make_float2(ok ? r[q].x : 0.f, ok ? r[q].y : 0.f);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         t[0 * 4 + j] = f2sub(r[0 * 4 + j], r[2 * 4 + j]);
@@ -74,7 +107,7 @@ __device__ __forceinline__ void xform_rows(const float* __restrict__ patch, uint
         t[3 * 4 + j] = f2sub(r[1 * 4 + j], r[3 * 4 + j]);
     }
 }
-__device__ __forceinline__ void xform_cols_store(const float2 (&t)[16], int i, float* __restrict__ d0, float* __restrict__ d1)
+__device__ __forceinline__ void xform_cols_store(const float2 (&t)[16], int i, float* __restrict__ d)
 {
     float2 v[4];
     v[0] = f2sub(t[i * 4 + 0], t[i * 4 + 2]);
@@ -82,10 +115,7 @@ __device__ __forceinline__ void xform_cols_store(const float2 (&t)[16], int i, f
     v[2] = f2sub(t[i * 4 + 2], t[i * 4 + 1]);
     v[3] = f2sub(t[i * 4 + 1], t[i * 4 + 3]);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        d0[(i * 4 + j) * KC * NTILE] = v[j].x;
-        d1[(i * 4 + j) * KC * NTILE] = v[j].y;
-    }
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(d + (i * 4 + j) * (KC * NTILE)) = v[j];
 }
 
 template <int MODE>   // 0 FULL, 1 HEAD1
@@ -94,7 +124,6 @@ void conv3x3_wino_kernel(wino_args a)
 {
     extern __shared__ float smem[];
     float* sV = smem;                        // [2][16][KC][NTILE]
-    float* sU = smem + 2 * V_FLOATS;         // [2][16][KC][NB]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int bx = blockIdx.x % a.nbx, rx = blockIdx.x / a.nbx;
     const int by = blockIdx.y % a.nby, ry = blockIdx.y / a.nby;
@@ -105,64 +134,56 @@ void conv3x3_wino_kernel(wino_args a)
     const int n0 = ng * NB;
     const int nchunks = a.Cin / KC;          // even (Cin % 16 == 0)
 
-    float* sP = smem + 2 * V_FLOATS + 2 * U_FLOATS;   // [2][18*18 px][KC] raw input patch of a chunk
+    float* sP = smem + 2 * V_FLOATS;         // [2][P_UNITS] raw input patch of a chunk
     // ---- raw patch: the 18 x 18 pixels x KC channels the block's tiles are cut from, LDS-DMA'd in
-    // 16-byte units (2 per pixel), unit q = (py*18 + px)*2 + half -> LDS slot q (lane-linear).  Fetching
-    // every pixel once (instead of once per overlapping tile and channel pair straight into registers)
-    // is what keeps the texture-address path off the critical path: a scattered per-lane load costs it
-    // one request per lane.  Pixels outside the image fetch a clamped address; the mask zeroes them.
-    uint32_t punit[3];
+    // 16-byte units.  Fetching every pixel once (instead of once per overlapping tile straight into
+    // registers) keeps the texture-address path off the critical path: a scattered per-lane load costs
+    // it one request per lane.  Pixels outside the image fetch a clamped address; the mask zeroes them.
+    uint32_t punit[4];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        int q = (wave + 4 * i) * 64 + lane;
-        if (q >= PW * PW * 2) q = PW * PW * 2 - 1;                 // tail lanes of the 11th instruction re-fetch the last unit
-        const int pix = q >> 1, py = pix / PW, px = pix - py * PW;
+    for (int i = 0; i < 4; ++i) {
+        const int q = (wave + 4 * i) * 64 + lane;                   // destination slot
+        const int h = q >= PH1 ? 1 : 0, r = q - h * PH1;
+        int py = r / PRS, pxs = r - py * PRS;
+        if (py >= PW) py = PW - 1;                                  // padding slots re-fetch a valid pixel
+        if (pxs >= PW) pxs = PW - 1;
+        const int px = pxs ^ ((py >> 1) & 1);
         const int sy = by * 2 * TB - 1 + py, sx = bx * 2 * TB - 1 + px;
         int y = ry + a.dil * sy, x = rx + a.dil * sx;
         const bool ok = sy >= 0 && sx >= 0 && y < a.H && x < a.W;
         y = ok ? y : 0; x = ok ? x : 0;
-        punit[i] = (uint32_t)((y * a.W + x) * a.Cin + (q & 1) * 4);
+        punit[i] = (uint32_t)((y * a.W + x) * a.Cin + h * 4);
     }
-    const int n_pinstr = wave < 3 ? 3 : 2;                          // 11 wave instructions over 4 waves
+    const int n_pinstr = wave < 2 ? 4 : 3;                          // 14 wave instructions over 4 waves
     auto glds_patch = [&](int chunk, float* dstbuf) {
         const float* base = xb + (chunk < nchunks ? chunk : nchunks - 1) * KC;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            if (i < n_pinstr)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + punit[i]),
-                                                 (__attribute__((address_space(3))) void*)(dstbuf + (wave + 4 * i) * 256), 16, 0, 0);
-    };
-    // transform item of this thread: tile = lane, channel pair = wave; validity of its 4 x 4 pixels
-    uint32_t pmask = 0;
-    {
-        const int uy0 = by * 2 * TB + 2 * (lane >> 3), ux0 = bx * 2 * TB + 2 * (lane & 7);
-#pragma unroll
         for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int sy = uy0 - 1 + i, sx = ux0 - 1 + j;
-                const bool ok = sy >= 0 && sx >= 0 && ry + a.dil * sy < a.H && rx + a.dil * sx < a.W;
-                pmask |= (ok ? 1u : 0u) << (i * 4 + j);
-            }
-    }
-    const int poff = ((2 * (lane >> 3)) * PW + 2 * (lane & 7)) * KC + wave * 2;   // this tile's top-left pixel, this pair
-    // ---- weight chunk: 128 rows (p, k) x 64 couts, LDS-DMA'd 4 rows (1 KiB) per wave instruction,
-    // 8 instructions per wave.  Odd-k rows are stored rotated by 32 couts (see xform_cols_store):
-    // the LDS image is lane-linear, so the rotation goes on the per-lane SOURCE address.
-    uint32_t uoff[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int row = (wave * 8 + i) * 4 + (lane >> 4);      // p * KC + k
-        const int p = row >> 3, k = row & 7;
-        uoff[i] = (uint32_t)((p * a.Cin + k) * a.Cout + n0 + 4 * ((lane & 15) ^ ((k & 1) << 3)));
-    }
-    auto glds_u = [&](int chunk, float* dstbuf) {
-        const float* base = a.U + (int64_t)(chunk < nchunks ? chunk : nchunks - 1) * KC * a.Cout;
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + uoff[i]),
-                                             (__attribute__((address_space(3))) void*)(dstbuf + (wave * 8 + i) * 256), 16, 0, 0);
+            if (i < n_pinstr) glds16(base + punit[i], __builtin_amdgcn_readfirstlane(lds_addr(dstbuf + (wave + 4 * i) * 256)));
     };
+    // transform item of this thread: half hk = wave & 1 (channels 4*cp + 2*hk, +1 = k-steps 2cp, 2cp+1), tile =
+    // 32*(wave>>1) + lane/2, cp = lane & 1; validity of its 4 x 4 pixels
+    const int xhk = wave & 1, xcp = lane & 1, xtile = (wave >> 1) * 32 + (lane >> 1);
+    const int xty = xtile >> 3, xtx = xtile & 7;
+    uint32_t pmask = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int sy = by * 2 * TB + 2 * xty - 1 + i, sx = bx * 2 * TB + 2 * xtx - 1 + j;
+            const bool ok = sy >= 0 && sx >= 0 && ry + a.dil * sy < a.H && rx + a.dil * sx < a.W;
+            pmask |= (ok ? 1u : 0u) << (i * 4 + j);
+        }
+    const int xf0 = xty & 1, xf1 = xf0 ^ 1;
+    const int pbase = (xcp * PH1 + 2 * xty * PRS + 2 * xtx) * 4 + 2 * xhk;
+    const int pe_lo = pbase + xf0 * 4, po_lo = pbase - xf0 * 4, pe_hi = pbase + xf1 * 4, po_hi = pbase - xf1 * 4;
+    const int vdoff = xhk * (4 * NTILE) + xtile * 4 + 2 * xcp;     // sV[p][hk][tile][2cp..2cp+1]
+    // ---- weights: the host lays U out as the B fragments, [chunk][p][hk][cout][s]: a lane's four
+    // k-steps of one position are 16 contiguous bytes, a wave's two halves read two 512-byte runs.
+    // They go straight from L2 to registers one position group ahead of their MFMAs (an LDS-DMA
+    // stage for them cost more issue time than it saved: ~130 cycles per 1 KiB instruction).
+    const float* ub = a.U + (size_t)((lane >> 5) * a.Cout + n0 + (wave & 1) * 32 + (lane & 31)) * 4;
+    const size_t u_pos = (size_t)2 * a.Cout * 4, u_chunk = (size_t)32 * a.Cout * 4;
 
     f32x16 acc[16];
 #pragma unroll
@@ -171,19 +192,19 @@ void conv3x3_wino_kernel(wino_args a)
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     const int mt = wave >> 1, nt = wave & 1, hk = lane >> 5, li = lane & 31;
-    const int aoff = hk * NTILE + ((mt * 32 + li) ^ (hk << 5));
-    const int boff = hk * NB + ((nt * 32 + li) ^ (hk << 5));
-    const int d0off = (wave * 2) * NTILE + lane, d1off = (wave * 2 + 1) * NTILE + (lane ^ 32);
+    const int aoff = hk * (4 * NTILE) + (mt * 32 + li) * 4;
 
-    glds_u(0, sU);
     glds_patch(0, sP);
     glds_patch(1, sP + P_FLOATS);
+    glds_wait();
     __syncthreads();
     {
-        float2 t[16];
-        xform_rows(sP + poff, pmask, t);
+        float2 r[16], t[16];
+        const patch_ptrs pp = {sP + pe_lo, sP + po_lo, sP + pe_hi, sP + po_hi};
+        patch_read(pp, r);
+        xform_rows(r, pmask, t);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) xform_cols_store(t, i, sV + d0off, sV + d1off);
+        for (int i = 0; i < 4; ++i) xform_cols_store(t, i, sV + vdoff);
     }
     __syncthreads();
 
@@ -191,53 +212,93 @@ void conv3x3_wino_kernel(wino_args a)
     // its patch (landed during the previous step) is transformed into V[BUF^1], its weights are
     // LDS-DMA'd into U[BUF^1], and the patch buffer the previous step's transform freed is refilled
     // with chunk c+2.  No conditionals: past the end the loads re-read the last chunk into buffers
-    // nobody consumes.  The four k-steps are software-pipelined by hand (operands of k-step s+1 are
-    // read while the MFMAs of s issue; a quarter of the transform rides in each group).
-#define WINO_LOAD_OPS(S, AV, BV)                                                               \
-    _Pragma("unroll") for (int p = 0; p < 16; ++p) {                                           \
-        AV[p] = pa[(p * KC + 2 * (S)) * NTILE];                                                \
-        BV[p] = pb[(p * KC + 2 * (S)) * NB];                                                   \
+    // nobody consumes.  The step is software-pipelined by hand in four groups of four positions
+    // (operands of group g+1 are read while the MFMAs of g issue; a quarter of the transform rides
+    // in each group).
+#define WINO_LOAD_A(G, AV)                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        AV[q] = *reinterpret_cast<const float4*>(pa + (4 * (G) + q) * (KC * NTILE));
+#define WINO_LOAD_B(UP, G, BV)                                                                 \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        BV[q] = *reinterpret_cast<const float4*>((UP) + (4 * (G) + q) * u_pos);
+#define WINO_MFMAS(G, AV, BV)                                                                  \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        acc[4 * (G) + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].x, BV[q].x, acc[4 * (G) + q], 0, 0, 0); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        acc[4 * (G) + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].y, BV[q].y, acc[4 * (G) + q], 0, 0, 0); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        acc[4 * (G) + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].z, BV[q].z, acc[4 * (G) + q], 0, 0, 0); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
+        acc[4 * (G) + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].w, BV[q].w, acc[4 * (G) + q], 0, 0, 0);
+    // Instruction-mix recipes for the scheduler: each MFMA is followed by a few of the companion
+    // instructions of its group, so staging work issues in the shadow of the 64-cycle MFMAs instead of
+    // in a clump that leaves the matrix core idle.  (mask 0x008 MFMA, 0x002 VALU, 0x020 VMEM read,
+    // 0x100 DS read, 0x200 DS write)
+#define WINO_MIX(NVALU, NVMEM, NDSR, NDSW)                                                     \
+    _Pragma("unroll") for (int m = 0; m < 16; ++m) {                                           \
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                     \
+        if (NVMEM) __builtin_amdgcn_sched_group_barrier(0x020, NVMEM, 0);                      \
+        if (NDSR) __builtin_amdgcn_sched_group_barrier(0x100, NDSR, 0);                        \
+        if (NVALU) __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);                      \
+        if (NDSW) __builtin_amdgcn_sched_group_barrier(0x200, NDSW, 0);                        \
     }
-#define WINO_MFMAS(AV, BV)                                                                     \
-    _Pragma("unroll") for (int p = 0; p < 16; ++p)                                             \
-        acc[p] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[p], BV[p], acc[p], 0, 0, 0);
+    // B0 enters holding the weights of (chunk C, group 0) and leaves holding those of (C+1, group 0).
 #define WINO_STEP(C, BUF)                                                                      \
     do {                                                                                       \
         const float* pa = sV + (BUF) * V_FLOATS + aoff;                                        \
-        const float* pb = sU + (BUF) * U_FLOATS + boff;                                        \
-        float* vd0 = sV + ((BUF) ^ 1) * V_FLOATS + d0off;                                      \
-        float* vd1 = sV + ((BUF) ^ 1) * V_FLOATS + d1off;                                      \
-        float a0[16], b0[16], a1[16], b1[16];                                                  \
-        float2 t[16];                                                                          \
-        WINO_LOAD_OPS(0, a0, b0)                                                               \
+        float* vd = sV + ((BUF) ^ 1) * V_FLOATS + vdoff;                                       \
+        const float* pn = sP + ((BUF) ^ 1) * P_FLOATS;                                         \
+        const patch_ptrs pp = {pn + pe_lo, pn + po_lo, pn + pe_hi, pn + po_hi};                \
+        const float* uc = ub + (size_t)(C) * u_chunk;                                          \
+        const float* un = ub + (size_t)((C) + 1 < nchunks ? (C) + 1 : (C)) * u_chunk;          \
+        float4 a0[4], a1[4];                                                                   \
+        float2 r[16], t[16];                                                                   \
+        WINO_LOAD_A(0, a0)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                     \
-        glds_u((C) + 1, sU + ((BUF) ^ 1) * U_FLOATS);                                          \
+        /* group 0: MFMAs + LDS-DMA issue + operands of group 1 + raw patch reads */            \
         glds_patch((C) + 2, sP + (BUF) * P_FLOATS);                                            \
-        xform_rows(sP + ((BUF) ^ 1) * P_FLOATS + poff, pmask, t);                              \
-        WINO_LOAD_OPS(1, a1, b1)                                                               \
-        xform_cols_store(t, 0, vd0, vd1);                                                      \
-        WINO_MFMAS(a0, b0)                                                                     \
+        WINO_LOAD_B(uc, 1, b1)                                                                 \
+        WINO_LOAD_A(1, a1)                                                                     \
+        patch_read(pp, r);                                                                     \
+        WINO_MFMAS(0, a0, b0)                                                                  \
+        WINO_MIX(2, 1, 2, 0)                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                     \
-        WINO_LOAD_OPS(2, a0, b0)                                                               \
-        xform_cols_store(t, 1, vd0, vd1);                                                      \
-        WINO_MFMAS(a1, b1)                                                                     \
+        /* group 1: MFMAs + row transform + operands of group 2 */                              \
+        xform_rows(r, pmask, t);                                                               \
+        WINO_LOAD_B(uc, 2, b0)                                                                 \
+        WINO_LOAD_A(2, a0)                                                                     \
+        WINO_MFMAS(1, a1, b1)                                                                  \
+        WINO_MIX(4, 1, 1, 0)                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                     \
-        WINO_LOAD_OPS(3, a1, b1)                                                               \
-        xform_cols_store(t, 2, vd0, vd1);                                                      \
-        WINO_MFMAS(a0, b0)                                                                     \
+        /* group 2: MFMAs + half of the column transform + operands of group 3 */               \
+        xform_cols_store(t, 0, vd);                                                            \
+        xform_cols_store(t, 1, vd);                                                            \
+        WINO_LOAD_B(uc, 3, b1)                                                                 \
+        WINO_LOAD_A(3, a1)                                                                     \
+        WINO_MFMAS(2, a0, b0)                                                                  \
+        WINO_MIX(2, 1, 1, 1)                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                     \
-        xform_cols_store(t, 3, vd0, vd1);                                                      \
-        WINO_MFMAS(a1, b1)                                                                     \
+        /* group 3: MFMAs + the other half of the column transform + next chunk's first weights */ \
+        xform_cols_store(t, 2, vd);                                                            \
+        xform_cols_store(t, 3, vd);                                                            \
+        WINO_LOAD_B(un, 0, b0)                                                                 \
+        WINO_MFMAS(3, a1, b1)                                                                  \
+        WINO_MIX(2, 1, 0, 1)                                                                   \
+        glds_wait_keep4();                                                                     \
         __syncthreads();                                                                       \
     } while (0)
+    float4 b0[4], b1[4];
+    WINO_LOAD_B(ub, 0, b0)
     static_assert(KC == 8, "the step below is written for four k-steps per chunk");
     for (int c = 0; c < nchunks; c += 2) {
         WINO_STEP(c, 0);
         WINO_STEP(c + 1, 1);
     }
-#undef WINO_LOAD_OPS
+#undef WINO_LOAD_A
+#undef WINO_LOAD_B
 #undef WINO_MFMAS
 #undef WINO_STEP
+#undef WINO_MIX
 
     // ---- output transform + epilogue.  acc[p][r]: tile row (r&3) + 8*(r>>2) + 4*hk of m-tile mt, cout li of n-tile nt
     const int n = n0 + nt * 32 + li;

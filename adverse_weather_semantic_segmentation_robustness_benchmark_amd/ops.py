@@ -405,14 +405,17 @@ def bias_act_nhwc_(x_nhwc: torch.Tensor, bias: Optional[torch.Tensor], residual:
 
 
 def winograd_weights(weight: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """[Cout,Cin,3,3] filters (times an optional per-Cout scale) -> U [16,Cin,Cout] = G g G^T,
-    computed in float64 and rounded once."""
+    """[Cout,Cin,3,3] filters (times an optional per-Cout scale) -> U = G g G^T in the kernel's LDS
+    image order [Cin/8][16 positions][2][Cout][4]: input channel 8*chunk + 4*(s>>1) + 2*hk + (s&1) at
+    [chunk][p][hk][n][s] (include/awseg.h), computed in float64 and rounded once.  Cin % 16 == 0."""
     g = weight.double()
     if scale is not None:
         g = g * scale.double().view(-1, 1, 1, 1)
+    cout, cin = weight.shape[0], weight.shape[1]
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=weight.device)
-    u = torch.einsum("ik,ockl,jl->ijco", G, g, G)                      # [4,4,Cin,Cout]
-    return u.reshape(16, weight.shape[1], weight.shape[0]).float().contiguous()
+    # channel within a chunk = 4*s_hi + 2*hk + s_lo with s = 2*s_hi + s_lo
+    u = torch.einsum("ik,ockl,jl->ijco", G, g, G).reshape(16, cin // 8, 2, 2, 2, cout)   # [p][chunk][s_hi][hk][s_lo][n]
+    return u.permute(1, 0, 3, 5, 2, 4).reshape(cin // 8, 16, 2, cout, 4).float().contiguous()   # [chunk][p][hk][n][s]
 
 
 def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, shift: torch.Tensor, act: int = 0, dilation: int = 1,
@@ -421,7 +424,7 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, shift: torch.Tensor, act:
     """x float32 [B,H,W,Cin] NHWC -> [B,H,W,Cout] (or [B,H,W] with the fused 1x1 + sigmoid head)."""
     x = x.contiguous()
     b, h, w, cin = x.shape
-    cout = u.shape[2]
+    cout = u.shape[3]
     out = torch.empty((b, h, w) if w2 is not None else (b, h, w, cout), dtype=torch.float32, device=x.device)
     N.call("awseg_conv3x3_winograd_nhwc", N.ptr(x), b, h, w, cin, cout, dilation, N.ptr(u), N.ptr(shift.contiguous()),
            N.ptr(None if residual is None else residual.contiguous()), act, N.ptr(None if w2 is None else w2.contiguous()),

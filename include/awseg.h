@@ -401,8 +401,9 @@ int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, int width, i
 
 /* awseg_conv3x3_winograd_nhwc: 3x3, stride 1, dilation d, zero padding d convolution of float32
  * [B,H,W,Cin] -> [B,H,W,Cout] as Winograd F(2x2,3x3) on the fp32 matrix cores, with the eval-mode
- * BatchNorm folded in.  u: device float32 [16][Cin][Cout] = (G g G^T) of the (scale-folded) 3x3
- * filters, position-major; shift float32 [Cout].  Cin % 16 == 0, Cout % 64 == 0.
+ * BatchNorm folded in.  u: device float32 [Cin/8][16][2][Cout][4] = (G g G^T) of the (scale-folded) 3x3
+ * filters in the kernel's LDS image order: position p = 4i+j of input channel 8*chunk + 4*(s>>1) + 2*hk + (s&1) at
+ * [chunk][p][hk][cout][s]; shift float32 [Cout].  Cin % 16 == 0, Cout % 64 == 0.
  *   w2 == NULL: out[b,y,x,n] = act(conv + shift[n] (+ residual[b,y,x,n])), act 0 none / 1 ReLU;
  *   w2 != NULL (Cout == 64, residual NULL): the whole tail of DepthEstimationHead
  *       (PKG/models/model.py:47-51: Conv3x3 -> BN -> ReLU -> Conv1x1 -> Sigmoid) in one launch:

@@ -411,11 +411,11 @@ def test_conv3x3_winograd_matches_direct(ops, shape):
 
 def test_conv3x3_winograd_abi_checks(ops, native):
     N = native
-    x = torch.zeros(1, 8, 8, 16, device="cuda"); u = torch.zeros(16, 16, 64, device="cuda"); sh = torch.zeros(64, device="cuda")
+    x = torch.zeros(1, 8, 8, 16, device="cuda"); u = torch.zeros(2, 16, 2, 64, 4, device="cuda"); sh = torch.zeros(64, device="cuda")
     with pytest.raises(N.AwsegError):
-        ops.conv3x3_winograd(torch.zeros(1, 8, 8, 8, device="cuda"), torch.zeros(16, 8, 64, device="cuda"), sh)      # Cin % 16
+        ops.conv3x3_winograd(torch.zeros(1, 8, 8, 8, device="cuda"), torch.zeros(1, 16, 2, 64, 4, device="cuda"), sh)      # Cin % 16
     with pytest.raises(N.AwsegError):
-        ops.conv3x3_winograd(x, torch.zeros(16, 16, 32, device="cuda"), sh[:32])                                        # Cout % 64
+        ops.conv3x3_winograd(x, torch.zeros(2, 16, 2, 32, 4, device="cuda"), sh[:32])                                        # Cout % 64
     with pytest.raises(N.AwsegError):
         ops.conv3x3_winograd(x, u, sh, w2=torch.zeros(64, device="cuda"))                                               # w2 without b2
     assert ops.conv3x3_winograd(x[:0], u, sh).shape == (0, 8, 8, 64)

@@ -101,13 +101,13 @@ def check(rc: int, what: str) -> None:
         raise AwsegError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
 
 
-launch_hook = None     # bench.py installs a (name, thunk) -> rc wrapper to time launches with HIP events
+launch_hook = None     # bench.py installs a (name, thunk, args) -> rc wrapper to time launches with HIP events
 
 
 def call(name: str, *args) -> None:
     """Invoke one C-ABI launcher and raise on a non-zero return code."""
     fn = getattr(lib(), name)
-    rc = fn(*args) if launch_hook is None else launch_hook(name, lambda: fn(*args))
+    rc = fn(*args) if launch_hook is None else launch_hook(name, lambda: fn(*args), args)
     check(rc, name)
 
 

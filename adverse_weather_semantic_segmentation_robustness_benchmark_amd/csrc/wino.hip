@@ -12,9 +12,18 @@
 //   Y   = A^T M A       2x2 outputs per tile                           (in-lane: a lane's 16 accumulators
 //                                                                       of one (tile, cout) are the 16 p's)
 // Block = 8x8 tiles (16x16 outputs) x 64 output channels, 4 waves: wave (mt, nt) owns tiles
-// 32*mt.. and couts 32*nt.., all 16 positions -> 16 accumulator tiles of 32x32 (256 registers per
-// lane, one wave per SIMD).  Input channels stream through LDS in chunks of 16; the next chunk's
-// raw pixels and weights are prefetched into registers while the matrix cores run on the current one.
+// 32*mt.. and couts 32*nt.., all 16 positions -> 16 accumulator tiles of 32x32 (256 AGPRs per
+// lane, one wave per SIMD).  Input channels stream in chunks of 8 (four k-steps):
+//   * the chunk's raw 18x18-pixel patch is LDS-DMA'd once (every pixel fetched once, not once per
+//     overlapping tile), two chunks ahead, into a bank-swizzled image;
+//   * each thread turns one (tile, 2 channels) of it into V with ds_read_b64 / ds_write_b64, a
+//     quarter of that work riding behind each group of 16 MFMAs of the previous chunk;
+//   * A fragments come from V by ds_read_b128 (four k-steps per read), B fragments straight from L2
+//     (the host stores U as the fragment image), both one position group ahead of their MFMAs.
+// What the measurements said on the way: per-lane scattered input loads made the
+// texture-address path the bottleneck (41 % of peak -> 52 %); the LDS-DMA builtin makes hipcc wait
+// vmcnt(0) before the next ds_read (inline asm instead); an LDS-DMA instruction costs the issuing
+// wave a few hundred cycles, so the weights go to registers directly (52 % -> 58 %).
 // Epilogues: FULL  out[b,y,x,n] = act(Y + shift[n] (+ residual))            (NHWC)
 //            HEAD1 out[b,y,x]   = sigmoid(b2 + sum_n w2[n] * relu(Y + shift[n]))   (Cout == 64)
 #include "awseg_common.h"
@@ -29,7 +38,6 @@ constexpr int NTILE = TB * TB;     // 64
 constexpr int KC = 8;              // input channels per chunk
 constexpr int NB = 64;             // output channels per block
 constexpr int V_FLOATS = 16 * KC * NTILE;   // 32 KB per buffer
-constexpr int U_FLOATS = 16 * KC * NB;      // 32 KB per buffer
 constexpr int PW = 2 * TB + 2;                // 18 x 18 input pixels feed the block's 8 x 8 tiles
 constexpr int PRS = 24;                       // patch row stride in 16-byte slots (18 used)
 constexpr int PH1 = 440;                      // slot offset of the second channel quad (== 8 mod 16: see patch layout)
@@ -70,7 +78,7 @@ __device__ __forceinline__ uint32_t lds_addr(const float* p)
 __device__ __forceinline__ float2 f2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 f2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 
-// LDS images.  Operands: sV[p][hk][tile][s], sU[p][hk][cout][s]: k-step s pairs the chunk's input
+// Images.  sV[p][hk][tile][s] in LDS, U[chunk][p][hk][cout][s] in global memory: k-step s pairs the chunk's input
 // channels c(s,0), c(s,1) with c(s,hk) = 4*(s>>1) + 2*hk + (s&1) (lane l of the 32x32x2 MFMA takes
 // half hk = l>>5), so a lane's four k-steps of one position are ONE conflict-free ds_read_b128 and
 // a transform thread's two channels are adjacent in memory.  Raw patch: 16-byte slots (4 channels of one

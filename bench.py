@@ -48,18 +48,34 @@ class KernelClock:
         self.enabled = False
         self.pairs = {}
 
-    def hook(self, name, thunk):
+    def hook(self, name, thunk, args=()):
         if not self.enabled:
             return thunk()
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = thunk()
         e.record()
-        self.pairs.setdefault(name, []).append((s, e))
+        self.pairs.setdefault(name, []).append((s, e, launch_work(name, args)))
         return rc
 
     def summary(self):
-        return {n: (len(p), sum(s.elapsed_time(e) for s, e in p) / len(p)) for n, p in self.pairs.items()}
+        """name -> (launches, mean ms per launch, mean per-launch work or None)."""
+        out = {}
+        for n, p in self.pairs.items():
+            works = [w for _, _, w in p]
+            out[n] = (len(p), sum(s.elapsed_time(e) for s, e, _ in p) / len(p), None if works[0] is None else sum(works) / len(works))
+        return out
+
+
+def launch_work(name, args):
+    """Work of ONE launch when it depends on the launch's own shape arguments (kernels called at
+    several shapes per step); None -> algorithmic_work() prices the launch from the bench shape."""
+    if name == "awseg_conv3x3_winograd_nhwc":
+        # (x, batch, H, W, Cin, Cout, dilation, ...): MFMA flops issued = 16 multiplies per 2x2 output tile,
+        # 2.25x fewer than the direct convolution computes
+        _, b, h, w, cin, cout = args[:6]
+        return 2.0 * 16 * cin * cout * b * ((h + 1) // 2) * ((w + 1) // 2)
+    return None
 
 
 CLOCK = KernelClock()
@@ -87,7 +103,7 @@ def algorithmic_work(name, B, H, W, C, info):
 
 
 # device-function names of the C-ABI launchers' dominant kernels (for the PMC traffic lookup)
-DEVICE_KERNEL = {"awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
+DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_kernel"}
 
 
@@ -236,8 +252,8 @@ def main():
 
     # ---- roofline of the dominant hand-written kernel (rank 0's launches) ----------------------
     kernels = []
-    for name, (count, avg_ms) in CLOCK.summary().items():
-        bound, work = algorithmic_work(name, B, H, W, C, info)
+    for name, (count, avg_ms, own_work) in CLOCK.summary().items():
+        bound, work = ("mfma", own_work) if own_work is not None else algorithmic_work(name, B, H, W, C, info)
         if work <= 0 or avg_ms <= 0:
             continue
         if bound == "hbm":

@@ -229,15 +229,17 @@ void conv3x3_wino_kernel(wino_args a)
 #define WINO_LOAD_B(UP, G, BV)                                                                 \
     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
         BV[q] = *reinterpret_cast<const float4*>((UP) + (4 * (G) + q) * u_pos);
+    // FULL keeps tiles on the accumulator rows and couts on its columns (a lane = one cout: coalesced
+    // NHWC stores).  HEAD1 swaps the operands -> couts on the rows, so the 1x1 convolution's sum over
+    // the 64 couts is 15 in-register adds + one cross-half shuffle + one cross-wave LDS add per pixel
+    // instead of a 32-lane butterfly per pixel.
+#define WINO_MM(X, Y, CACC) (MODE == 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(Y, X, CACC, 0, 0, 0)   \
+                                       : __builtin_amdgcn_mfma_f32_32x32x2f32(X, Y, CACC, 0, 0, 0))
 #define WINO_MFMAS(G, AV, BV)                                                                  \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        acc[4 * (G) + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].x, BV[q].x, acc[4 * (G) + q], 0, 0, 0); \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        acc[4 * (G) + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].y, BV[q].y, acc[4 * (G) + q], 0, 0, 0); \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        acc[4 * (G) + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].z, BV[q].z, acc[4 * (G) + q], 0, 0, 0); \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        acc[4 * (G) + q] = __builtin_amdgcn_mfma_f32_32x32x2f32(AV[q].w, BV[q].w, acc[4 * (G) + q], 0, 0, 0);
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].x, BV[q].x, acc[4 * (G) + q]); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].y, BV[q].y, acc[4 * (G) + q]); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].z, BV[q].z, acc[4 * (G) + q]); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].w, BV[q].w, acc[4 * (G) + q]);
     // Instruction-mix recipes for the scheduler: each MFMA is followed by a few of the companion
     // instructions of its group, so staging work issues in the shadow of the 64-cycle MFMAs instead of
     // in a clump that leaves the matrix core idle.  (mask 0x008 MFMA, 0x002 VALU, 0x020 VMEM read,
@@ -305,30 +307,30 @@ void conv3x3_wino_kernel(wino_args a)
 #undef WINO_LOAD_A
 #undef WINO_LOAD_B
 #undef WINO_MFMAS
+#undef WINO_MM
 #undef WINO_STEP
 #undef WINO_MIX
 
-    // ---- output transform + epilogue.  acc[p][r]: tile row (r&3) + 8*(r>>2) + 4*hk of m-tile mt, cout li of n-tile nt
-    const int n = n0 + nt * 32 + li;
-    const float sh = a.shift[n];
-    float w2v = 0.f;
-    if (MODE == 1) w2v = a.w2[n];
+    // ---- output transform + epilogue.  acc[p][r] is element (row (r&3) + 8*(r>>2) + 4*hk, column li) of
+    // this wave's 32x32 block of M_p: FULL rows = tiles of m-tile mt, columns = couts of n-tile nt;
+    // HEAD1 rows = couts of nt, columns = tiles of mt.
     float* red = smem;                                   // HEAD1: [2][NTILE][4] partial sums (after the last sync)
+    if (MODE == 0) {
+        const int n = n0 + nt * 32 + li;
+        const float sh = a.shift[n];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int row = (r & 3) + 8 * (r >> 2) + 4 * hk;
-        const int tile = mt * 32 + row;
-        float m[4][4];
+        for (int r = 0; r < 16; ++r) {
+            const int tile = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+            float m[4][4];
 #pragma unroll
-        for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = acc[p][r];
-        float t0[4], t1[4];
+            for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = acc[p][r];
+            float t0[4], t1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { t0[j] = m[0][j] + m[1][j] + m[2][j]; t1[j] = m[1][j] - m[2][j] - m[3][j]; }
-        float y[2][2];
-        y[0][0] = t0[0] + t0[1] + t0[2]; y[0][1] = t0[1] - t0[2] - t0[3];
-        y[1][0] = t1[0] + t1[1] + t1[2]; y[1][1] = t1[1] - t1[2] - t1[3];
-        const int uy = by * 2 * TB + 2 * (tile >> 3), ux = bx * 2 * TB + 2 * (tile & 7);
-        if (MODE == 0) {
+            for (int j = 0; j < 4; ++j) { t0[j] = m[0][j] + m[1][j] + m[2][j]; t1[j] = m[1][j] - m[2][j] - m[3][j]; }
+            float y[2][2];
+            y[0][0] = t0[0] + t0[1] + t0[2]; y[0][1] = t0[1] - t0[2] - t0[3];
+            y[1][0] = t1[0] + t1[1] + t1[2]; y[1][1] = t1[1] - t1[2] - t1[3];
+            const int uy = by * 2 * TB + 2 * (tile >> 3), ux = bx * 2 * TB + 2 * (tile & 7);
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa)
 #pragma unroll
@@ -341,29 +343,44 @@ void conv3x3_wino_kernel(wino_args a)
                         a.out[o] = act_apply(v, a.act);
                     }
                 }
-        } else {
-            float v[4];
+        }
+    } else {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float t = y[q >> 1][q & 1] + sh;
-                v[q] = (t > 0.f ? t : 0.f) * w2v;
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int c4 = n0 + nt * 32 + 8 * r4 + 4 * hk;                      // rows 4*r4 .. 4*r4+3 are four consecutive couts
+            const float4 sh4 = *reinterpret_cast<const float4*>(a.shift + c4);
+            const float4 w4 = *reinterpret_cast<const float4*>(a.w2 + c4);
+            const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
 #pragma unroll
-                for (int o = 16; o > 0; o >>= 1) v[q] += __shfl_xor(v[q], o, 32);
-            }
-            if (li == 0) {
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = r4 * 4 + rr;
+                float m[4][4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) red[(nt * NTILE + tile) * 4 + q] = v[q];
+                for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = acc[p][r];
+                float t0[4], t1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t0[j] = m[0][j] + m[1][j] + m[2][j]; t1[j] = m[1][j] - m[2][j] - m[3][j]; }
+                const float y0 = t0[0] + t0[1] + t0[2], y1 = t0[1] - t0[2] - t0[3];
+                const float y2 = t1[0] + t1[1] + t1[2], y3 = t1[1] - t1[2] - t1[3];
+                const float yv[4] = {y0, y1, y2, y3};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float v = yv[q] + shv[rr];
+                    z[q] = z[q] + (v > 0.f ? v : 0.f) * wv[rr];
+                }
             }
         }
-    }
-    if (MODE == 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) z[q] += __shfl_xor(z[q], 32, 64);           // the other half holds rows +4 of the same tile
+        if (hk == 0) *reinterpret_cast<float4*>(red + (nt * NTILE + mt * 32 + li) * 4) = make_float4(z[0], z[1], z[2], z[3]);
         __syncthreads();
         const int tile = tid >> 2, q = tid & 3;
         const int uy = by * 2 * TB + 2 * (tile >> 3) + (q >> 1), ux = bx * 2 * TB + 2 * (tile & 7) + (q & 1);
         const int yy = ry + a.dil * uy, xx = rx + a.dil * ux;
         if (yy < a.H && xx < a.W) {
-            const float z = red[tile * 4 + q] + red[(NTILE + tile) * 4 + q] + a.b2[0];
-            a.out[((int64_t)b * a.H + yy) * a.W + xx] = 1.0f / (1.0f + expf(-z));
+            const float zz = red[tile * 4 + q] + red[(NTILE + tile) * 4 + q] + a.b2[0];
+            a.out[((int64_t)b * a.H + yy) * a.W + xx] = 1.0f / (1.0f + expf(-zz));
         }
     }
 }

@@ -71,7 +71,7 @@ def nhwc_view(t: torch.Tensor) -> torch.Tensor:
     return v if v.is_contiguous() else v.contiguous()
 
 
-WINOGRAD_MIN_CIN = 128     # below this the direct MIOpen kernel is as fast (tools/kernel_bench.py, 64->64 @1/4)
+WINOGRAD_MIN_CIN = 64      # 64->64 @1/4 (ResNet layer1): 0.585 ms vs 0.64-0.69 ms for MIOpen's direct kernel (tools/kernel_bench.py)
 
 
 def _is_winograd(conv: nn.Conv2d) -> bool:

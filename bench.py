@@ -113,7 +113,7 @@ def pmc_traffic(name):
     FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads).  None if the
     profile is not there — bench.py itself does not collect counters."""
     import csv
-    path = ROOT / "profiles" / "r01_kernel_bench_v3_stats_and_traffic.csv"
+    path = ROOT / "profiles" / "r01_kernel_bench_v4_stats_and_traffic.csv"
     key = DEVICE_KERNEL.get(name)
     if not key or not path.exists():
         return None
@@ -269,7 +269,7 @@ def main():
         k0 = kernels[0]
         roofline = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
                     "unit": k0["unit"], "frac": k0["frac"], "traffic": pmc_traffic(k0["kernel"]),
-                    "traffic_source": "profiles/r01_kernel_bench_v3_stats_and_traffic.csv (separate --pmc FETCH_SIZE / WRITE_SIZE passes, same launch shape)"}
+                    "traffic_source": "profiles/r01_kernel_bench_v4_stats_and_traffic.csv (separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/kernel_bench.py; for the Winograd kernel: the full-resolution 128->64 depth-head launch, the largest of its 17 launches per step)"}
 
     if rank == 0:
         cpu = None

@@ -17,7 +17,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent
 PKG = CSRC.parent
 LIB = PKG / "libawseg_hip.so"
-SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "backbone.hip", "depth.hip", "wino.hip"]
+SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "backbone.hip", "depth.hip", "wino.hip", "gemm.hip"]
 ARCH = "gfx950"
 
 
@@ -30,7 +30,7 @@ def hipcc() -> str:
 
 def _flags():
     return [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-            "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+            "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]   # inline asm: wino.hip clobbers m0 on purpose
 
 
 def needs_build() -> bool:
@@ -59,7 +59,9 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     with ThreadPoolExecutor(max_workers=min(4, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     tmp = LIB.with_suffix(".so.tmp")
-    subprocess.check_call([cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs)])
+    rocm_lib = str(Path(cc).resolve().parent.parent / "lib")
+    subprocess.check_call([cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs),
+                           f"-L{rocm_lib}", "-lhipblaslt", f"-Wl,-rpath,{rocm_lib}"])     # gemm.hip: plain library GEMMs
     os.replace(tmp, LIB)
     return LIB
 

@@ -101,25 +101,22 @@ def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, 
     """act(bn(conv(x)) [+ residual]) with x / result logically NCHW in channels_last memory.
 
     A 1x1 stride-1 convolution of an NHWC tensor IS a row-major GEMM [B*H*W, Cin] x [Cin, Cout], so
-    it goes to hipBLASLt with the epilogue doing the work of the separate passes: `+shift -> ReLU`
-    rides on the GEMM (torch._addmm_activation), and a residual is the GEMM's beta*C operand —
-    accumulated IN PLACE into the residual's buffer when the caller says it is dead afterwards
-    (`residual_is_scratch`), leaving one in-place `+shift -> ReLU` pass.  Everything else (3x3, 7x7,
-    strided 1x1) stays on MIOpen with the one-pass HIP epilogue."""
+    it is ONE hipBLASLt call (awseg_gemm_bias_act) whose epilogue does `+shift`, the residual (the
+    GEMM's beta*C operand, written over the residual's buffer when the caller says it is dead
+    afterwards: `residual_is_scratch`) and the ReLU.  3x3 stride-1 convolutions go to the Winograd /
+    MFMA kernel; the rest (7x7, strided) stays on MIOpen with the one-pass HIP epilogue."""
     w, shift = folded_conv_bn(conv, bn)
     if _is_pointwise(conv) and x.is_contiguous(memory_format=CL):
         B, Cin, H, W = x.shape
         Cout = w.shape[0]
         x2 = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin)
-        w2t = w.view(Cout, Cin).t()
-        if residual is None:
-            y2 = torch._addmm_activation(shift, x2, w2t) if act == N.ACT_RELU else torch.addmm(shift, x2, w2t)
-            if act not in (N.ACT_RELU, N.ACT_NONE):
-                ops.bias_act_nhwc_(y2, torch.zeros_like(shift), None, act)
+        w2 = w.view(Cout, Cin)
+        if act in (N.ACT_RELU, N.ACT_NONE):
+            r2 = None if residual is None else nhwc_view(residual).reshape(B * H * W, Cout)
+            y2 = ops.gemm_bias_act(x2, w2, shift, act, residual=r2, out=r2 if (r2 is not None and residual_is_scratch) else None)
         else:
-            r2 = nhwc_view(residual).reshape(B * H * W, Cout)
-            y2 = r2.addmm_(x2, w2t) if residual_is_scratch else torch.addmm(r2, x2, w2t)
-            ops.bias_act_nhwc_(y2, shift, None, act)
+            y2 = torch.addmm(shift, x2, w2.t()) if residual is None else torch.addmm(nhwc_view(residual).reshape(B * H * W, Cout), x2, w2.t())
+            ops.bias_act_nhwc_(y2, torch.zeros_like(shift) if residual is None else shift, None, act)
         return y2.view(B, H, W, Cout).permute(0, 3, 1, 2)
     if _is_winograd(conv) and act in (N.ACT_NONE, N.ACT_RELU):
         # 3x3 stride-1 "same" convolution: Winograd F(2x2,3x3) on the fp32 matrix cores, epilogue fused

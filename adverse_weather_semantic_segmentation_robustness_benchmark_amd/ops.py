@@ -432,6 +432,23 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, shift: torch.Tensor, act:
     return out
 
 
+GEMM_WORKSPACE_BYTES = 32 << 20
+
+
+def gemm_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int = 0, residual: Optional[torch.Tensor] = None,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x[M,K] @ w[N,K]^T + bias (+ residual[M,N])) in one hipBLASLt call (epilogue-fused); `out` may be `residual`."""
+    x, w = x.contiguous(), w.contiguous()
+    m, k = x.shape
+    n = w.shape[0]
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    ws = N.workspace.get(x.device, GEMM_WORKSPACE_BYTES, tag="gemm")
+    N.call("awseg_gemm_bias_act", N.ptr(x), N.ptr(w), N.ptr(bias.contiguous()), N.ptr(residual), act, N.ptr(out), m, n, k,
+           N.ptr(ws), GEMM_WORKSPACE_BYTES, N.stream())
+    return out
+
+
 def layernorm_rows(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     """torch.nn.functional.layer_norm over the last dimension for small channel counts (MiT tokens)."""
     x = x.contiguous()

@@ -415,6 +415,18 @@ int awseg_conv3x3_winograd_nhwc(const float* x, int batch, int height, int width
                                 const float* u, const float* shift, const float* residual, int act,
                                 const float* w2, const float* b2, float* out, awseg_stream_t stream);
 
+/* awseg_gemm_bias_act: out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])), row-major float32,
+ * act 0 none / 1 ReLU — a 1x1 stride-1 convolution of an NHWC tensor with the eval-mode BatchNorm folded
+ * into w / bias and the bottleneck's identity as `residual` (the 1x1s of the ResNet-50 encoder and the
+ * decoder projections behind PKG/models/model.py:349).  One hipBLASLt matmul (the library GEMM) whose
+ * epilogue does the bias, the residual (beta*C) and the ReLU, so no separate pass touches the output.
+ * residual may alias out.  workspace: device scratch for the library (32 MiB is plenty; pass the same size
+ * for the same shape — the algorithm choice is cached per (M,N,K,residual,act,workspace_bytes)).  The
+ * library handle and the cached choices are host state created on first use. */
+int awseg_gemm_bias_act(const float* x, const float* w, const float* bias, const float* residual, int act,
+                        float* out, int64_t m, int n, int k, void* workspace, size_t workspace_bytes,
+                        awseg_stream_t stream);
+
 /* awseg_bias_act_nhwc: x = act(x + bias[c] (+ residual)) in place on float32 [n_pixels, C]:
  * the epilogue of a convolution whose eval-mode BatchNorm scale was folded into its weights
  * (Conv -> BN -> [+identity] -> ReLU of the ResNet bottlenecks behind PKG/models/model.py:349). */

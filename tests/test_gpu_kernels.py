@@ -421,6 +421,26 @@ def test_conv3x3_winograd_abi_checks(ops, native):
     assert ops.conv3x3_winograd(x[:0], u, sh).shape == (0, 8, 8, 64)
 
 
+@pytest.mark.parametrize("shape", [(4096, 64, 256), (1000, 48, 304), (8 * 64 * 128, 256, 1024), (37, 19, 64)])
+def test_gemm_bias_act_epilogues(ops, shape):
+    """1x1 convolution as one hipBLASLt call: bias, residual (also in place) and ReLU in the epilogue, against
+    a float64 reference; 1e-4 abs on O(1) outputs."""
+    M, Nn, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + Nn + K)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    w = torch.randn(Nn, K, device="cuda", generator=g) / K ** 0.5
+    b = torch.randn(Nn, device="cuda", generator=g)
+    r = torch.randn(M, Nn, device="cuda", generator=g)
+    ref = x.double() @ w.double().t() + b.double()
+    assert (ops.gemm_bias_act(x, w, b, 0).double() - ref).abs().max().item() < 1e-4
+    assert (ops.gemm_bias_act(x, w, b, 1).double() - ref.clamp_min(0)).abs().max().item() < 1e-4
+    assert (ops.gemm_bias_act(x, w, b, 1, residual=r).double() - (ref + r.double()).clamp_min(0)).abs().max().item() < 1e-4
+    r2 = r.clone()
+    out = ops.gemm_bias_act(x, w, b, 0, residual=r2, out=r2)                  # accumulate over the residual's buffer
+    assert out.data_ptr() == r2.data_ptr() and (r2.double() - (ref + r.double())).abs().max().item() < 1e-4
+    assert ops.gemm_bias_act(x[:0], w, b, 1).shape == (0, Nn)
+
+
 def test_aspp_depthwise3(ops):
     torch.manual_seed(0)
     B, h, w, Cc = 2, 20, 28, 16

@@ -197,7 +197,7 @@ class DeepLabV3PlusDecoder(nn.Module):
 
         def branch(inp, wmat, bn):
             s, b = _bn_fold(bn)
-            return torch.addmm(b, inp, (wmat * s[:, None]).t()).relu_()
+            return ops.gemm_bias_act(inp, wmat * s[:, None], b, 1)          # GEMM with bias + ReLU in the epilogue
 
         acc = None
         # branch 0: 1x1

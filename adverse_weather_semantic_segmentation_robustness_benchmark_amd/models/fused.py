@@ -160,8 +160,7 @@ def separable_bn_relu(x: torch.Tensor, sep, bn: nn.BatchNorm2d) -> torch.Tensor:
     B, H, W, C = xl.shape
     d = ops.dwconv3x3_nhwc(xl, dw_taps(dwc), None, N.ACT_NONE, dilation=dwc.dilation[0])
     w, shift = folded_conv_bn(pwc, bn)                                   # [Cout,Cin,1,1]
-    y = d.view(B * H * W, C) @ w.view(w.shape[0], C).t()
-    ops.bias_act_nhwc_(y, shift, None, N.ACT_RELU)
+    y = ops.gemm_bias_act(d.view(B * H * W, C), w.view(w.shape[0], C), shift, N.ACT_RELU)
     return y.view(B, H, W, -1).permute(0, 3, 1, 2)                       # NCHW view, channels_last memory
 
 
@@ -171,6 +170,15 @@ def _ln(t, ln: nn.LayerNorm):
     if c % 4 == 0 and c <= 1024 and ln.weight is not None and ln.bias is not None:
         return ops.layernorm_rows(t, ln.weight, ln.bias, ln.eps)           # sub-wave rows (HIP)
     return F.layer_norm(t, (c,), ln.weight, ln.bias, ln.eps)
+
+
+def _linear_residual(x2: torch.Tensor, lin: nn.Linear, tok: torch.Tensor) -> torch.Tensor:
+    """tok + lin(x2) for NHWC tokens [B,H,W,C], written over tok (which the caller owns and drops)."""
+    if lin.bias is None or not tok.is_contiguous():
+        return tok + F.linear(x2, lin.weight, lin.bias).view_as(tok)
+    t2 = tok.view(-1, tok.shape[-1])
+    ops.gemm_bias_act(x2, lin.weight, lin.bias, N.ACT_NONE, residual=t2, out=t2)
+    return tok
 
 
 @torch.no_grad()
@@ -205,15 +213,15 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
             nh, d = a.num_attention_heads, a.head_dim
             o = F.scaled_dot_product_attention(q.view(B, H * W, nh, d).transpose(1, 2), k.reshape(B, -1, nh, d).transpose(1, 2),
                                                v.reshape(B, -1, nh, d).transpose(1, 2), scale=a.scaling)
-            o = F.linear(o.transpose(1, 2).reshape(B, H, W, C), a.o_proj.weight, a.o_proj.bias)
-            tok = tok + o
+            # tok + o_proj(o): the residual is the GEMM's beta*C operand, accumulated over tok's buffer
+            tok = _linear_residual(o.transpose(1, 2).reshape(B * H * W, C), a.o_proj, tok)
             m = blk.mlp
             hcur = F.linear(_ln(tok, blk.layernorm_after), m.fc1.weight, m.fc1.bias)
             if getattr(seg.config, "hidden_act", "gelu") == "gelu":
                 hcur = ops.dwconv3x3_nhwc(hcur, dw_taps(m.dwconv.dwconv), m.dwconv.dwconv.bias, N.ACT_GELU)   # dwconv + GELU fused
             else:
                 hcur = m.activation_fn(ops.dwconv3x3_nhwc(hcur, dw_taps(m.dwconv.dwconv), m.dwconv.dwconv.bias, N.ACT_NONE))
-            tok = tok + F.linear(hcur, m.fc2.weight, m.fc2.bias)
+            tok = _linear_residual(hcur.reshape(B * H * W, -1), m.fc2, tok)
         tok = _ln(tok, st.layer_norm)
         t = tok.permute(0, 3, 1, 2)                                          # NCHW view (channels_last) for the next stage
     return tok

@@ -39,10 +39,10 @@ constexpr int KC = 8;              // input channels per chunk
 constexpr int NB = 64;             // output channels per block
 constexpr int V_FLOATS = 16 * KC * NTILE;   // 32 KB per buffer
 constexpr int PW = 2 * TB + 2;                // 18 x 18 input pixels feed the block's 8 x 8 tiles
-constexpr int PRS = 24;                       // patch row stride in 16-byte slots (18 used)
-constexpr int PH1 = 440;                      // slot offset of the second channel quad (== 8 mod 16: see patch layout)
-constexpr int P_UNITS = 14 * 64;              // slots per patch buffer (440 + 18*24 = 872, whole wave instructions)
-constexpr int P_FLOATS = P_UNITS * 4;         // 14 KB per buffer
+constexpr int PRS = PW;                       // patch row stride in 16-byte slots (dense)
+constexpr int PH1 = PW * PW;                  // slot offset of the second channel quad
+constexpr int P_UNITS = 11 * 64;              // slots per patch buffer (2 * 324 = 648, whole wave instructions)
+constexpr int P_FLOATS = P_UNITS * 4;         // 11 KB per buffer
 constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * P_FLOATS;   // 92 KB: transformed input and the raw patch, double-buffered
 
 struct wino_args {
@@ -75,56 +75,58 @@ __device__ __forceinline__ uint32_t lds_addr(const float* p)
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
-__device__ __forceinline__ float2 f2sub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 f2add(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+// two channels per lane as a 2-vector: a - b / a + b compile to ONE v_pk_add_f32.  fp32 MFMA runs at the
+// vector rate — VALU instructions do not hide behind it, every one removed from the loop is MFMA time back.
+typedef float v2f __attribute__((ext_vector_type(2)));
+#define V2SUB(a, b) ((a) - (b))
+#define V2ADD(a, b) ((a) + (b))
 
 // Images.  sV[p][hk][tile][s] in LDS, U[chunk][p][hk][cout][s] in global memory: k-step s pairs the chunk's input
 // channels c(s,0), c(s,1) with c(s,hk) = 4*(s>>1) + 2*hk + (s&1) (lane l of the 32x32x2 MFMA takes
 // half hk = l>>5), so a lane's four k-steps of one position are ONE conflict-free ds_read_b128 and
 // a transform thread's two channels are adjacent in memory.  Raw patch: 16-byte slots (4 channels of one
-// pixel), slot = quad*PH1 + py*PRS + (px ^ ((py>>1)&1)): the column flip on every other row pair and
-// PH1 == 8 (mod 16) make the 16 lanes of every ds_read_b128 lane group land on 16 distinct slots.
+// pixel), slot = quad*PH1 + py*PRS + (px ^ ((py>>1)&1)), dense: the column flip on every other row pair
+// keeps the transform's ds_read_b64 (8 of a slot's 16 bytes per lane) at its 2-way floor for every tap.
 //
 // V = B^T d B of one (tile, 2 adjacent channels) in two stages so the work can ride between the MFMA groups
-// of a step: rows first (t = B^T d, pixels outside the image masked to zero), then one output row i
+// of a step: rows first (t = B^T d), then one output row i
 // of (t B) -> positions 4i..4i+3, stored as float2 (k-steps 2*cp, 2*cp+1 of half hk).
 struct patch_ptrs { const float* e_lo; const float* o_lo; const float* e_hi; const float* o_hi; };
 
-__device__ __forceinline__ void patch_read(const patch_ptrs& pp, float2 (&r)[16])
+__device__ __forceinline__ void patch_read(const patch_ptrs& pp, v2f (&r)[16])
 {
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float* base = i < 2 ? ((j & 1) ? pp.o_lo : pp.e_lo) : ((j & 1) ? pp.o_hi : pp.e_hi);
-            r[i * 4 + j] = *reinterpret_cast<const float2*>(base + (i * PRS + j) * 4);
+            r[i * 4 + j] = *reinterpret_cast<const v2f*>(base + (i * PRS + j) * 4);
         }
 }
-__device__ __forceinline__ void xform_rows(float2 (&r)[16], uint32_t mask, float2 (&t)[16])
+__device__ __forceinline__ void xform_rows(const v2f (&r)[16], v2f (&t)[16])
 {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const bool ok = (mask >> q) & 1u;
-        r[q] = make_float2(ok ? r[q].x : 0.f, ok ? r[q].y : 0.f);
-    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        t[0 * 4 + j] = f2sub(r[0 * 4 + j], r[2 * 4 + j]);
-        t[1 * 4 + j] = f2add(r[1 * 4 + j], r[2 * 4 + j]);
-        t[2 * 4 + j] = f2sub(r[2 * 4 + j], r[1 * 4 + j]);
-        t[3 * 4 + j] = f2sub(r[1 * 4 + j], r[3 * 4 + j]);
+        t[0 * 4 + j] = r[0 * 4 + j] - r[2 * 4 + j];
+        t[1 * 4 + j] = r[1 * 4 + j] + r[2 * 4 + j];
+        t[2 * 4 + j] = r[2 * 4 + j] - r[1 * 4 + j];
+        t[3 * 4 + j] = r[1 * 4 + j] - r[3 * 4 + j];
     }
 }
-__device__ __forceinline__ void xform_cols_store(const float2 (&t)[16], int i, float* __restrict__ d)
+__device__ __forceinline__ void xform_cols_store(const v2f (&t)[16], int i, float* __restrict__ d)
 {
-    float2 v[4];
-    v[0] = f2sub(t[i * 4 + 0], t[i * 4 + 2]);
-    v[1] = f2add(t[i * 4 + 1], t[i * 4 + 2]);
-    v[2] = f2sub(t[i * 4 + 2], t[i * 4 + 1]);
-    v[3] = f2sub(t[i * 4 + 1], t[i * 4 + 3]);
+    v2f v[4];
+    v[0] = t[i * 4 + 0] - t[i * 4 + 2];
+    v[1] = t[i * 4 + 1] + t[i * 4 + 2];
+    v[2] = t[i * 4 + 2] - t[i * 4 + 1];
+    v[3] = t[i * 4 + 1] - t[i * 4 + 3];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<float2*>(d + (i * 4 + j) * (KC * NTILE)) = v[j];
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<v2f*>(d + (i * 4 + j) * (KC * NTILE)) = v[j];
 }
+
+// Pixels outside the image are fetched from this row of zeros (the patch DMA's source address is per lane),
+// so the transform needs no per-pixel masking.
+__device__ float g_zero_row[4096 + 8];
 
 template <int MODE>   // 0 FULL, 1 HEAD1
 __global__ __launch_bounds__(WT, 1)
@@ -147,41 +149,30 @@ void conv3x3_wino_kernel(wino_args a)
     // 16-byte units.  Fetching every pixel once (instead of once per overlapping tile straight into
     // registers) keeps the texture-address path off the critical path: a scattered per-lane load costs
     // it one request per lane.  Pixels outside the image fetch a clamped address; the mask zeroes them.
-    uint32_t punit[4];
+    const float* psrc[3];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 3; ++i) {
         const int q = (wave + 4 * i) * 64 + lane;                   // destination slot
         const int h = q >= PH1 ? 1 : 0, r = q - h * PH1;
         int py = r / PRS, pxs = r - py * PRS;
         if (py >= PW) py = PW - 1;                                  // padding slots re-fetch a valid pixel
-        if (pxs >= PW) pxs = PW - 1;
         const int px = pxs ^ ((py >> 1) & 1);
         const int sy = by * 2 * TB - 1 + py, sx = bx * 2 * TB - 1 + px;
-        int y = ry + a.dil * sy, x = rx + a.dil * sx;
+        const int y = ry + a.dil * sy, x = rx + a.dil * sx;
         const bool ok = sy >= 0 && sx >= 0 && y < a.H && x < a.W;
-        y = ok ? y : 0; x = ok ? x : 0;
-        punit[i] = (uint32_t)((y * a.W + x) * a.Cin + h * 4);
+        psrc[i] = (ok ? xb + ((size_t)y * a.W + x) * a.Cin : g_zero_row) + h * 4;
     }
-    const int n_pinstr = wave < 2 ? 4 : 3;                          // 14 wave instructions over 4 waves
+    const int n_pinstr = wave < 3 ? 3 : 2;                          // 11 wave instructions over 4 waves
     auto glds_patch = [&](int chunk, float* dstbuf) {
-        const float* base = xb + (chunk < nchunks ? chunk : nchunks - 1) * KC;
+        const int coff = (chunk < nchunks ? chunk : nchunks - 1) * KC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (i < n_pinstr) glds16(base + punit[i], __builtin_amdgcn_readfirstlane(lds_addr(dstbuf + (wave + 4 * i) * 256)));
+        for (int i = 0; i < 3; ++i)
+            if (i < n_pinstr) glds16(psrc[i] + coff, __builtin_amdgcn_readfirstlane(lds_addr(dstbuf + (wave + 4 * i) * 256)));
     };
     // transform item of this thread: half hk = wave & 1 (channels 4*cp + 2*hk, +1 = k-steps 2cp, 2cp+1), tile =
     // 32*(wave>>1) + lane/2, cp = lane & 1; validity of its 4 x 4 pixels
     const int xhk = wave & 1, xcp = lane & 1, xtile = (wave >> 1) * 32 + (lane >> 1);
     const int xty = xtile >> 3, xtx = xtile & 7;
-    uint32_t pmask = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int sy = by * 2 * TB + 2 * xty - 1 + i, sx = bx * 2 * TB + 2 * xtx - 1 + j;
-            const bool ok = sy >= 0 && sx >= 0 && ry + a.dil * sy < a.H && rx + a.dil * sx < a.W;
-            pmask |= (ok ? 1u : 0u) << (i * 4 + j);
-        }
     const int xf0 = xty & 1, xf1 = xf0 ^ 1;
     const int pbase = (xcp * PH1 + 2 * xty * PRS + 2 * xtx) * 4 + 2 * xhk;
     const int pe_lo = pbase + xf0 * 4, po_lo = pbase - xf0 * 4, pe_hi = pbase + xf1 * 4, po_hi = pbase - xf1 * 4;
@@ -207,10 +198,10 @@ void conv3x3_wino_kernel(wino_args a)
     glds_wait();
     __syncthreads();
     {
-        float2 r[16], t[16];
+        v2f r[16], t[16];
         const patch_ptrs pp = {sP + pe_lo, sP + po_lo, sP + pe_hi, sP + po_hi};
         patch_read(pp, r);
-        xform_rows(r, pmask, t);
+        xform_rows(r, t);
 #pragma unroll
         for (int i = 0; i < 4; ++i) xform_cols_store(t, i, sV + vdoff);
     }
@@ -262,7 +253,7 @@ void conv3x3_wino_kernel(wino_args a)
         const float* uc = ub + (size_t)(C) * u_chunk;                                          \
         const float* un = ub + (size_t)((C) + 1 < nchunks ? (C) + 1 : (C)) * u_chunk;          \
         float4 a0[4], a1[4];                                                                   \
-        float2 r[16], t[16];                                                                   \
+        v2f r[16], t[16];                                                                      \
         WINO_LOAD_A(0, a0)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                     \
         /* group 0: MFMAs + LDS-DMA issue + operands of group 1 + raw patch reads */            \
@@ -274,7 +265,7 @@ void conv3x3_wino_kernel(wino_args a)
         WINO_MIX(2, 1, 2, 0)                                                                   \
         __builtin_amdgcn_sched_barrier(0);                                                     \
         /* group 1: MFMAs + row transform + operands of group 2 */                              \
-        xform_rows(r, pmask, t);                                                               \
+        xform_rows(r, t);                                                               \
         WINO_LOAD_B(uc, 2, b0)                                                                 \
         WINO_LOAD_A(2, a0)                                                                     \
         WINO_MFMAS(1, a1, b1)                                                                  \
@@ -406,7 +397,7 @@ AWSEG_API int awseg_conv3x3_winograd_nhwc(const float* x, int batch, int height,
 {
     if (batch == 0) return 0;
     if (!x || !u || !shift || !out || batch < 0 || height < 1 || width < 1 || dilation < 1) return AWSEG_EINVAL;
-    if (cin < 2 * KC || (cin % (2 * KC)) || cout < NB || (cout % NB)) return AWSEG_ERANGE;
+    if (cin < 2 * KC || (cin % (2 * KC)) || cin > 4096 || cout < NB || (cout % NB)) return AWSEG_ERANGE;
     if ((w2 == nullptr) != (b2 == nullptr)) return AWSEG_EINVAL;
     if (w2 && (cout != NB || residual)) return AWSEG_ERANGE;          // the fused 1x1 head reduces over one 64-channel block
     if (act != AWSEG_ACT_NONE && act != AWSEG_ACT_RELU) return AWSEG_ERANGE;

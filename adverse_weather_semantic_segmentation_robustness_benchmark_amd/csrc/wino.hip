@@ -78,8 +78,20 @@ __device__ __forceinline__ uint32_t lds_addr(const float* p)
 // two channels per lane as a 2-vector: a - b / a + b compile to ONE v_pk_add_f32.  fp32 MFMA runs at the
 // vector rate — VALU instructions do not hide behind it, every one removed from the loop is MFMA time back.
 typedef float v2f __attribute__((ext_vector_type(2)));
-#define V2SUB(a, b) ((a) - (b))
-#define V2ADD(a, b) ((a) + (b))
+// (hipcc's pre-emit peephole splits v_pk_add_f32 back into two v_add_f32 when it sits behind an MFMA, assuming
+// the MFMA hides them; inline asm keeps the packed form.)
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
 
 // Images.  sV[p][hk][tile][s] in LDS, U[chunk][p][hk][cout][s] in global memory: k-step s pairs the chunk's input
 // channels c(s,0), c(s,1) with c(s,hk) = 4*(s>>1) + 2*hk + (s&1) (lane l of the 32x32x2 MFMA takes
@@ -107,19 +119,19 @@ __device__ __forceinline__ void xform_rows(const v2f (&r)[16], v2f (&t)[16])
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        t[0 * 4 + j] = r[0 * 4 + j] - r[2 * 4 + j];
-        t[1 * 4 + j] = r[1 * 4 + j] + r[2 * 4 + j];
-        t[2 * 4 + j] = r[2 * 4 + j] - r[1 * 4 + j];
-        t[3 * 4 + j] = r[1 * 4 + j] - r[3 * 4 + j];
+        t[0 * 4 + j] = pk_sub(r[0 * 4 + j], r[2 * 4 + j]);
+        t[1 * 4 + j] = pk_add(r[1 * 4 + j], r[2 * 4 + j]);
+        t[2 * 4 + j] = pk_sub(r[2 * 4 + j], r[1 * 4 + j]);
+        t[3 * 4 + j] = pk_sub(r[1 * 4 + j], r[3 * 4 + j]);
     }
 }
 __device__ __forceinline__ void xform_cols_store(const v2f (&t)[16], int i, float* __restrict__ d)
 {
     v2f v[4];
-    v[0] = t[i * 4 + 0] - t[i * 4 + 2];
-    v[1] = t[i * 4 + 1] + t[i * 4 + 2];
-    v[2] = t[i * 4 + 2] - t[i * 4 + 1];
-    v[3] = t[i * 4 + 1] - t[i * 4 + 3];
+    v[0] = pk_sub(t[i * 4 + 0], t[i * 4 + 2]);
+    v[1] = pk_add(t[i * 4 + 1], t[i * 4 + 2]);
+    v[2] = pk_sub(t[i * 4 + 2], t[i * 4 + 1]);
+    v[3] = pk_sub(t[i * 4 + 1], t[i * 4 + 3]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) *reinterpret_cast<v2f*>(d + (i * 4 + j) * (KC * NTILE)) = v[j];
 }

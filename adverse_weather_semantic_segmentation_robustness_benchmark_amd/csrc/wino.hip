@@ -193,8 +193,12 @@ void conv3x3_wino_kernel(wino_args a)
     // k-steps of one position are 16 contiguous bytes, a wave's two halves read two 512-byte runs.
     // They go straight from L2 to registers one position group ahead of their MFMAs (an LDS-DMA
     // stage for them cost more issue time than it saved: ~130 cycles per 1 KiB instruction).
-    const float* ub = a.U + (size_t)((lane >> 5) * a.Cout + n0 + (wave & 1) * 32 + (lane & 31)) * 4;
-    const size_t u_pos = (size_t)2 * a.Cout * 4, u_chunk = (size_t)32 * a.Cout * 4;
+    // Buffer addressing: descriptor + ONE per-lane byte offset (VGPR) + a scalar byte offset per load (chunk,
+    // position, cout block: scalar adds) — no 64-bit vector address arithmetic beside the MFMAs.
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, 0x7fffffff, 0x00020000);
+    const uint32_t ulane = (uint32_t)(((lane >> 5) * a.Cout + (lane & 31)) * 16);
+    const uint32_t ub = (uint32_t)(n0 + (__builtin_amdgcn_readfirstlane(wave) & 1) * 32) * 16;      // bytes, wave-uniform
+    const uint32_t u_pos = (uint32_t)2 * a.Cout * 16, u_chunk = (uint32_t)32 * a.Cout * 16;         // bytes
 
     f32x16 acc[16];
 #pragma unroll
@@ -231,7 +235,7 @@ void conv3x3_wino_kernel(wino_args a)
         AV[q] = *reinterpret_cast<const float4*>(pa + (4 * (G) + q) * (KC * NTILE));
 #define WINO_LOAD_B(UP, G, BV)                                                                 \
     _Pragma("unroll") for (int q = 0; q < 4; ++q)                                              \
-        BV[q] = *reinterpret_cast<const float4*>((UP) + (4 * (G) + q) * u_pos);
+        BV[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane, (UP) + (4 * (G) + q) * u_pos, 0));
     // FULL keeps tiles on the accumulator rows and couts on its columns (a lane = one cout: coalesced
     // NHWC stores).  HEAD1 swaps the operands -> couts on the rows, so the 1x1 convolution's sum over
     // the 64 couts is 15 in-register adds + one cross-half shuffle + one cross-wave LDS add per pixel
@@ -262,8 +266,8 @@ void conv3x3_wino_kernel(wino_args a)
         float* vd = sV + ((BUF) ^ 1) * V_FLOATS + vdoff;                                       \
         const float* pn = sP + ((BUF) ^ 1) * P_FLOATS;                                         \
         const patch_ptrs pp = {pn + pe_lo, pn + po_lo, pn + pe_hi, pn + po_hi};                \
-        const float* uc = ub + (size_t)(C) * u_chunk;                                          \
-        const float* un = ub + (size_t)((C) + 1 < nchunks ? (C) + 1 : (C)) * u_chunk;          \
+        const uint32_t uc = ub + (uint32_t)(C) * u_chunk;                                      \
+        const uint32_t un = ub + (uint32_t)((C) + 1 < nchunks ? (C) + 1 : (C)) * u_chunk;      \
         float4 a0[4], a1[4];                                                                   \
         v2f r[16], t[16];                                                                      \
         WINO_LOAD_A(0, a0)                                                                     \

@@ -322,37 +322,42 @@ void conv3x3_wino_kernel(wino_args a)
     // this wave's 32x32 block of M_p: FULL rows = tiles of m-tile mt, columns = couts of n-tile nt;
     // HEAD1 rows = couts of nt, columns = tiles of mt.
     float* red = smem;                                   // HEAD1: [2][NTILE][4] partial sums (after the last sync)
+    // Two accumulator rows at a time: rows r, r+1 of one position sit in adjacent registers, so the inverse
+    // transform (24 adds per row) runs as packed 2-vector adds.
     if (MODE == 0) {
         const int n = n0 + nt * 32 + li;
         const float sh = a.shift[n];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int tile = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
-            float m[4][4];
+        for (int r = 0; r < 16; r += 2) {
+            v2f m[4][4];
 #pragma unroll
-            for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = acc[p][r];
-            float t0[4], t1[4];
+            for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = v2f{acc[p][r], acc[p][r + 1]};
+            v2f t0[4], t1[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) { t0[j] = m[0][j] + m[1][j] + m[2][j]; t1[j] = m[1][j] - m[2][j] - m[3][j]; }
-            float y[2][2];
+            v2f y[2][2];
             y[0][0] = t0[0] + t0[1] + t0[2]; y[0][1] = t0[1] - t0[2] - t0[3];
             y[1][0] = t1[0] + t1[1] + t1[2]; y[1][1] = t1[1] - t1[2] - t1[3];
-            const int uy = by * 2 * TB + 2 * (tile >> 3), ux = bx * 2 * TB + 2 * (tile & 7);
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa)
+            for (int e = 0; e < 2; ++e) {
+                const int tile = mt * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * hk;
+                const int uy = by * 2 * TB + 2 * (tile >> 3), ux = bx * 2 * TB + 2 * (tile & 7);
 #pragma unroll
-                for (int bb = 0; bb < 2; ++bb) {
-                    const int yy = ry + a.dil * (uy + aa), xx = rx + a.dil * (ux + bb);
-                    if (yy < a.H && xx < a.W) {
-                        const int64_t o = (((int64_t)b * a.H + yy) * a.W + xx) * a.Cout + n;
-                        float v = y[aa][bb] + sh;
-                        if (a.residual) v += a.residual[o];
-                        a.out[o] = act_apply(v, a.act);
+                for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                    for (int bb = 0; bb < 2; ++bb) {
+                        const int yy = ry + a.dil * (uy + aa), xx = rx + a.dil * (ux + bb);
+                        if (yy < a.H && xx < a.W) {
+                            const int64_t o = (((int64_t)b * a.H + yy) * a.W + xx) * a.Cout + n;
+                            float v = y[aa][bb][e] + sh;
+                            if (a.residual) v += a.residual[o];
+                            a.out[o] = act_apply(v, a.act);
+                        }
                     }
-                }
+            }
         }
     } else {
-        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        float zs[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const int c4 = n0 + nt * 32 + 8 * r4 + 4 * hk;                      // rows 4*r4 .. 4*r4+3 are four consecutive couts
@@ -368,19 +373,17 @@ void conv3x3_wino_kernel(wino_args a)
                 float t0[4], t1[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { t0[j] = m[0][j] + m[1][j] + m[2][j]; t1[j] = m[1][j] - m[2][j] - m[3][j]; }
-                const float y0 = t0[0] + t0[1] + t0[2], y1 = t0[1] - t0[2] - t0[3];
-                const float y2 = t1[0] + t1[1] + t1[2], y3 = t1[1] - t1[2] - t1[3];
-                const float yv[4] = {y0, y1, y2, y3};
+                const float yv[4] = {t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float v = yv[q] + shv[rr];
-                    z[q] = z[q] + (v > 0.f ? v : 0.f) * wv[rr];
+                    zs[q] = zs[q] + (v > 0.f ? v : 0.f) * wv[rr];
                 }
             }
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) z[q] += __shfl_xor(z[q], 32, 64);           // the other half holds rows +4 of the same tile
-        if (hk == 0) *reinterpret_cast<float4*>(red + (nt * NTILE + mt * 32 + li) * 4) = make_float4(z[0], z[1], z[2], z[3]);
+        for (int q = 0; q < 4; ++q) zs[q] += __shfl_xor(zs[q], 32, 64);         // the other half holds rows +4 of the same tile
+        if (hk == 0) *reinterpret_cast<float4*>(red + (nt * NTILE + mt * 32 + li) * 4) = make_float4(zs[0], zs[1], zs[2], zs[3]);
         __syncthreads();
         const int tile = tid >> 2, q = tid & 3;
         const int uy = by * 2 * TB + 2 * (tile >> 3) + (q >> 1), ux = bx * 2 * TB + 2 * (tile & 7) + (q & 1);

@@ -175,8 +175,8 @@ def cpu_baseline(model, H, W, C, seed=0, fwd_div=1, max_threads=16):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5, help="untimed steps; the first ~4 steps after start-up run ~10 %% slower (allocator growth, clocks)")
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (README.md:125 batch size)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
@@ -224,8 +224,19 @@ def main():
         model.forward_eval(image, labels, acc.counts, acc.oob, acc.cond_ids(conds), want_logits=False, want_pred=False)
 
     with torch.no_grad():
+        def finish():
+            """Counters -> mIoUs (inside the timed region: the job is not done until the metric exists)."""
+            acc.all_reduce()
+            acc.check()
+            res = {"overall_miou": acc.miou(0)}
+            for k, name in enumerate(conds_all):
+                if acc.present(1 + k):
+                    res[f"miou_{name}"] = acc.miou(1 + k)
+            return res
+
         for i in range(args.warmup):
             step(i)
+        finish()                                  # warm the host-side finalisation too (first-use costs of the CPU ops)
         acc.counts.zero_()
         torch.cuda.synchronize()
         parallel.barrier()
@@ -233,12 +244,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             step(args.warmup + i)
-        acc.all_reduce()
-        acc.check()
-        results = {"overall_miou": acc.miou(0)}
-        for k, name in enumerate(conds_all):
-            if acc.present(1 + k):
-                results[f"miou_{name}"] = acc.miou(1 + k)
+        results = finish()
         torch.cuda.synchronize()
         parallel.barrier()
         dt = time.perf_counter() - t0

@@ -97,8 +97,8 @@ def algorithmic_work(name, B, H, W, C, info):
         return "hbm", (2048 * 4 + 3 * 2048 * 4) * h * w * B
     if name == "awseg_segformer_head_fused":           # executed MFMA flops: GEMM1 K=12 + GEMM2 N padded to 32
         return "mfma", 2.0 * (12 * 256 + 256 * 32) * px * B
-    if name == "awseg_upconv3x3_bn_relu":
-        return "mfma", 2.0 * (12 * 128) * px * B
+    if name == "awseg_upconv3x3_bn_relu":              # 24 MFMAs per 32 px, but 512 B/px of output: the write is the roofline
+        return "hbm", 128 * 4 * px * B
     return "hbm", 0
 
 

@@ -106,8 +106,8 @@ def main():
     cases["segformer_head_fused (MFMA)"] = (lambda: ops.segformer_head_fused(g9, None, sf, w2, b2, H, W), "mfma",
                                              2.0 * (12 * 256 + 256 * 32) * px * B)
     g9d = torch.randn(B, h, w, 9, 128, device=dev)
-    cases["upconv3x3_bn_relu 128ch NHWC (MFMA)"] = (lambda: ops.upconv3x3_bn_relu(g9d, None, sf[:128].contiguous(), H, W, True),
-                                                     "mfma", 2.0 * (12 * 128) * px * B)
+    cases["upconv3x3_bn_relu 128ch NHWC (512 B/px written)"] = (lambda: ops.upconv3x3_bn_relu(g9d, None, sf[:128].contiguous(), H, W, True),
+                                                                "hbm", 128 * 4 * px * B)
     xa = torch.randn(B, H // 16, W // 16, 2048, device=dev); wdw = torch.randn(3, 9, 2048, device=dev)
     cases["aspp_depthwise3"] = (lambda: ops.aspp_depthwise3(xa, wdw, (12, 24, 36)), "hbm", 4 * 2048 * 4 * (H // 16) * (W // 16) * B)
     xd = torch.randn(B, H // 4, W // 4, 128, device=dev); w9 = torch.randn(9, 128, device=dev); bb = torch.randn(128, device=dev)

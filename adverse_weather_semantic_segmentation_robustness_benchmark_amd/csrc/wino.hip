@@ -66,6 +66,12 @@ __device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_base)
 {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "m0");
 }
+// Same through a buffer descriptor: per-lane 32-bit byte offset + scalar byte offset, bounds-checked by the
+// hardware (an out-of-range lane reads zeros) — no 64-bit address arithmetic and no zero row for padding pixels.
+__device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "m0");
+}
 __device__ __forceinline__ void glds_wait() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 // the four youngest vector-memory operations (the next chunk's first weight fragments, issued after
 // the step's LDS-DMAs) may stay in flight across the barrier
@@ -136,10 +142,6 @@ __device__ __forceinline__ void xform_cols_store(const v2f (&t)[16], int i, floa
     for (int j = 0; j < 4; ++j) *reinterpret_cast<v2f*>(d + (i * 4 + j) * (KC * NTILE)) = v[j];
 }
 
-// Pixels outside the image are fetched from this row of zeros (the patch DMA's source address is per lane),
-// so the transform needs no per-pixel masking.
-__device__ float g_zero_row[4096 + 8];
-
 template <int MODE>   // 0 FULL, 1 HEAD1
 __global__ __launch_bounds__(WT, 1)
 void conv3x3_wino_kernel(wino_args a)
@@ -161,7 +163,8 @@ void conv3x3_wino_kernel(wino_args a)
     // 16-byte units.  Fetching every pixel once (instead of once per overlapping tile straight into
     // registers) keeps the texture-address path off the critical path: a scattered per-lane load costs
     // it one request per lane.  Pixels outside the image fetch a clamped address; the mask zeroes them.
-    const float* psrc[3];
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+    uint32_t pvoff[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int q = (wave + 4 * i) * 64 + lane;                   // destination slot
@@ -172,14 +175,15 @@ void conv3x3_wino_kernel(wino_args a)
         const int sy = by * 2 * TB - 1 + py, sx = bx * 2 * TB - 1 + px;
         const int y = ry + a.dil * sy, x = rx + a.dil * sx;
         const bool ok = sy >= 0 && sx >= 0 && y < a.H && x < a.W;
-        psrc[i] = (ok ? xb + ((size_t)y * a.W + x) * a.Cin : g_zero_row) + h * 4;
+        pvoff[i] = ok ? (uint32_t)(((y * a.W + x) * a.Cin + h * 4) * 4) : 0x80000000u;   // out of range -> zeros
     }
     const int n_pinstr = wave < 3 ? 3 : 2;                          // 11 wave instructions over 4 waves
-    auto glds_patch = [&](int chunk, float* dstbuf) {
-        const int coff = (chunk < nchunks ? chunk : nchunks - 1) * KC;
+    const uint32_t p_lds = __builtin_amdgcn_readfirstlane(lds_addr(sP) + wave * 1024);       // scalar LDS byte address of this wave's first slot run
+    auto glds_patch = [&](int chunk, int buf) {
+        const uint32_t soff = (uint32_t)((chunk < nchunks ? chunk : nchunks - 1) * KC * 4);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
-            if (i < n_pinstr) glds16(psrc[i] + coff, __builtin_amdgcn_readfirstlane(lds_addr(dstbuf + (wave + 4 * i) * 256)));
+            if (i < n_pinstr) bufdma16(x_rsrc, pvoff[i], soff, p_lds + (uint32_t)(buf * P_FLOATS * 4 + i * 4096));
     };
     // transform item of this thread: half hk = wave & 1 (channels 4*cp + 2*hk, +1 = k-steps 2cp, 2cp+1), tile =
     // 32*(wave>>1) + lane/2, cp = lane & 1; validity of its 4 x 4 pixels
@@ -209,8 +213,8 @@ void conv3x3_wino_kernel(wino_args a)
     const int mt = wave >> 1, nt = wave & 1, hk = lane >> 5, li = lane & 31;
     const int aoff = hk * (4 * NTILE) + (mt * 32 + li) * 4;
 
-    glds_patch(0, sP);
-    glds_patch(1, sP + P_FLOATS);
+    glds_patch(0, 0);
+    glds_patch(1, 1);
     glds_wait();
     __syncthreads();
     {
@@ -273,7 +277,7 @@ void conv3x3_wino_kernel(wino_args a)
         WINO_LOAD_A(0, a0)                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                     \
         /* group 0: MFMAs + LDS-DMA issue + operands of group 1 + raw patch reads */            \
-        glds_patch((C) + 2, sP + (BUF) * P_FLOATS);                                            \
+        glds_patch((C) + 2, (BUF));                                                            \
         WINO_LOAD_B(uc, 1, b1)                                                                 \
         WINO_LOAD_A(1, a1)                                                                     \
         patch_read(pp, r);                                                                     \
@@ -416,7 +420,7 @@ AWSEG_API int awseg_conv3x3_winograd_nhwc(const float* x, int batch, int height,
 {
     if (batch == 0) return 0;
     if (!x || !u || !shift || !out || batch < 0 || height < 1 || width < 1 || dilation < 1) return AWSEG_EINVAL;
-    if (cin < 2 * KC || (cin % (2 * KC)) || cin > 4096 || cout < NB || (cout % NB)) return AWSEG_ERANGE;
+    if (cin < 2 * KC || (cin % (2 * KC)) || cout < NB || (cout % NB)) return AWSEG_ERANGE;
     if ((w2 == nullptr) != (b2 == nullptr)) return AWSEG_EINVAL;
     if (w2 && (cout != NB || residual)) return AWSEG_ERANGE;          // the fused 1x1 head reduces over one 64-channel block
     if (act != AWSEG_ACT_NONE && act != AWSEG_ACT_RELU) return AWSEG_ERANGE;

@@ -194,7 +194,7 @@ def main():
 
     rank, local, world = parallel.init_from_env()
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local)
+    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))     # ranks beyond the device count share GPUs (rehearsal only)
     torch.cuda.set_device(dev)
     B, H, W, C = args.batch, args.height, args.width, 19
     conds_all = ["clean", "fog", "rain", "snow", "night"]

@@ -16,6 +16,7 @@
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 namespace {
 
@@ -23,8 +24,9 @@ struct plan {
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t a = nullptr, b = nullptr, c = nullptr;
     hipblasLtMatmulAlgo_t algo;
+    std::vector<hipblasLtMatmulAlgo_t> candidates;     // the heuristic's ranked list (awseg_gemm_tune times them)
     size_t ws = 0;
-    bool ok = false;
+    bool ok = false, tuned = false;
 };
 
 std::mutex g_mu;
@@ -42,7 +44,8 @@ plan* get_plan(int64_t M, int N, int K, int has_res, int act, size_t ws_bytes)
     hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
     hipblasLtEpilogue_t epi = act == AWSEG_ACT_RELU ? HIPBLASLT_EPILOGUE_RELU_BIAS : HIPBLASLT_EPILOGUE_BIAS;
     hipblasLtMatmulPreference_t pref = nullptr;
-    hipblasLtMatmulHeuristicResult_t res;
+    constexpr int kMaxCand = 24;
+    hipblasLtMatmulHeuristicResult_t res[kMaxCand];
     int found = 0;
     bool ok = hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) == HIPBLAS_STATUS_SUCCESS
            && hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) == HIPBLAS_STATUS_SUCCESS
@@ -57,11 +60,15 @@ plan* get_plan(int64_t M, int N, int K, int has_res, int act, size_t ws_bytes)
         // the bias pointer is part of the heuristic query's problem description: any non-null value will do here
         const void* dummy = reinterpret_cast<const void*>(uintptr_t(16));
         ok = hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &dummy, sizeof(dummy)) == HIPBLAS_STATUS_SUCCESS
-          && hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.c, pref, 1, &res, &found) == HIPBLAS_STATUS_SUCCESS
+          && hipblasLtMatmulAlgoGetHeuristic(g_handle, p.desc, p.a, p.b, p.c, p.c, pref, kMaxCand, res, &found) == HIPBLAS_STATUS_SUCCESS
           && found > 0;
     }
     if (pref) hipblasLtMatmulPreferenceDestroy(pref);
-    if (ok) { p.algo = res.algo; p.ws = res.workspaceSize; p.ok = true; }
+    if (ok) {
+        p.algo = res[0].algo; p.ws = res[0].workspaceSize; p.ok = true;
+        for (int i = 0; i < found; ++i)
+            if (res[i].state == HIPBLAS_STATUS_SUCCESS && res[i].workspaceSize <= ws_bytes) p.candidates.push_back(res[i].algo);
+    }
     auto ins = g_plans.emplace(key, p);
     return ins.first->second.ok ? &ins.first->second : nullptr;
 }
@@ -87,4 +94,44 @@ AWSEG_API int awseg_gemm_bias_act(const float* x, const float* w, const float* b
     const hipblasStatus_t st = hipblasLtMatmul(g_handle, p->desc, &alpha, w, p->a, x, p->b, &beta, residual ? residual : out, p->c,
                                                out, p->c, &p->algo, workspace, workspace_bytes, awseg_s(stream));
     return st == HIPBLAS_STATUS_SUCCESS ? 0 : AWSEG_EINVAL;
+}
+
+// Optional, explicit, SYNCHRONISING: time the library's ranked candidates for one problem on the caller's
+// buffers and keep the fastest for later awseg_gemm_bias_act calls of the same (M,N,K,residual,act,workspace).
+// `scratch_out` [M,N] is overwritten (it also stands in for the residual).  Returns the number of candidates
+// timed (>= 1), or a negative error.  Meant for warm-up; never called implicitly.
+AWSEG_API int awseg_gemm_tune(const float* x, const float* w, const float* bias, int has_residual, int act,
+                              float* scratch_out, int64_t m, int n, int k, void* workspace, size_t workspace_bytes,
+                              awseg_stream_t stream)
+{
+    if (!x || !w || !bias || !scratch_out || m < 1 || n < 1 || k < 1) return AWSEG_EINVAL;
+    plan* p = get_plan(m, n, k, has_residual ? 1 : 0, act, workspace_bytes);
+    if (!p) return AWSEG_ERANGE;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (p->tuned) return (int)p->candidates.size();
+    const void* bp = bias;
+    if (hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bp, sizeof(bp)) != HIPBLAS_STATUS_SUCCESS) return AWSEG_EINVAL;
+    const float alpha = 1.0f, beta = has_residual ? 1.0f : 0.0f;
+    hipStream_t s = awseg_s(stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return AWSEG_EINVAL;
+    float best = 1e30f;
+    int timed = 0;
+    for (const hipblasLtMatmulAlgo_t& cand : p->candidates) {
+        bool ok = true;
+        for (int rep = 0; rep < 4 && ok; ++rep) {                       // 1 warm + 3 timed
+            if (rep == 1) hipEventRecord(e0, s);
+            ok = hipblasLtMatmul(g_handle, p->desc, &alpha, w, p->a, x, p->b, &beta, scratch_out, p->c, scratch_out, p->c, &cand,
+                                 workspace, workspace_bytes, s) == HIPBLAS_STATUS_SUCCESS;
+        }
+        hipEventRecord(e1, s);
+        if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        ++timed;
+        if (ms < best) { best = ms; p->algo = cand; }
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    p->tuned = true;
+    return timed > 0 ? timed : AWSEG_ERANGE;
 }

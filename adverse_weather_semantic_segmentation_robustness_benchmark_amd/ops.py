@@ -6,6 +6,8 @@ current torch stream, never synchronise, and raise if handed CPU tensors.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Optional, Sequence
 
@@ -433,18 +435,33 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, shift: torch.Tensor, act:
 
 
 GEMM_WORKSPACE_BYTES = 32 << 20
+GEMM_TUNE = os.environ.get("AWSEG_GEMM_TUNE", "0") != "0"      # opt-in: time hipBLASLt's candidates once per new problem shape
+# (measured on the bench step: 102.0 vs 101.8 images/s — the library's first-ranked algorithm is already the fastest here)
+_gemm_tuned = set()
 
 
 def gemm_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int = 0, residual: Optional[torch.Tensor] = None,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x[M,K] @ w[N,K]^T + bias (+ residual[M,N])) in one hipBLASLt call (epilogue-fused); `out` may be `residual`."""
+    """act(x[M,K] @ w[N,K]^T + bias (+ residual[M,N])) in one hipBLASLt call (epilogue-fused); `out` may be `residual`.
+    With AWSEG_GEMM_TUNE=1 the first call of a new (M,N,K,residual,act) times the library's candidate algorithms
+    on a scratch output (synchronising, once) and keeps the fastest."""
     x, w = x.contiguous(), w.contiguous()
     m, k = x.shape
     n = w.shape[0]
+    bias = bias.contiguous()
+    ws = N.workspace.get(x.device, GEMM_WORKSPACE_BYTES, tag="gemm")
+    key = (str(x.device), m, n, k, residual is not None, act)
+    if GEMM_TUNE and m > 0 and key not in _gemm_tuned:
+        _gemm_tuned.add(key)
+        scratch = torch.empty(m, n, dtype=torch.float32, device=x.device)
+        rc = N.lib().awseg_gemm_tune(N.ptr(x), N.ptr(w), N.ptr(bias), int(residual is not None), act, N.ptr(scratch), m, n, k,
+                                     N.ptr(ws), GEMM_WORKSPACE_BYTES, N.stream())
+        if rc < 0:
+            N.check(rc, "awseg_gemm_tune")
+        del scratch
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=x.device)
-    ws = N.workspace.get(x.device, GEMM_WORKSPACE_BYTES, tag="gemm")
-    N.call("awseg_gemm_bias_act", N.ptr(x), N.ptr(w), N.ptr(bias.contiguous()), N.ptr(residual), act, N.ptr(out), m, n, k,
+    N.call("awseg_gemm_bias_act", N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(residual), act, N.ptr(out), m, n, k,
            N.ptr(ws), GEMM_WORKSPACE_BYTES, N.stream())
     return out
 

@@ -427,6 +427,15 @@ int awseg_gemm_bias_act(const float* x, const float* w, const float* bias, const
                         float* out, int64_t m, int n, int k, void* workspace, size_t workspace_bytes,
                         awseg_stream_t stream);
 
+/* awseg_gemm_tune: OPTIONAL and SYNCHRONISING (the only entry point that waits on the device) — times the
+ * library's ranked algorithm candidates for one awseg_gemm_bias_act problem on the caller's buffers and
+ * keeps the fastest for later calls with the same (M,N,K,residual,act,workspace_bytes).  scratch_out [M,N]
+ * is overwritten and also stands in for the residual.  Returns the number of candidates timed or < 0.
+ * Meant for a warm-up pass; awseg_gemm_bias_act never calls it. */
+int awseg_gemm_tune(const float* x, const float* w, const float* bias, int has_residual, int act,
+                    float* scratch_out, int64_t m, int n, int k, void* workspace, size_t workspace_bytes,
+                    awseg_stream_t stream);
+
 /* awseg_bias_act_nhwc: x = act(x + bias[c] (+ residual)) in place on float32 [n_pixels, C]:
  * the epilogue of a convolution whose eval-mode BatchNorm scale was folded into its weights
  * (Conv -> BN -> [+identity] -> ReLU of the ResNet bottlenecks behind PKG/models/model.py:349). */

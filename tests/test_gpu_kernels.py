@@ -613,3 +613,16 @@ def test_rain_zero_primitives_and_many_jobs(ops, oracle):
     ops.fog(dev(imgs), fj, noise=dev(fz), out=out)
     for b in (0, 16, 19):
         assert np.array_equal(out[b].cpu().numpy(), oracle.fog(imgs[b], oracle.synthetic_depth(fz[b]), 0.5))
+
+
+def test_gemm_tune_keeps_results(ops, native):
+    """awseg_gemm_tune (opt-in, synchronising) times hipBLASLt's candidates; whichever it keeps, results stay right."""
+    N = native
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.randn(8192, 128, device="cuda", generator=g); w = torch.randn(64, 128, device="cuda", generator=g) / 11.0
+    b = torch.randn(64, device="cuda", generator=g); scratch = torch.empty(8192, 64, device="cuda")
+    ws = N.workspace.get(x.device, ops.GEMM_WORKSPACE_BYTES, tag="gemm")
+    rc = N.lib().awseg_gemm_tune(N.ptr(x), N.ptr(w), N.ptr(b), 0, 1, N.ptr(scratch), 8192, 64, 128, N.ptr(ws), ops.GEMM_WORKSPACE_BYTES, N.stream())
+    assert rc >= 1
+    ref = (x.double() @ w.double().t() + b.double()).clamp_min(0)
+    assert (ops.gemm_bias_act(x, w, b, 1).double() - ref).abs().max().item() < 1e-4

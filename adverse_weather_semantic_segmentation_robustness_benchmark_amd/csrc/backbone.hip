@@ -116,6 +116,100 @@ void dwconv3x3_nhwc_strip_kernel(const float* __restrict__ x, int64_t batch, int
     }
 }
 
+// DeepLabV3+ decoder (smp DeepLabV3PlusDecoder.forward: up(aspp) -> cat with the 48-channel skip -> SeparableConv2d):
+// the depthwise 3x3 of block2 applied to cat(UpsamplingBilinear2d(x4, align_corners=True)(a), hi) WITHOUT
+// materialising the upsampled map or the concatenation (1.07 + 1.27 GB per batch at 1024x2048).  Same strip
+// scheme as above; a column of the first Ca channels is sampled from the stride-16 map with torch's
+// upsample_bilinear2d arithmetic (source index = dst * (in-1)/(out-1), value = l0*(w0*v00 + w1*v01) + l1*(w0*v10 + w1*v11)).
+template <int SX>
+__global__ __launch_bounds__(kThreads)
+void dwconv3x3_upcat_strip_kernel(const float* __restrict__ a, int h, int w, int Ca, const float* __restrict__ hi, int Ch,
+                                  int64_t batch, int H, int W, float ry, float rx, const float* __restrict__ w9,
+                                  float* __restrict__ out)
+{
+    const int C = Ca + Ch, c4n = C / 4, ca4 = Ca / 4;
+    const int nsx = (W + SX - 1) / SX;
+    const int64_t total = batch * H * nsx * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int xs = (int)(t % nsx); t /= nsx;
+        const int yy = (int)(t % H);
+        const int64_t b = t / H;
+        float4 k[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) k[j] = *reinterpret_cast<const float4*>(w9 + j * C + c4 * 4);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool up = c4 < ca4;
+        const float* ab = a + b * (int64_t)h * w * Ca + c4 * 4;
+        const float* hb = hi + b * (int64_t)H * W * Ch + (c4 - ca4) * 4;
+        // per-row sampling constants of the three tap rows
+        int r0[3], r1[3]; float l1[3], l0[3]; bool rok[3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int sy = yy + ky - 1;
+            rok[ky] = sy >= 0 && sy < H;
+            const float f = ry * (float)(rok[ky] ? sy : 0);
+            const int i0 = (int)f;
+            r0[ky] = i0; r1[ky] = i0 + (i0 < h - 1 ? 1 : 0);
+            l1[ky] = f - (float)i0; l0[ky] = 1.0f - l1[ky];
+        }
+        auto col = [&](int sx, float4* v) {
+            const bool cok = sx >= 0 && sx < W;
+            if (up) {
+                const float f = rx * (float)(cok ? sx : 0);
+                const int j0 = (int)f, j1 = j0 + (j0 < w - 1 ? 1 : 0);
+                const float m1 = f - (float)j0, m0 = 1.0f - m1;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (cok && rok[ky]) {
+                        const float4 v00 = *reinterpret_cast<const float4*>(ab + ((int64_t)r0[ky] * w + j0) * Ca);
+                        const float4 v01 = *reinterpret_cast<const float4*>(ab + ((int64_t)r0[ky] * w + j1) * Ca);
+                        const float4 v10 = *reinterpret_cast<const float4*>(ab + ((int64_t)r1[ky] * w + j0) * Ca);
+                        const float4 v11 = *reinterpret_cast<const float4*>(ab + ((int64_t)r1[ky] * w + j1) * Ca);
+                        float4 o;
+                        o.x = l0[ky] * (m0 * v00.x + m1 * v01.x) + l1[ky] * (m0 * v10.x + m1 * v11.x);
+                        o.y = l0[ky] * (m0 * v00.y + m1 * v01.y) + l1[ky] * (m0 * v10.y + m1 * v11.y);
+                        o.z = l0[ky] * (m0 * v00.z + m1 * v01.z) + l1[ky] * (m0 * v10.z + m1 * v11.z);
+                        o.w = l0[ky] * (m0 * v00.w + m1 * v01.w) + l1[ky] * (m0 * v10.w + m1 * v11.w);
+                        v[ky] = o;
+                    } else {
+                        v[ky] = zero;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int sy = yy + ky - 1;
+                    v[ky] = (cok && rok[ky]) ? *reinterpret_cast<const float4*>(hb + ((int64_t)sy * W + sx) * Ch) : zero;
+                }
+            }
+        };
+        const int x0 = xs * SX;
+        float4 c0[3], c1[3], c2[3];
+        col(x0 - 1, c0); col(x0, c1);
+#pragma unroll
+        for (int u = 0; u < SX; ++u) {
+            const int xx = x0 + u;
+            col(xx + 1, c2);
+            if (xx < W) {
+                float4 acc = zero;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float4 p = c0[ky], m = c1[ky], d = c2[ky];
+                    const float4 ka = k[ky * 3], km = k[ky * 3 + 1], kd = k[ky * 3 + 2];
+                    acc.x = fmaf(p.x, ka.x, acc.x); acc.y = fmaf(p.y, ka.y, acc.y); acc.z = fmaf(p.z, ka.z, acc.z); acc.w = fmaf(p.w, ka.w, acc.w);
+                    acc.x = fmaf(m.x, km.x, acc.x); acc.y = fmaf(m.y, km.y, acc.y); acc.z = fmaf(m.z, km.z, acc.z); acc.w = fmaf(m.w, km.w, acc.w);
+                    acc.x = fmaf(d.x, kd.x, acc.x); acc.y = fmaf(d.y, kd.y, acc.y); acc.z = fmaf(d.z, kd.z, acc.z); acc.w = fmaf(d.w, kd.w, acc.w);
+                }
+                *reinterpret_cast<float4*>(out + ((b * H + yy) * (int64_t)W + xx) * C + c4 * 4) = acc;
+            }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(kThreads)
 void bias_act_nhwc_kernel(float* __restrict__ x, int64_t n_pixels, int C, const float* __restrict__ bias,
                           const float* __restrict__ residual, int act)
@@ -250,6 +344,24 @@ AWSEG_API int awseg_layernorm_rows(const float* x, int64_t n_rows, int channels,
         default: AWSEG_LN(64); break;
     }
 #undef AWSEG_LN
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_width, int a_channels, const float* hi, int hi_channels,
+                                         int64_t batch, int height, int width, const float* w9, float* out, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!a || !hi || !w9 || !out || batch < 0 || height < 1 || width < 1 || a_height < 1 || a_width < 1) return AWSEG_EINVAL;
+    if (a_channels < 4 || (a_channels & 3) || hi_channels < 4 || (hi_channels & 3)) return AWSEG_ERANGE;
+    if (((uintptr_t)a & 15) || ((uintptr_t)hi & 15) || ((uintptr_t)w9 & 15) || ((uintptr_t)out & 15)) return AWSEG_EALIGN;
+    // torch: area_pixel_compute_scale(in, out, align_corners=true) = out > 1 ? (float)(in - 1) / (out - 1) : 0
+    const float ry = height > 1 ? (float)(a_height - 1) / (float)(height - 1) : 0.f;
+    const float rx = width > 1 ? (float)(a_width - 1) / (float)(width - 1) : 0.f;
+    constexpr int SX = 8;
+    const int64_t items = batch * height * ((width + SX - 1) / SX) * ((a_channels + hi_channels) / 4);
+    hipLaunchKernelGGL((dwconv3x3_upcat_strip_kernel<SX>), dim3(awseg_grid_1d(items, kThreads)), dim3(kThreads), 0, awseg_s(stream),
+                       a, a_height, a_width, a_channels, hi, hi_channels, batch, height, width, ry, rx, w9, out);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

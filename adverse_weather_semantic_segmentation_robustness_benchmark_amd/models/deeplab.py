@@ -224,10 +224,15 @@ class DeepLabV3PlusDecoder(nn.Module):
         from .. import _native as N
         a = self.aspp_fused(features[-1])
         a = fused.separable_bn_relu(a, self.aspp[1], self.aspp[2])          # SeparableConv2d -> BN -> ReLU
-        a = self.up(a)
         hi = fused.conv_bn_act(features[-4], self.block1[0], self.block1[1], N.ACT_RELU)
-        cat = torch.cat([a, hi], dim=1).contiguous(memory_format=torch.channels_last)
-        return fused.separable_bn_relu(cat, self.block2[0], self.block2[1])
+        # up x4 (align_corners=True) -> cat -> depthwise 3x3 in one HIP pass (no upsampled map, no concat), then the
+        # pointwise half of block2's SeparableConv2d with BN + ReLU in the GEMM epilogue
+        dwc, pwc = self.block2[0][0], self.block2[0][1]
+        d = ops.dwconv3x3_upcat(fused.nhwc_view(a), fused.nhwc_view(hi), fused.dw_taps(dwc))
+        B, H4, W4, Cc = d.shape
+        w, shift = fused.folded_conv_bn(pwc, self.block2[1])
+        y = ops.gemm_bias_act(d.view(B * H4 * W4, Cc), w.view(w.shape[0], Cc), shift, N.ACT_RELU)
+        return y.view(B, H4, W4, -1).permute(0, 3, 1, 2)
 
 
 class SegmentationHead(nn.Sequential):

@@ -466,6 +466,17 @@ def gemm_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int
     return out
 
 
+def dwconv3x3_upcat(a: torch.Tensor, hi: torch.Tensor, w9: torch.Tensor) -> torch.Tensor:
+    """depthwise3x3(cat(bilinear_up_align_corners(a -> hi's size), hi)) on NHWC tensors: a [B,h,w,Ca], hi [B,H,W,Ch],
+    w9 [9,Ca+Ch] -> [B,H,W,Ca+Ch] (DeepLabV3+ decoder, no intermediate tensors)."""
+    a, hi = a.contiguous(), hi.contiguous()
+    b, h, w, ca = a.shape
+    _, H, W, ch = hi.shape
+    out = torch.empty(b, H, W, ca + ch, dtype=torch.float32, device=a.device)
+    N.call("awseg_dwconv3x3_upcat_nhwc", N.ptr(a), h, w, ca, N.ptr(hi), ch, b, H, W, N.ptr(w9.contiguous()), N.ptr(out), N.stream())
+    return out
+
+
 def layernorm_rows(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     """torch.nn.functional.layer_norm over the last dimension for small channel counts (MiT tokens)."""
     x = x.contiguous()

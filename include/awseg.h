@@ -436,6 +436,14 @@ int awseg_gemm_tune(const float* x, const float* w, const float* bias, int has_r
                     float* scratch_out, int64_t m, int n, int k, void* workspace, size_t workspace_bytes,
                     awseg_stream_t stream);
 
+/* awseg_dwconv3x3_upcat_nhwc: the depthwise 3x3 (stride 1, zero padding 1, no bias) of the DeepLabV3+ decoder's
+ * block2 applied to cat(UpsamplingBilinear2d(align_corners=True)(a), hi) without materialising the upsampled
+ * map or the concatenation: a float32 [B,h,w,Ca] (the ASPP branch at stride 16), hi float32 [B,H,W,Ch] (the
+ * 48-channel skip at stride 4), w9 float32 [9 taps][Ca+Ch], out float32 [B,H,W,Ca+Ch].  Replaces the
+ * up -> cat -> depthwise part of smp's DeepLabV3PlusDecoder.forward behind PKG/models/model.py:349. */
+int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_width, int a_channels, const float* hi, int hi_channels,
+                               int64_t batch, int height, int width, const float* w9, float* out, awseg_stream_t stream);
+
 /* awseg_bias_act_nhwc: x = act(x + bias[c] (+ residual)) in place on float32 [n_pixels, C]:
  * the epilogue of a convolution whose eval-mode BatchNorm scale was folded into its weights
  * (Conv -> BN -> [+identity] -> ReLU of the ResNet bottlenecks behind PKG/models/model.py:349). */

@@ -626,3 +626,18 @@ def test_gemm_tune_keeps_results(ops, native):
     assert rc >= 1
     ref = (x.double() @ w.double().t() + b.double()).clamp_min(0)
     assert (ops.gemm_bias_act(x, w, b, 1).double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 8, 4), (1, 16, 32, 256, 48), (1, 3, 3, 4, 4)])
+def test_dwconv3x3_upcat_matches_torch(ops, shape):
+    """Decoder fusion: depthwise3x3(cat(UpsamplingBilinear2d(x4)(a), hi)) against the torch ops it replaces (1e-5)."""
+    B, h, w, Ca, Ch = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    a = torch.randn(B, Ca, h, w, device="cuda", generator=g)
+    hi = torch.randn(B, Ch, 4 * h, 4 * w, device="cuda", generator=g)
+    wdw = torch.randn(Ca + Ch, 1, 3, 3, device="cuda", generator=g)
+    cat = torch.cat([torch.nn.UpsamplingBilinear2d(scale_factor=4)(a), hi], dim=1)
+    ref = torch.nn.functional.conv2d(cat, wdw, padding=1, groups=Ca + Ch)
+    got = ops.dwconv3x3_upcat(a.permute(0, 2, 3, 1).contiguous(), hi.permute(0, 2, 3, 1).contiguous(), wdw.view(Ca + Ch, 9).t().contiguous())
+    assert (got.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-5
+

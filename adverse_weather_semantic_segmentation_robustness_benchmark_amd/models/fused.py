@@ -133,13 +133,24 @@ def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, 
 
 # --------------------------------------------------------------------------- ResNet encoder
 @torch.no_grad()
-def resnet_features(enc, x: torch.Tensor) -> List[torch.Tensor]:
-    """smp feature list [x, stem, layer1..layer4] of `deeplab.ResNetEncoder`, fused eval execution."""
+def resnet_features(enc, x: torch.Tensor, stem_feature: bool = False) -> List[torch.Tensor]:
+    """smp feature list [x, stem, layer1..layer4] of `deeplab.ResNetEncoder`, fused eval execution.
+    The DeepLabV3+ decoder never reads the stride-2 stem feature, so by default it is not produced (None in the
+    list) and the stem's `+shift -> ReLU` runs AFTER the max-pool, on a quarter of the pixels: both are monotone
+    per channel, so maxpool(relu(x + b)) == relu(maxpool(x) + b) bit for bit."""
     x = x.contiguous(memory_format=CL)
     feats = [x]
-    y = conv_bn_act(x, enc.conv1, enc.bn1, N.ACT_RELU)
-    feats.append(y)
-    y = enc.maxpool(y)
+    if stem_feature:
+        y = conv_bn_act(x, enc.conv1, enc.bn1, N.ACT_RELU)
+        feats.append(y)
+        y = enc.maxpool(y)
+    else:
+        w, shift = folded_conv_bn(enc.conv1, enc.bn1)
+        y = enc.maxpool(F.conv2d(x, w, None, enc.conv1.stride, enc.conv1.padding))
+        if not y.is_contiguous(memory_format=CL):
+            y = y.contiguous(memory_format=CL)
+        ops.bias_act_nhwc_(y.permute(0, 2, 3, 1), shift, None, N.ACT_RELU)
+        feats.append(None)
     for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
         for blk in layer:
             out = conv_bn_act(y, blk.conv1, blk.bn1, N.ACT_RELU)

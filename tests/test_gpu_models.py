@@ -199,13 +199,18 @@ def test_resnet_fused_matches_modules(P):
     x = torch.randn(1, 3, 96, 128, device="cuda")
     with torch.no_grad():
         ref = enc(x)
-        got = fused.resnet_features(enc, x)
+        got = fused.resnet_features(enc, x, stem_feature=True)
+        lean = fused.resnet_features(enc, x)                    # default: stem feature skipped, stem epilogue after the max-pool
     for a, b in zip(got[1:], ref[1:]):
         assert a.shape == b.shape and rel_err(a, b) < 1e-4
+    assert lean[1] is None
+    for a, b in zip(lean[2:], got[2:]):
+        # maxpool(relu(x+b)) == relu(maxpool(x)+b) exactly; what remains is MIOpen's run-to-run summation order
+        assert rel_err(a, b) < 1e-5
     # fold cache follows in-place weight updates
     with torch.no_grad():
         enc.conv1.weight.mul_(0.5)
-        assert rel_err(fused.resnet_features(enc, x)[1], enc(x)[1]) < 1e-4
+        assert rel_err(fused.resnet_features(enc, x, stem_feature=True)[1], enc(x)[1]) < 1e-4
 
 
 def test_ensemble_eval_stats_matches_reference_expressions(P, oracle):

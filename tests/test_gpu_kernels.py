@@ -641,3 +641,16 @@ def test_dwconv3x3_upcat_matches_torch(ops, shape):
     got = ops.dwconv3x3_upcat(a.permute(0, 2, 3, 1).contiguous(), hi.permute(0, 2, 3, 1).contiguous(), wdw.view(Ca + Ch, 9).t().contiguous())
     assert (got.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-5
 
+
+def test_aspp_depthwise3_xcd_sliced_path(ops):
+    """The XCD-aware (image, 64-channel slice) work order of the ASPP depthwise kernel (C % 64 == 0), real rates."""
+    torch.manual_seed(1)
+    B, h, w, Cc = 2, 40, 52, 128
+    x = torch.randn(B, Cc, h, w, device="cuda")
+    wdw = torch.randn(3, Cc, 1, 3, 3, device="cuda")
+    rates = (12, 24, 36)
+    out = ops.aspp_depthwise3(x.permute(0, 2, 3, 1).contiguous(), wdw.reshape(3, Cc, 9).permute(0, 2, 1).contiguous(), rates)
+    for r in range(3):
+        ref = torch.nn.functional.conv2d(x, wdw[r], padding=rates[r], dilation=rates[r], groups=Cc)
+        assert (out[r].permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-4
+

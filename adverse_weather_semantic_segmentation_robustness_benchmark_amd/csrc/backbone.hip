@@ -15,22 +15,6 @@ namespace {
 
 constexpr int kThreads = 256;
 
-// XCD-aware grid-stride: consecutive block ids alternate over the 8 XCDs (each with its own L2), so the item range
-// is cut into 8 contiguous chunks and block b works on chunk b % 8 — neighbouring rows of a stencil are then read
-// through ONE L2 instead of up to three.  Returns the [begin, end) and stride of this thread's walk.
-struct xcd_walk { int64_t i, end, stride; };
-__device__ __forceinline__ xcd_walk xcd_range(int64_t total)
-{
-    const int xcd = blockIdx.x & 7;
-    const int64_t per = (total + 7) / 8;
-    xcd_walk wk;
-    const int64_t lo = per * xcd, hi = lo + per < total ? lo + per : total;
-    wk.i = lo + (int64_t)(blockIdx.x >> 3) * kThreads + threadIdx.x;
-    wk.end = hi;
-    wk.stride = (int64_t)(gridDim.x >> 3) * kThreads;
-    return wk;
-}
-
 __device__ __forceinline__ float act1(float v, int act)
 {
     if (act == 1) return v > 0.f ? v : 0.f;
@@ -88,8 +72,7 @@ void dwconv3x3_nhwc_strip_kernel(const float* __restrict__ x, int64_t batch, int
     const int c4n = C / 4;
     const int nsx = (W + SX - 1) / SX;
     const int64_t total = batch * H * nsx * c4n;
-    const xcd_walk wk = xcd_range(total);
-    for (int64_t i = wk.i; i < wk.end; i += wk.stride) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         const int c4 = (int)(i % c4n);
         int64_t t = i / c4n;
         const int xs = (int)(t % nsx); t /= nsx;
@@ -147,8 +130,7 @@ void dwconv3x3_upcat_strip_kernel(const float* __restrict__ a, int h, int w, int
     const int C = Ca + Ch, c4n = C / 4, ca4 = Ca / 4;
     const int nsx = (W + SX - 1) / SX;
     const int64_t total = batch * H * nsx * c4n;
-    const xcd_walk wk = xcd_range(total);
-    for (int64_t i = wk.i; i < wk.end; i += wk.stride) {
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
         const int c4 = (int)(i % c4n);
         int64_t t = i / c4n;
         const int xs = (int)(t % nsx); t /= nsx;
@@ -317,7 +299,7 @@ AWSEG_API int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, in
     if (dilation == 1 && width >= 8) {
         constexpr int SX = 8;
         const int64_t total = batch * height * ((width + SX - 1) / SX) * (channels / 4);
-        hipLaunchKernelGGL((dwconv3x3_nhwc_strip_kernel<SX>), dim3((awseg_grid_1d(total, kThreads) + 7) & ~7), dim3(kThreads), 0, awseg_s(stream),   // multiple of 8: xcd_range
+        hipLaunchKernelGGL((dwconv3x3_nhwc_strip_kernel<SX>), dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream),
                            x, batch, height, width, channels, w9, bias, act, out);
         AWSEG_LAUNCH_CHECK();
         return 0;
@@ -378,7 +360,7 @@ AWSEG_API int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_wid
     const float rx = width > 1 ? (float)(a_width - 1) / (float)(width - 1) : 0.f;
     constexpr int SX = 8;
     const int64_t items = batch * height * ((width + SX - 1) / SX) * ((a_channels + hi_channels) / 4);
-    hipLaunchKernelGGL((dwconv3x3_upcat_strip_kernel<SX>), dim3((awseg_grid_1d(items, kThreads) + 7) & ~7), dim3(kThreads), 0, awseg_s(stream),   // multiple of 8: xcd_range
+    hipLaunchKernelGGL((dwconv3x3_upcat_strip_kernel<SX>), dim3(awseg_grid_1d(items, kThreads)), dim3(kThreads), 0, awseg_s(stream),
                        a, a_height, a_width, a_channels, hi, hi_channels, batch, height, width, ry, rx, w9, out);
     AWSEG_LAUNCH_CHECK();
     return 0;

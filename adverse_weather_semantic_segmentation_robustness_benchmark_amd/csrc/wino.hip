@@ -48,7 +48,7 @@ constexpr int LDS_FLOATS = 2 * V_FLOATS + 2 * P_FLOATS;   // 92 KB: transformed 
 struct wino_args {
     const float* x; const float* U; const float* shift; const float* residual; const float* w2; const float* b2;
     float* out;
-    int H, W, Cin, Cout, dil, act, nbx, nby, ngroups;
+    int H, W, Cin, Cout, dil, act, nbx, nby, ngroups, batch;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act)
@@ -149,9 +149,16 @@ void conv3x3_wino_kernel(wino_args a)
     extern __shared__ float smem[];
     float* sV = smem;                        // [2][16][KC][NTILE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int bx = blockIdx.x % a.nbx, rx = blockIdx.x / a.nbx;
-    const int by = blockIdx.y % a.nby, ry = blockIdx.y / a.nby;
-    const int ng = blockIdx.z % a.ngroups, b = blockIdx.z / a.ngroups;
+    // 1-D grid, XCD-aware: consecutive block ids alternate over the 8 XCDs (one L2 each).  Spatial tile t goes to
+    // XCD t % 8 and its cout groups run back to back there, so the groups share the tile's input patch in that L2
+    // instead of each fetching it again.
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ng = jj % a.ngroups, t = (jj / a.ngroups) * 8 + xcd;
+    const int gx = a.nbx * a.dil, gy = a.nby * a.dil;
+    if (t >= gx * gy * a.batch) return;
+    const int b = t / (gx * gy), txy = t - b * (gx * gy), tyy = txy / gx, txx = txy - tyy * gx;
+    const int bx = txx % a.nbx, rx = txx / a.nbx;
+    const int by = tyy % a.nby, ry = tyy / a.nby;
     const int Hs = (a.H - ry + a.dil - 1) / a.dil, Ws = (a.W - rx + a.dil - 1) / a.dil;   // sub-grid extent of this residue
     if (by * 2 * TB >= Hs || bx * 2 * TB >= Ws) return;
     const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
@@ -406,8 +413,10 @@ int launch_wino(const wino_args& a, int batch, hipStream_t s)
     const size_t lds = (size_t)LDS_FLOATS * sizeof(float);
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    dim3 grid((unsigned)(a.nbx * a.dil), (unsigned)(a.nby * a.dil), (unsigned)(batch * a.ngroups));
-    hipLaunchKernelGGL(kern, grid, dim3(WT), lds, s, a);
+    const int64_t tiles = (int64_t)a.nbx * a.dil * a.nby * a.dil * batch;
+    const int64_t nblocks = ((tiles + 7) / 8) * a.ngroups * 8;
+    if (nblocks >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WT), lds, s, a);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -430,7 +439,6 @@ AWSEG_API int awseg_conv3x3_winograd_nhwc(const float* x, int batch, int height,
     a.x = x; a.U = u; a.shift = shift; a.residual = residual; a.w2 = w2; a.b2 = b2; a.out = out;
     a.H = height; a.W = width; a.Cin = cin; a.Cout = cout; a.dil = dilation; a.act = act;
     const int hs = (height + dilation - 1) / dilation, ws = (width + dilation - 1) / dilation;
-    a.nbx = (ws + 2 * TB - 1) / (2 * TB); a.nby = (hs + 2 * TB - 1) / (2 * TB); a.ngroups = cout / NB;
-    if ((int64_t)batch * a.ngroups > 65535 || (int64_t)a.nby * dilation > 65535) return AWSEG_ERANGE;
+    a.nbx = (ws + 2 * TB - 1) / (2 * TB); a.nby = (hs + 2 * TB - 1) / (2 * TB); a.ngroups = cout / NB; a.batch = batch;
     return w2 ? launch_wino<1>(a, batch, awseg_s(stream)) : launch_wino<0>(a, batch, awseg_s(stream));
 }

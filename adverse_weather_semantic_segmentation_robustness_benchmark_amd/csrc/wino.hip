@@ -15,15 +15,16 @@
 // 32*mt.. and couts 32*nt.., all 16 positions -> 16 accumulator tiles of 32x32 (256 AGPRs per
 // lane, one wave per SIMD).  Input channels stream in chunks of 8 (four k-steps):
 //   * the chunk's raw 18x18-pixel patch is LDS-DMA'd once (every pixel fetched once, not once per
-//     overlapping tile), two chunks ahead, into a bank-swizzled image;
-//   * each thread turns one (tile, 2 channels) of it into V with ds_read_b64 / ds_write_b64, a
-//     quarter of that work riding behind each group of 16 MFMAs of the previous chunk;
+//     overlapping tile) two chunks ahead, through a buffer descriptor: per-lane 32-bit offsets, a
+//     scalar chunk offset, and the hardware bounds check supplies the zero padding;
+//   * each thread turns one (tile, 2 adjacent channels) of it into V with ds_read_b64, packed
+//     v_pk_add_f32 (kept packed by inline asm) and ds_write_b64, a quarter of that work riding
+//     behind each group of 16 MFMAs of the previous chunk;
 //   * A fragments come from V by ds_read_b128 (four k-steps per read), B fragments straight from L2
-//     (the host stores U as the fragment image), both one position group ahead of their MFMAs.
-// What the measurements said on the way: per-lane scattered input loads made the
-// texture-address path the bottleneck (41 % of peak -> 52 %); the LDS-DMA builtin makes hipcc wait
-// vmcnt(0) before the next ds_read (inline asm instead); an LDS-DMA instruction costs the issuing
-// wave a few hundred cycles, so the weights go to registers directly (52 % -> 58 %).
+//     through a buffer descriptor with scalar offsets (the host stores U as the fragment image),
+//     both one position group ahead of their MFMAs.
+// fp32-input MFMA runs at the vector rate and vector instructions do NOT hide behind it — the loop
+// was tuned by removing them (DESIGN.md §5a has the measurements and the ablation builds).
 // Epilogues: FULL  out[b,y,x,n] = act(Y + shift[n] (+ residual))            (NHWC)
 //            HEAD1 out[b,y,x]   = sigmoid(b2 + sum_n w2[n] * relu(Y + shift[n]))   (Cout == 64)
 #include "awseg_common.h"

@@ -337,8 +337,29 @@ void conv3x3_wino_kernel(wino_args a)
     // Two accumulator rows at a time: rows r, r+1 of one position sit in adjacent registers, so the inverse
     // transform (24 adds per row) runs as packed 2-vector adds.
     if (MODE == 0) {
+        // Stores (and residual loads) go through buffer descriptors: the pixel part of the address is a SCALAR
+        // per (row, aa, bb) — tile row / column come from the compile-time accumulator row and the wave-uniform
+        // m-tile — and the lane part (cout, and the 4-tile column shift of the upper half-wave) is one VGPR per
+        // (r & 3, bb) with the x-bound folded in as an out-of-range VECTOR offset (the part the hardware range check is defined
+        // on); the y-bound is a scalar branch.  No per-store
+        // vector address arithmetic.
         const int n = n0 + nt * 32 + li;
         const float sh = a.shift[n];
+        const size_t img = (size_t)a.H * a.W * a.Cout;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img), 0, (int)(img * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual ? a.residual + (size_t)b * img : a.out), 0, (int)(img * 4), 0x00020000);
+        const bool has_res = a.residual != nullptr;
+        const int mt_u = __builtin_amdgcn_readfirstlane(mt);
+        const uint32_t kOob = 0x80000000u;
+        uint32_t vsel[4][2];                               // lane byte offset for column (r & 3, bb), or out of range
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int xs = rx + a.dil * (bx * 2 * TB + 2 * c + bb);          // scalar part of x
+                const int xl = a.dil * 8 * hk;                                   // the upper half-wave sits 4 tiles to the right
+                vsel[c][bb] = (xs + xl < a.W) ? (uint32_t)((xl * a.Cout + n) * 4) : kOob;
+            }
 #pragma unroll
         for (int r = 0; r < 16; r += 2) {
             v2f m[4][4];
@@ -352,20 +373,21 @@ void conv3x3_wino_kernel(wino_args a)
             y[1][0] = t1[0] + t1[1] + t1[2]; y[1][1] = t1[1] - t1[2] - t1[3];
 #pragma unroll
             for (int e = 0; e < 2; ++e) {
-                const int tile = mt * 32 + ((r + e) & 3) + 8 * ((r + e) >> 2) + 4 * hk;
-                const int uy = by * 2 * TB + 2 * (tile >> 3), ux = bx * 2 * TB + 2 * (tile & 7);
+                const int rr = r + e;
+                const int ty = mt_u * 4 + (rr >> 2), c = rr & 3;                 // tile row (scalar), tile column within the half
 #pragma unroll
-                for (int aa = 0; aa < 2; ++aa)
+                for (int aa = 0; aa < 2; ++aa) {
+                    const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + aa);
+                    if (yy >= a.H) continue;                                     // wave-uniform: a scalar branch
 #pragma unroll
                     for (int bb = 0; bb < 2; ++bb) {
-                        const int yy = ry + a.dil * (uy + aa), xx = rx + a.dil * (ux + bb);
-                        if (yy < a.H && xx < a.W) {
-                            const int64_t o = (((int64_t)b * a.H + yy) * a.W + xx) * a.Cout + n;
-                            float v = y[aa][bb][e] + sh;
-                            if (a.residual) v += a.residual[o];
-                            a.out[o] = act_apply(v, a.act);
-                        }
+                        const int xs = rx + a.dil * (bx * 2 * TB + 2 * c + bb);
+                        const uint32_t soff = (uint32_t)((yy * a.W + xs) * a.Cout * 4);   // always in range; x-bound is in vsel
+                        float v = y[aa][bb][e] + sh;
+                        if (has_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vsel[c][bb], soff, 0));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, act_apply(v, a.act)), o_rsrc, vsel[c][bb], soff, 0);
                     }
+                }
             }
         }
     } else {

@@ -1,0 +1,164 @@
+// attn.hip — the self-attention of the MiT encoder (transformers SegformerEfficientSelfAttention inside
+// PKG/models/model.py:193's SegformerModel call) for head_dim 32 in exact fp32 on the matrix cores:
+//     O = softmax(Q K^T * scale) V          Q [B,Nq,heads*32], K/V [B,Nkv,heads*32] (token-major, as the
+//                                           q/k/v Linear layers write them), O in the same layout.
+// MiT-B0 has head_dim 32 in every stage and, at 1024x2048, 2048 keys per image after the strided reduction;
+// the queries are what is large (131072 tokens in stage 1).
+//
+// Flash-style, one pass over the keys, both GEMMs on v_mfma_f32_32x32x2_f32, written around one fact measured on
+// the Winograd kernel: fp32-input MFMA runs at the vector rate and VALU work does not hide behind
+// it, so the softmax must cost as few vector instructions as possible:
+//   * S^T = K Q^T is computed TRANSPOSED (keys on the accumulator rows, queries on its columns): a lane owns one
+//     query, its 16 accumulator registers are 16 keys -> row max / row sum are in-register, plus ONE cross-half
+//     shuffle each, instead of a 32-lane butterfly per query;
+//   * the exponentiated tile P^T is, register for register, the B operand of the second GEMM O^T += V^T P^T
+//     (lane = query column, register r of the two wave halves = keys row(r,0), row(r,1)); V^T is staged in LDS in
+//     exactly that key order, so nothing is transposed or round-tripped;
+//   * exp is one v_exp_f32 per element (log2 e folded into the query scale), the running maximum starts at a
+//     large negative finite value (no inf - inf).
+// Block = 128 queries of one (image, head): 4 waves x 32 queries, all waves sharing the K / V^T tiles (32 keys,
+// double-buffered in LDS, register-prefetched one tile ahead).
+#include "awseg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int AT = 256;          // threads
+constexpr int D = 32;            // head dim
+constexpr int TK = 32;           // keys per tile
+constexpr int LDK = 36;          // padded row length (floats): conflict-free ds_read_b128 at a 144-byte lane stride
+
+// accumulator row of register r in wave half hk
+__device__ __forceinline__ constexpr int acc_row(int r, int hk) { return (r & 3) + 8 * (r >> 2) + 4 * hk; }
+
+__global__ __launch_bounds__(AT, 2)
+void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                          float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+{
+    __shared__ float sK[2][TK * LDK];       // [key][hk*16 + s]   = K[key][2s + hk]
+    __shared__ float sV[2][D * LDK];        // [d][hk*16 + r]     = V[row(r,hk)][d]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int C = heads * D;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float* kb = k + ((size_t)b * nkv * heads + h) * D;
+    const float* vb = v + ((size_t)b * nkv * heads + h) * D;
+
+    // Q fragment: B operand of S^T = K Q^T, B[k = d][j = query]: lane (j = li, half hk) holds d = 2s + hk
+    float qf[16];
+    {
+        const int qi = q0 + li;
+        const float* qp = q + ((size_t)b * nq + (qi < nq ? qi : nq - 1)) * C + h * D;
+#pragma unroll
+        for (int s4 = 0; s4 < 8; ++s4) {
+            const float4 t4 = *reinterpret_cast<const float4*>(qp + 4 * s4);       // d = 4*s4 .. 4*s4+3
+            qf[2 * s4] = (hk ? t4.y : t4.x) * scale_log2e;                          // d = 4*s4 + hk
+            qf[2 * s4 + 1] = (hk ? t4.w : t4.z) * scale_log2e;                      // d = 4*s4 + 2 + hk
+        }
+    }
+    // tile staging role of this thread: key = tid / 8, 4 consecutive d = 4c..4c+3
+    const int lkey = tid >> 3, lc = tid & 7;
+    const size_t g_off = (size_t)lkey * C + 4 * lc;
+    const int wk0 = lkey * LDK + 2 * lc;                 // sK: (d = 4c, 4c+2) -> hk 0, s = 2c, 2c+1 ; (4c+1, 4c+3) -> hk 1
+    const int vkk = (lkey >> 2) & 1, vr = (lkey & 3) + 4 * (lkey >> 3);             // inverse of acc_row
+    const int wv0 = (4 * lc) * LDK + vkk * 16 + vr;      // sV[d = 4c + e][vkk*16 + vr], e = 0..3
+    auto stage = [&](int buf, const float4& kk4, const float4& vv4) {
+        *reinterpret_cast<float2*>(&sK[buf][wk0]) = make_float2(kk4.x, kk4.z);
+        *reinterpret_cast<float2*>(&sK[buf][wk0 + 16]) = make_float2(kk4.y, kk4.w);
+        sV[buf][wv0] = vv4.x; sV[buf][wv0 + LDK] = vv4.y; sV[buf][wv0 + 2 * LDK] = vv4.z; sV[buf][wv0 + 3 * LDK] = vv4.w;
+    };
+    const int ntiles = nkv / TK;
+    float4 kreg = *reinterpret_cast<const float4*>(kb + g_off), vreg = *reinterpret_cast<const float4*>(vb + g_off);
+    stage(0, kreg, vreg);
+    if (ntiles > 1) {
+        kreg = *reinterpret_cast<const float4*>(kb + (size_t)TK * C + g_off);
+        vreg = *reinterpret_cast<const float4*>(vb + (size_t)TK * C + g_off);
+    }
+    __syncthreads();
+
+    f32x16 oacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const int a_off = li * LDK + hk * 16;                // this lane's 16 contiguous operand floats in a tile row
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        // ---- S^T = K Q^T for this tile: rows = 32 keys, columns = this wave's 32 queries
+        float kf[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&sK[buf][a_off + 4 * j]);
+            kf[4 * j] = t4.x; kf[4 * j + 1] = t4.y; kf[4 * j + 2] = t4.z; kf[4 * j + 3] = t4.w;
+        }
+        f32x16 sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[s], qf[s], sacc, 0, 0, 0);
+        // ---- the next tile's V^T fragments do not depend on the softmax: fetch them now
+        float vf[16];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 t4 = *reinterpret_cast<const float4*>(&sV[buf][a_off + 4 * j]);
+            vf[4 * j] = t4.x; vf[4 * j + 1] = t4.y; vf[4 * j + 2] = t4.z; vf[4 * j + 3] = t4.w;
+        }
+        // ---- online softmax, one query per lane (its keys: 16 registers here + 16 in the other wave half)
+        float mt = fmaxf(fmaxf(sacc[0], sacc[1]), fmaxf(sacc[2], sacc[3]));
+#pragma unroll
+        for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(sacc[r], sacc[r + 1]), fmaxf(sacc[r + 2], sacc[r + 3])));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float p[16], ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(sacc[r] - m_new); ls += p[r]; }
+        ls += __shfl_xor(ls, 32, 64);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+        // ---- O^T += V^T P^T: A = V^T [d][key], B = P^T — the accumulator tile itself, register r = k-step r
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], p[r], oacc, 0, 0, 0);
+        // ---- stage tile t+1 (already in registers) into the other buffer, prefetch tile t+2
+        if (t + 1 < ntiles) {
+            stage(buf ^ 1, kreg, vreg);
+            if (t + 2 < ntiles) {
+                kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * C + g_off);
+                vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * C + g_off);
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- O = O^T / l: lane = query li, registers = d rows; rows 4g..4g+3 of a half are 4 consecutive d
+    const int qi = q0 + li;
+    if (qi < nq) {
+        const float inv = 1.0f / l_run;
+        float* op = out + ((size_t)b * nq + qi) * C + h * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(op + 8 * g + 4 * hk) =
+                make_float4(oacc[4 * g] * inv, oacc[4 * g + 1] * inv, oacc[4 * g + 2] * inv, oacc[4 * g + 3] * inv);
+    }
+}
+
+}  // namespace
+
+AWSEG_API int awseg_attention_d32(const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                                  int n_queries, int n_keys, float scale, awseg_stream_t stream)
+{
+    if (batch == 0 || n_queries == 0) return 0;
+    if (!q || !k || !v || !out || batch < 0 || heads < 1 || n_queries < 0 || n_keys < TK) return AWSEG_EINVAL;
+    if (n_keys % TK) return AWSEG_ERANGE;                 // whole key tiles only (MiT: the key grid is (H/32) x (W/32) ... x sr^-2)
+    if (heads > 65535 || batch > 65535) return AWSEG_ERANGE;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15)) return AWSEG_EALIGN;
+    dim3 grid((unsigned)((n_queries + 127) / 128), (unsigned)heads, (unsigned)batch);
+    hipLaunchKernelGGL(attention_d32_kernel, grid, dim3(AT), 0, awseg_s(stream), q, k, v, out, n_queries, n_keys, heads,
+                       scale * 1.4426950408889634f);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

@@ -17,7 +17,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent
 PKG = CSRC.parent
 LIB = PKG / "libawseg_hip.so"
-SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "backbone.hip", "depth.hip", "wino.hip", "gemm.hip"]
+SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "backbone.hip", "depth.hip", "wino.hip", "gemm.hip", "attn.hip"]
 ARCH = "gfx950"
 
 

@@ -120,18 +120,18 @@ AWSEG_API int awseg_gemm_tune(const float* x, const float* w, const float* bias,
     for (const hipblasLtMatmulAlgo_t& cand : p->candidates) {
         bool ok = true;
         for (int rep = 0; rep < 4 && ok; ++rep) {                       // 1 warm + 3 timed
-            if (rep == 1) hipEventRecord(e0, s);
+            if (rep == 1) (void)hipEventRecord(e0, s);
             ok = hipblasLtMatmul(g_handle, p->desc, &alpha, w, p->a, x, p->b, &beta, scratch_out, p->c, scratch_out, p->c, &cand,
                                  workspace, workspace_bytes, s) == HIPBLAS_STATUS_SUCCESS;
         }
-        hipEventRecord(e1, s);
+        (void)hipEventRecord(e1, s);
         if (hipEventSynchronize(e1) != hipSuccess || !ok) continue;
         float ms = 0.f;
-        hipEventElapsedTime(&ms, e0, e1);
+        (void)hipEventElapsedTime(&ms, e0, e1);
         ++timed;
         if (ms < best) { best = ms; p->algo = cand; }
     }
-    hipEventDestroy(e0); hipEventDestroy(e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     p->tuned = true;
     return timed > 0 ? timed : AWSEG_ERANGE;
 }

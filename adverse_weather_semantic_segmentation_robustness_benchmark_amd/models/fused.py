@@ -222,10 +222,16 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
             k = F.linear(kv, a.k_proj.weight, a.k_proj.bias)
             v = F.linear(kv, a.v_proj.weight, a.v_proj.bias)
             nh, d = a.num_attention_heads, a.head_dim
-            o = F.scaled_dot_product_attention(q.view(B, H * W, nh, d).transpose(1, 2), k.reshape(B, -1, nh, d).transpose(1, 2),
-                                               v.reshape(B, -1, nh, d).transpose(1, 2), scale=a.scaling)
+            nkv = kv.shape[1] * kv.shape[2]
+            if d == 32 and nkv % 32 == 0:
+                # exact-fp32 flash attention on the matrix cores, token-major in and out (no head transposes)
+                o = ops.attention_d32(q.view(B, H * W, C), k.reshape(B, nkv, C), v.reshape(B, nkv, C), nh, a.scaling).view(B * H * W, C)
+            else:
+                o = F.scaled_dot_product_attention(q.view(B, H * W, nh, d).transpose(1, 2), k.reshape(B, -1, nh, d).transpose(1, 2),
+                                                   v.reshape(B, -1, nh, d).transpose(1, 2), scale=a.scaling)
+                o = o.transpose(1, 2).reshape(B * H * W, C)
             # tok + o_proj(o): the residual is the GEMM's beta*C operand, accumulated over tok's buffer
-            tok = _linear_residual(o.transpose(1, 2).reshape(B * H * W, C), a.o_proj, tok)
+            tok = _linear_residual(o, a.o_proj, tok)
             m = blk.mlp
             hcur = F.linear(_ln(tok, blk.layernorm_after), m.fc1.weight, m.fc1.bias)
             if getattr(seg.config, "hidden_act", "gelu") == "gelu":

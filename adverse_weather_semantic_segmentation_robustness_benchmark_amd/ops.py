@@ -477,6 +477,15 @@ def dwconv3x3_upcat(a: torch.Tensor, hi: torch.Tensor, w9: torch.Tensor) -> torc
     return out
 
 
+def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """softmax(q k^T * scale) v for head_dim 32: q [B,Nq,heads*32], k / v [B,Nkv,heads*32] (token-major) -> [B,Nq,heads*32]."""
+    q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+    b, nq, c = q.shape
+    out = torch.empty_like(q)
+    N.call("awseg_attention_d32", N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), b, heads, nq, k.shape[1], float(scale), N.stream())
+    return out
+
+
 def layernorm_rows(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     """torch.nn.functional.layer_norm over the last dimension for small channel counts (MiT tokens)."""
     x = x.contiguous()

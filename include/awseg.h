@@ -444,6 +444,14 @@ int awseg_gemm_tune(const float* x, const float* w, const float* bias, int has_r
 int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_width, int a_channels, const float* hi, int hi_channels,
                                int64_t batch, int height, int width, const float* w9, float* out, awseg_stream_t stream);
 
+/* awseg_attention_d32: O = softmax(Q K^T * scale) V for head_dim 32 in exact float32 on the matrix cores — the
+ * self-attention of the MiT encoder (transformers' SegformerEfficientSelfAttention inside the SegformerModel call at
+ * PKG/models/model.py:193).  q float32 [batch, n_queries, heads*32], k / v float32 [batch, n_keys, heads*32]
+ * (token-major, exactly what the q/k/v Linear layers write), out like q.  n_keys % 32 == 0.  One pass over the
+ * keys (online softmax), no score matrix in memory. */
+int awseg_attention_d32(const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                        int n_queries, int n_keys, float scale, awseg_stream_t stream);
+
 /* awseg_bias_act_nhwc: x = act(x + bias[c] (+ residual)) in place on float32 [n_pixels, C]:
  * the epilogue of a convolution whose eval-mode BatchNorm scale was folded into its weights
  * (Conv -> BN -> [+identity] -> ReLU of the ResNet bottlenecks behind PKG/models/model.py:349). */

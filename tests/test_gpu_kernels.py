@@ -654,3 +654,23 @@ def test_aspp_depthwise3_xcd_sliced_path(ops):
         ref = torch.nn.functional.conv2d(x, wdw[r], padding=rates[r], dilation=rates[r], groups=Cc)
         assert (out[r].permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-4
 
+
+@pytest.mark.parametrize("shape", [(2, 1, 200, 64), (1, 2, 128, 32), (2, 5, 300, 2048), (1, 8, 64, 96)])
+def test_attention_d32_matches_sdpa(ops, shape):
+    """fp32 flash attention (head_dim 32, token-major layout) against a float64 softmax(QK^T)V; ragged query counts."""
+    B, nh, nq, nkv = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    C = nh * 32
+    q = torch.randn(B, nq, C, device="cuda", generator=g)
+    k = torch.randn(B, nkv, C, device="cuda", generator=g)
+    v = torch.randn(B, nkv, C, device="cuda", generator=g)
+    scale = 32 ** -0.5
+    got = ops.attention_d32(q, k, v, nh, scale)
+    qh, kh, vh = (t.double().view(B, -1, nh, 32).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(B, nq, C)
+    assert (got.double() - ref).abs().max().item() < 2e-5
+    # large logits: the running-maximum rescaling must hold
+    got = ops.attention_d32(q * 8, k * 8, v, nh, scale)
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * (64 * scale), dim=-1) @ vh).transpose(1, 2).reshape(B, nq, C)
+    assert (got.double() - ref).abs().max().item() < 1e-4
+

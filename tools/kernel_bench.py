@@ -140,6 +140,15 @@ def main():
     wino_case("winograd 512->512 d2 @1/16 (resnet l4)", B, H // 16, W // 16, 512, 512, 2, False)
     wino_case("winograd 2048->256 @1/16 (deeplab depth)", B, H // 16, W // 16, 2048, 256, 1, False)
 
+    def attn_case(name, nh, nq, nkv):
+        qa = torch.randn(B, nq, nh * 32, device=dev); ka = torch.randn(B, nkv, nh * 32, device=dev); va = torch.randn(B, nkv, nh * 32, device=dev)
+        fl = 4.0 * B * nh * nq * nkv * 32
+        cases[name] = (lambda: ops.attention_d32(qa, ka, va, nh, 32 ** -0.5), "mfma", fl)
+        qh, kh, vh = (t.view(B, -1, nh, 32).transpose(1, 2) for t in (qa, ka, va))
+        cases[name + " [torch SDPA]"] = (lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, scale=32 ** -0.5), "mfma", fl)
+    attn_case("attention d32 stage1 (131072 q x 2048 k, 1 head)", 1, (H // 4) * (W // 4), (H // 32) * (W // 32))
+    attn_case("attention d32 stage3 (8192 q x 2048 k, 5 heads)", 5, (H // 16) * (W // 16), (H // 32) * (W // 32))
+
     only = [s for s in a.only.split(",") if s]
     rows = []
     for name, (fn, bound, work) in cases.items():

@@ -118,8 +118,12 @@ void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__
         ls += __shfl_xor(ls, 32, 64);
         l_run = l_run * alpha + ls;
         m_run = m_new;
+        // after the first few tiles the running maxima stop moving: skip the 16 rescaling multiplies unless some
+        // lane of the wave needs them (wave-uniform branch; VALU instructions are MFMA time here)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+            for (int r = 0; r < 16; ++r) oacc[r] *= alpha;
+        }
         // ---- O^T += V^T P^T: A = V^T [d][key], B = P^T — the accumulator tile itself, register r = k-step r
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[r], p[r], oacc, 0, 0, 0);

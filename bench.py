@@ -75,6 +75,10 @@ def launch_work(name, args):
         # 2.25x fewer than the direct convolution computes
         _, b, h, w, cin, cout = args[:6]
         return 2.0 * 16 * cin * cout * b * ((h + 1) // 2) * ((w + 1) // 2)
+    if name == "awseg_attention_d32":
+        # (q, k, v, out, batch, heads, n_queries, n_keys, ...): QK^T and PV, head_dim 32
+        b, heads, nq, nkv = args[4:8]
+        return 4.0 * b * heads * nq * nkv * 32
     return None
 
 

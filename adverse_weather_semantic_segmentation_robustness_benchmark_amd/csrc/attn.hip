@@ -16,6 +16,9 @@
 //     exactly that key order, so nothing is transposed or round-tripped;
 //   * exp is one v_exp_f32 per element (log2 e folded into the query scale), the running maximum starts at a
 //     large negative finite value (no inf - inf).
+// (Tried: the softmax subtract / sum as inline-asm v_pk_* — wrong results, because hipcc pads the "VALU reads a
+// transcendental / MFMA result" hazards only for instructions it emitted itself; written in plain C++ the packed
+// forms bring nothing measurable, so the loop stays scalar.)
 // Block = 128 queries of one (image, head): 4 waves x 32 queries, all waves sharing the K / V^T tiles (32 keys,
 // double-buffered in LDS, register-prefetched one tile ahead).
 #include "awseg_common.h"

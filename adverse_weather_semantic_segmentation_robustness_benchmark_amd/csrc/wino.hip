@@ -58,17 +58,14 @@ __device__ __forceinline__ float act_apply(float v, int act)
     return v;
 }
 
-// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): lane l's bytes land at lds_base + 16*l.
-// Issued through inline asm on purpose: the builtin makes hipcc treat every later ds_read as possibly
-// aliasing the DMA's LDS write and wait vmcnt(0) right after the first MFMA of a step, which
-// serialises the copy with the math.  The kernel orders the copy itself: glds_wait() before the
-// barrier that ends the step in which the copy was issued.
-__device__ __forceinline__ void glds16(const float* gsrc, uint32_t lds_base)
-{
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(lds_base) : "m0");
-}
-// Same through a buffer descriptor: per-lane 32-bit byte offset + scalar byte offset, bounds-checked by the
-// hardware (an out-of-range lane reads zeros) — no 64-bit address arithmetic and no zero row for padding pixels.
+// LDS-DMA of 16 bytes per lane through a buffer descriptor (buffer_load_dwordx4 ... lds): lane l's bytes land at
+// lds_base + 16*l; per-lane 32-bit byte offset + scalar byte offset, bounds-checked by the hardware (an out-of-range
+// lane reads zeros) — no 64-bit address arithmetic and no zero row for padding pixels.  Issued through inline asm on
+// purpose: the LDS-DMA builtins make hipcc treat every later ds_read as possibly aliasing the DMA's LDS write and
+// wait vmcnt(0) right after the first MFMA of a step, which serialises the copy with the math.  The kernel orders
+// the copy itself: a vmcnt wait before the barrier that ends the step in which the copy was issued.
+// (Inline asm is only used where its operands come from / go to LDS and plain VALU results: hipcc pads MFMA-result
+// and transcendental-result use hazards only for instructions it emitted itself — see attn.hip.)
 __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_base)
 {
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "m0");

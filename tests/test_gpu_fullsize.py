@@ -214,3 +214,30 @@ def test_fullsize_depth_estimate(ops):
     assert (flat[H // 2 + 9: H - 9, 5] - ((y / H) * 0.8 + 0.2) * 0.5).abs().max().item() < 1e-9   # linear ramp is a Gaussian fixed point
     alone = ops.depth_estimate(imgs[2:3], dtype=torch.float64)
     assert torch.equal(alone[0], d[2])
+
+
+def test_fullsize_ensemble_fused_vs_module_graph():
+    """One 1024x2048 frame through the eval executors (Winograd / own attention / fused GEMM epilogues at their real
+    shapes: 2048 keys, 2048->256 and full-resolution 128->64 convolutions) against the SAME weights run through the
+    reference's op graph on torch-ROCm (MIOpen, SDPA): 1e-4 on the logits (relative to their magnitude), 1e-4 on depth."""
+    import adverse_weather_semantic_segmentation_robustness_benchmark_amd as P
+    torch.manual_seed(11)
+    m = P.EnsembleModel(num_classes=C, include_depth=True, pretrained=False).cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) * 1.5 + 0.5)
+            mod.running_mean.copy_((torch.rand(mod.running_mean.shape, generator=g) - 0.5) * 0.2)
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=g) * 0.5 + 0.25)
+    x = torch.randn(1, 3, H, W, device="cuda")
+    with torch.no_grad():
+        fused = m(x)
+        for sub in (m, m.segformer, m.deeplabv3plus):
+            sub.fused_eval = False
+        ref = m(x)
+    for key in ("segformer_seg", "deeplabv3plus_seg", "segmentation"):
+        scale = max(1.0, ref[key].abs().max().item())
+        assert (fused[key] - ref[key]).abs().max().item() / scale < 1e-4, key
+    for key in ("segformer_depth", "deeplabv3plus_depth", "depth"):
+        assert (fused[key] - ref[key]).abs().max().item() < 1e-4, key
+

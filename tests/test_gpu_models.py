@@ -54,6 +54,18 @@ def test_segformer_model_hip_vs_as_written(P):
     assert (out["depth"].cpu() - ref["depth"]).abs().max().item() < 1e-4
 
 
+def test_segformer_model_hip_vs_as_written_own_attention_path(P):
+    """256x256: every MiT stage has 64 keys (a multiple of 32), so the encoder runs awseg_attention_d32, not the
+    SDPA fall-back the smaller sizes take."""
+    torch.manual_seed(3)
+    m = calibrate_bn(P.SegFormerModel(num_classes=19, include_depth=True, pretrained=False)).cuda().eval()
+    x = torch.randn(1, 3, 256, 256, device="cuda")
+    out = m(x)
+    ref = as_written_cpu(m, x)
+    assert rel_err(out["segmentation"].cpu(), ref["segmentation"]) < 1e-4
+    assert (out["depth"].cpu() - ref["depth"]).abs().max().item() < 1e-4
+
+
 def test_deeplab_model_hip_vs_as_written(P):
     torch.manual_seed(1)
     m = calibrate_bn(P.DeepLabV3PlusModel(num_classes=19, include_depth=True, pretrained=False)).cuda().eval()

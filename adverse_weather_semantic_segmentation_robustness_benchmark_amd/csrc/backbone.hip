@@ -210,6 +210,33 @@ void dwconv3x3_upcat_strip_kernel(const float* __restrict__ a, int h, int w, int
     }
 }
 
+// Depth tail of EnsembleModel.forward (PKG/models/model.py:368-371 + :471-478): the DeepLab depth map is predicted at
+// stride 16, upsampled bilinearly (align_corners=False) to the input size and combined with the SegFormer map as
+// w0*d1 + w1*d2 (or their mean).  One pass: reads d1 and the 64x-smaller low-resolution map, writes both outputs.
+__global__ __launch_bounds__(kThreads)
+void depth_up_combine_kernel(const float* __restrict__ d1, const float* __restrict__ d2_low, int h, int w, int H, int W,
+                             float sy, float sx, const float* __restrict__ weights, float* __restrict__ d2_full,
+                             float* __restrict__ d_out)
+{
+    const int64_t hw = (int64_t)H * W;
+    const float* lo = d2_low + (int64_t)blockIdx.y * h * w;
+    const float w0 = weights ? weights[0] : 0.f, w1 = weights ? weights[1] : 0.f;
+    for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < hw; p += (int64_t)gridDim.x * kThreads) {
+        const int y = (int)(p / W), x = (int)(p - (int64_t)y * W);
+        // torch area_pixel_compute_source_index(scale, dst, align_corners=false, cubic=false)
+        float fy = sy * ((float)y + 0.5f) - 0.5f; fy = fy < 0.f ? 0.f : fy;
+        float fx = sx * ((float)x + 0.5f) - 0.5f; fx = fx < 0.f ? 0.f : fx;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1, lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+        const float v = ly0 * (lx0 * lo[y0 * w + x0] + lx1 * lo[y0 * w + x1]) + ly1 * (lx0 * lo[y1 * w + x0] + lx1 * lo[y1 * w + x1]);
+        const int64_t o = (int64_t)blockIdx.y * hw + p;
+        d2_full[o] = v;
+        const float a = d1[o];
+        d_out[o] = weights ? (w0 * a + w1 * v) : ((a + v) / 2.0f);
+    }
+}
+
 __global__ __launch_bounds__(kThreads)
 void bias_act_nhwc_kernel(float* __restrict__ x, int64_t n_pixels, int C, const float* __restrict__ bias,
                           const float* __restrict__ residual, int act)
@@ -362,6 +389,22 @@ AWSEG_API int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_wid
     const int64_t items = batch * height * ((width + SX - 1) / SX) * ((a_channels + hi_channels) / 4);
     hipLaunchKernelGGL((dwconv3x3_upcat_strip_kernel<SX>), dim3(awseg_grid_1d(items, kThreads)), dim3(kThreads), 0, awseg_s(stream),
                        a, a_height, a_width, a_channels, hi, hi_channels, batch, height, width, ry, rx, w9, out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_depth_upsample_combine(const float* d1, const float* d2_low, int batch, int low_height, int low_width,
+                                           int height, int width, const float* weights, float* d2_full, float* d_out,
+                                           awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!d1 || !d2_low || !d2_full || !d_out || batch < 0 || low_height < 1 || low_width < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (batch > 65535) return AWSEG_ERANGE;
+    // torch area_pixel_compute_scale(in, out, align_corners=false, scale=None) = (float)in / out
+    const float sy = (float)low_height / (float)height, sx = (float)low_width / (float)width;
+    dim3 grid(awseg_grid_1d((int64_t)height * width, kThreads, 1024), (unsigned)batch);
+    hipLaunchKernelGGL(depth_up_combine_kernel, grid, dim3(kThreads), 0, awseg_s(stream), d1, d2_low, low_height, low_width, height, width,
+                       sy, sx, weights, d2_full, d_out);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

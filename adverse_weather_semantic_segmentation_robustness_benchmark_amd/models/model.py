@@ -259,7 +259,10 @@ class DeepLabV3PlusModel(nn.Module):
             # the reference runs the encoder a second time here (model.py:358); in eval mode the
             # result is identical, so the features of the first pass are reused
             d = self.depth_head.forward_fused(enc)
-            results["depth"] = F.interpolate(d, size=x.shape[2:], mode="bilinear", align_corners=False).contiguous()
+            if getattr(self, "_defer_depth_upsample", False):
+                results["depth_low"] = d.contiguous()        # the ensemble upsamples + combines in one HIP pass
+            else:
+                results["depth"] = F.interpolate(d, size=x.shape[2:], mode="bilinear", align_corners=False).contiguous()
         return results
 
 
@@ -294,7 +297,11 @@ class EnsembleModel(nn.Module):
                      want_pred: bool = True, pred_dtype=torch.int64) -> Dict[str, torch.Tensor]:
         """members -> ONE pass: combine, /temperature, argmax, confusion (slots: overall + condition)."""
         o1 = self.segformer(x)
-        o2 = self.deeplabv3plus(x)
+        self.deeplabv3plus._defer_depth_upsample = self.include_depth
+        try:
+            o2 = self.deeplabv3plus(x)
+        finally:
+            self.deeplabv3plus._defer_depth_upsample = False
         mode = _STRATEGY.get(self.ensemble_strategy, N.COMBINE_MEAN)
         w = F.softmax(self.ensemble_weights, dim=0) if mode == N.COMBINE_WEIGHTED else None
         T = self.temperature if self.temperature_scaling else None
@@ -307,7 +314,12 @@ class EnsembleModel(nn.Module):
         if pred is not None:
             res["prediction"] = pred
         if self.include_depth:
-            res.update(self._combine_depth(o1["depth"], o2["depth"]))
+            if "depth_low" in o2:
+                wd = F.softmax(self.ensemble_weights, dim=0) if self.ensemble_strategy == "weighted_average" else None
+                d2, d = ops.depth_upsample_combine(o1["depth"], o2["depth_low"], wd)
+                res.update({"depth": d, "segformer_depth": o1["depth"], "deeplabv3plus_depth": d2})
+            else:
+                res.update(self._combine_depth(o1["depth"], o2["depth"]))
         return res
 
     def _combine_depth(self, d1, d2):

@@ -486,6 +486,18 @@ def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     return out
 
 
+def depth_upsample_combine(d1: torch.Tensor, d2_low: torch.Tensor, weights: Optional[torch.Tensor]):
+    """(d2_full, d) with d2_full = bilinear(align_corners=False) upsample of d2_low [B,1,h,w] to d1's size [B,1,H,W] and
+    d = weights[0]*d1 + weights[1]*d2_full (mean when weights is None) — PKG/models/model.py:368-371, 471-478."""
+    d1, d2_low = d1.contiguous(), d2_low.contiguous()
+    b, _, H, W = d1.shape
+    h, w = d2_low.shape[-2:]
+    d2_full, d = torch.empty_like(d1), torch.empty_like(d1)
+    N.call("awseg_depth_upsample_combine", N.ptr(d1), N.ptr(d2_low), b, h, w, H, W, N.ptr(None if weights is None else weights.contiguous()),
+           N.ptr(d2_full), N.ptr(d), N.stream())
+    return d2_full, d
+
+
 def layernorm_rows(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
     """torch.nn.functional.layer_norm over the last dimension for small channel counts (MiT tokens)."""
     x = x.contiguous()

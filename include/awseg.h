@@ -452,6 +452,14 @@ int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_width, int a_
 int awseg_attention_d32(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                         int n_queries, int n_keys, float scale, awseg_stream_t stream);
 
+/* awseg_depth_upsample_combine: the depth tail of the ensemble in one pass — d2_full = bilinear upsample
+ * (align_corners=False) of the stride-16 DeepLab depth map d2_low [B,h,w] to [B,H,W] (PKG/models/model.py:368-371) and
+ * d_out = weights[0]*d1 + weights[1]*d2_full, or (d1 + d2_full)/2 when weights is NULL (model.py:471-478).
+ * weights: device float32 [2] (softmax of the ensemble weights).  d1, d2_full, d_out float32 [B,H,W]. */
+int awseg_depth_upsample_combine(const float* d1, const float* d2_low, int batch, int low_height, int low_width,
+                                 int height, int width, const float* weights, float* d2_full, float* d_out,
+                                 awseg_stream_t stream);
+
 /* awseg_bias_act_nhwc: x = act(x + bias[c] (+ residual)) in place on float32 [n_pixels, C]:
  * the epilogue of a convolution whose eval-mode BatchNorm scale was folded into its weights
  * (Conv -> BN -> [+identity] -> ReLU of the ResNet bottlenecks behind PKG/models/model.py:349). */

@@ -674,3 +674,16 @@ def test_attention_d32_matches_sdpa(ops, shape):
     ref = (torch.softmax(qh @ kh.transpose(-1, -2) * (64 * scale), dim=-1) @ vh).transpose(1, 2).reshape(B, nq, C)
     assert (got.double() - ref).abs().max().item() < 1e-4
 
+
+@pytest.mark.parametrize("shape", [(2, 4, 8, 64, 128), (1, 3, 5, 37, 61), (1, 64, 128, 1024, 2048)])
+def test_depth_upsample_combine_matches_torch(ops, shape):
+    B, h, w, H, W = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    d1 = torch.rand(B, 1, H, W, device="cuda", generator=g); lo = torch.rand(B, 1, h, w, device="cuda", generator=g)
+    wts = torch.softmax(torch.tensor([0.3, -0.2], device="cuda"), 0)
+    ref2 = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)
+    d2, d = ops.depth_upsample_combine(d1, lo, wts)
+    assert (d2 - ref2).abs().max().item() < 1e-6 and (d - (wts[0] * d1 + wts[1] * ref2)).abs().max().item() < 1e-6
+    d2, d = ops.depth_upsample_combine(d1, lo, None)
+    assert (d - (d1 + ref2) / 2).abs().max().item() < 1e-6
+

@@ -209,11 +209,7 @@ void conv3x3_wino_kernel(wino_args a)
     const uint32_t ub = (uint32_t)(n0 + (__builtin_amdgcn_readfirstlane(wave) & 1) * 32) * 16;      // bytes, wave-uniform
     const uint32_t u_pos = (uint32_t)2 * a.Cout * 16, u_chunk = (uint32_t)32 * a.Cout * 16;         // bytes
 
-    f32x16 acc[16];
-#pragma unroll
-    for (int p = 0; p < 16; ++p)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+    f32x16 acc[16];                       // first written by the first chunk's MFMAs (zero C operand: no 256-register clear)
 
     const int mt = wave >> 1, nt = wave & 1, hk = lane >> 5, li = lane & 31;
     const int aoff = hk * (4 * NTILE) + (mt * 32 + li) * 4;
@@ -252,7 +248,7 @@ void conv3x3_wino_kernel(wino_args a)
 #define WINO_MM(X, Y, CACC) (MODE == 1 ? __builtin_amdgcn_mfma_f32_32x32x2f32(Y, X, CACC, 0, 0, 0)   \
                                        : __builtin_amdgcn_mfma_f32_32x32x2f32(X, Y, CACC, 0, 0, 0))
 #define WINO_MFMAS(G, AV, BV)                                                                  \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].x, BV[q].x, acc[4 * (G) + q]); \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].x, BV[q].x, (FIRST ? kZero16 : acc[4 * (G) + q])); \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].y, BV[q].y, acc[4 * (G) + q]); \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].z, BV[q].z, acc[4 * (G) + q]); \
     _Pragma("unroll") for (int q = 0; q < 4; ++q) acc[4 * (G) + q] = WINO_MM(AV[q].w, BV[q].w, acc[4 * (G) + q]);
@@ -269,8 +265,9 @@ void conv3x3_wino_kernel(wino_args a)
         if (NDSW) __builtin_amdgcn_sched_group_barrier(0x200, NDSW, 0);                        \
     }
     // B0 enters holding the weights of (chunk C, group 0) and leaves holding those of (C+1, group 0).
-#define WINO_STEP(C, BUF)                                                                      \
+#define WINO_STEP(C, BUF, IS_FIRST)                                                            \
     do {                                                                                       \
+        constexpr bool FIRST = IS_FIRST;                                                       \
         const float* pa = sV + (BUF) * V_FLOATS + aoff;                                        \
         float* vd = sV + ((BUF) ^ 1) * V_FLOATS + vdoff;                                       \
         const float* pn = sP + ((BUF) ^ 1) * P_FLOATS;                                         \
@@ -316,9 +313,12 @@ void conv3x3_wino_kernel(wino_args a)
     float4 b0[4], b1[4];
     WINO_LOAD_B(ub, 0, b0)
     static_assert(KC == 8, "the step below is written for four k-steps per chunk");
-    for (int c = 0; c < nchunks; c += 2) {
-        WINO_STEP(c, 0);
-        WINO_STEP(c + 1, 1);
+    const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    WINO_STEP(0, 0, true);
+    WINO_STEP(1, 1, false);
+    for (int c = 2; c < nchunks; c += 2) {
+        WINO_STEP(c, 0, false);
+        WINO_STEP(c + 1, 1, false);
     }
 #undef WINO_LOAD_A
 #undef WINO_LOAD_B

@@ -19,6 +19,9 @@ PKG = CSRC.parent
 LIB = PKG / "libawseg_hip.so"
 SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "backbone.hip", "depth.hip", "wino.hip", "gemm.hip", "attn.hip"]
 ARCH = "gfx950"
+# per-file extras.  wino.hip: the SLP vectoriser packs the scalar inverse transform of the fused-head epilogue into
+# v_pk_add_f32 fed by ~220 v_mov (and spills); the kernel packs by hand where adjacent registers make it free.
+EXTRA_FLAGS = {"wino.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc() -> str:
@@ -50,7 +53,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     def compile_one(src):
         obj = objdir / (Path(src).stem + ".o")
-        cmd = [cc, *_flags(), "-c", str(CSRC / src), "-o", str(obj)]
+        cmd = [cc, *_flags(), *EXTRA_FLAGS.get(src, []), "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -388,32 +388,37 @@ void conv3x3_wino_kernel(wino_args a)
             }
         }
     } else {
-        float zs[4] = {0.f, 0.f, 0.f, 0.f};
+        // two accumulator rows (= two consecutive couts) at a time: adjacent registers -> packed adds
+        v2f z[4] = {v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}, v2f{0.f, 0.f}};
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const int c4 = n0 + nt * 32 + 8 * r4 + 4 * hk;                      // rows 4*r4 .. 4*r4+3 are four consecutive couts
             const float4 sh4 = *reinterpret_cast<const float4*>(a.shift + c4);
             const float4 w4 = *reinterpret_cast<const float4*>(a.w2 + c4);
-            const float shv[4] = {sh4.x, sh4.y, sh4.z, sh4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w};
+            const v2f shv[2] = {v2f{sh4.x, sh4.y}, v2f{sh4.z, sh4.w}}, wv[2] = {v2f{w4.x, w4.y}, v2f{w4.z, w4.w}};
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
-                const int r = r4 * 4 + rr;
-                float m[4][4];
+            for (int rr = 0; rr < 2; ++rr) {
+                const int r = r4 * 4 + 2 * rr;
+                v2f m[4][4];
 #pragma unroll
-                for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = acc[p][r];
-                float t0[4], t1[4];
+                for (int p = 0; p < 16; ++p) m[p >> 2][p & 3] = v2f{acc[p][r], acc[p][r + 1]};
+                v2f t0[4], t1[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { t0[j] = m[0][j] + m[1][j] + m[2][j]; t1[j] = m[1][j] - m[2][j] - m[3][j]; }
-                const float yv[4] = {t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]};
+                const v2f yv[4] = {t0[0] + t0[1] + t0[2], t0[1] - t0[2] - t0[3], t1[0] + t1[1] + t1[2], t1[1] - t1[2] - t1[3]};
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v = yv[q] + shv[rr];
-                    zs[q] = zs[q] + (v > 0.f ? v : 0.f) * wv[rr];
+                    const v2f v = yv[q] + shv[rr];
+                    z[q] = z[q] + __builtin_elementwise_max(v, v2f{0.f, 0.f}) * wv[rr];
                 }
             }
         }
+        float zs[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) zs[q] += __shfl_xor(zs[q], 32, 64);         // the other half holds rows +4 of the same tile
+        for (int q = 0; q < 4; ++q) {
+            zs[q] = z[q][0] + z[q][1];
+            zs[q] += __shfl_xor(zs[q], 32, 64);                                 // the other half holds rows +4 of the same tile
+        }
         if (hk == 0) *reinterpret_cast<float4*>(red + (nt * NTILE + mt * 32 + li) * 4) = make_float4(zs[0], zs[1], zs[2], zs[3]);
         __syncthreads();
         const int tile = tid >> 2, q = tid & 3;

@@ -59,26 +59,41 @@ class KernelClock:
         return rc
 
     def summary(self):
-        """name -> (launches, mean ms per launch, mean per-launch work or None)."""
+        """name -> (launches, mean ms per launch, (bound, mean per-launch work) or None)."""
         out = {}
         for n, p in self.pairs.items():
             works = [w for _, _, w in p]
-            out[n] = (len(p), sum(s.elapsed_time(e) for s, e, _ in p) / len(p), None if works[0] is None else sum(works) / len(works))
+            own = None if works[0] is None else (works[0][0], sum(w[1] for w in works) / len(works))
+            out[n] = (len(p), sum(s.elapsed_time(e) for s, e, _ in p) / len(p), own)
         return out
 
 
 def launch_work(name, args):
-    """Work of ONE launch when it depends on the launch's own shape arguments (kernels called at
-    several shapes per step); None -> algorithmic_work() prices the launch from the bench shape."""
+    """(bound, work) of ONE launch when it depends on the launch's own shape arguments (kernels called at several
+    shapes per step); None -> algorithmic_work() prices the launch from the bench shape."""
     if name == "awseg_conv3x3_winograd_nhwc":
         # (x, batch, H, W, Cin, Cout, dilation, ...): MFMA flops issued = 16 multiplies per 2x2 output tile,
         # 2.25x fewer than the direct convolution computes
         _, b, h, w, cin, cout = args[:6]
-        return 2.0 * 16 * cin * cout * b * ((h + 1) // 2) * ((w + 1) // 2)
+        return "mfma", 2.0 * 16 * cin * cout * b * ((h + 1) // 2) * ((w + 1) // 2)
     if name == "awseg_attention_d32":
         # (q, k, v, out, batch, heads, n_queries, n_keys, ...): QK^T and PV, head_dim 32
         b, heads, nq, nkv = args[4:8]
-        return 4.0 * b * heads * nq * nkv * 32
+        return "mfma", 4.0 * b * heads * nq * nkv * 32
+    if name == "awseg_dwconv3x3_nhwc":
+        # (x, batch, H, W, C, ...): read + write of the activation
+        _, b, h, w, c = args[:5]
+        return "hbm", 8.0 * b * h * w * c
+    if name == "awseg_dwconv3x3_upcat_nhwc":
+        # (a, h, w, Ca, hi, Ch, batch, H, W, ...): read the two inputs once, write the concatenated map
+        _, h, w, ca, _, ch, b, H, W = args[:9]
+        return "hbm", 4.0 * b * (h * w * ca + H * W * ch + H * W * (ca + ch))
+    if name == "awseg_bias_act_nhwc":
+        # (x, n_pixels, C, bias, residual, act): in-place pass (+ residual read)
+        _, npx, c, _, res = args[:5]
+        return "hbm", 4.0 * npx * c * (3 if res is not None else 2)
+    if name == "awseg_layernorm_rows":
+        return "hbm", 8.0 * args[1] * args[2]            # (x, n_rows, C, ...)
     return None
 
 
@@ -263,7 +278,7 @@ def main():
     # ---- roofline of the dominant hand-written kernel (rank 0's launches) ----------------------
     kernels = []
     for name, (count, avg_ms, own_work) in CLOCK.summary().items():
-        bound, work = ("mfma", own_work) if own_work is not None else algorithmic_work(name, B, H, W, C, info)
+        bound, work = own_work if own_work is not None else algorithmic_work(name, B, H, W, C, info)
         if work <= 0 or avg_ms <= 0:
             continue
         if bound == "hbm":

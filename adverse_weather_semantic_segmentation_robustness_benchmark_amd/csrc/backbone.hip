@@ -120,7 +120,7 @@ void dwconv3x3_nhwc_strip_kernel(const float* __restrict__ x, int64_t batch, int
 // the depthwise 3x3 of block2 applied to cat(UpsamplingBilinear2d(x4, align_corners=True)(a), hi) WITHOUT
 // materialising the upsampled map or the concatenation (1.07 + 1.27 GB per batch at 1024x2048).  Same strip
 // scheme as above; a column of the first Ca channels is sampled from the stride-16 map with torch's
-// upsample_bilinear2d arithmetic (source index = dst * (in-1)/(out-1), value = l0*(w0*v00 + w1*v01) + l1*(w0*v10 + w1*v11)).
+// upsample_bilinear2d source indices and weights (source index = dst * (in-1)/(out-1)).
 template <int SX>
 __global__ __launch_bounds__(kThreads)
 void dwconv3x3_upcat_strip_kernel(const float* __restrict__ a, int h, int w, int Ca, const float* __restrict__ hi, int Ch,
@@ -154,25 +154,37 @@ void dwconv3x3_upcat_strip_kernel(const float* __restrict__ a, int h, int w, int
             r0[ky] = i0; r1[ky] = i0 + (i0 < h - 1 ? 1 : 0);
             l1[ky] = f - (float)i0; l0[ky] = 1.0f - l1[ky];
         }
+        // the four corner columns of the current source cell, kept across output columns: at x4 upsampling the
+        // source column index changes every ~4 output columns, so most columns reuse all 12 loads
+        float4 vj0[3], vj1[3];                              // per tap row: the two source columns, already blended vertically
+        int cur_j0 = -1;
         auto col = [&](int sx, float4* v) {
             const bool cok = sx >= 0 && sx < W;
             if (up) {
                 const float f = rx * (float)(cok ? sx : 0);
                 const int j0 = (int)f, j1 = j0 + (j0 < w - 1 ? 1 : 0);
                 const float m1 = f - (float)j0, m0 = 1.0f - m1;
+                if (cok && j0 != cur_j0) {
+                    cur_j0 = j0;
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    if (cok && rok[ky]) {
+                    for (int ky = 0; ky < 3; ++ky) {
                         const float4 v00 = *reinterpret_cast<const float4*>(ab + ((int64_t)r0[ky] * w + j0) * Ca);
                         const float4 v01 = *reinterpret_cast<const float4*>(ab + ((int64_t)r0[ky] * w + j1) * Ca);
                         const float4 v10 = *reinterpret_cast<const float4*>(ab + ((int64_t)r1[ky] * w + j0) * Ca);
                         const float4 v11 = *reinterpret_cast<const float4*>(ab + ((int64_t)r1[ky] * w + j1) * Ca);
-                        float4 o;
-                        o.x = l0[ky] * (m0 * v00.x + m1 * v01.x) + l1[ky] * (m0 * v10.x + m1 * v11.x);
-                        o.y = l0[ky] * (m0 * v00.y + m1 * v01.y) + l1[ky] * (m0 * v10.y + m1 * v11.y);
-                        o.z = l0[ky] * (m0 * v00.z + m1 * v01.z) + l1[ky] * (m0 * v10.z + m1 * v11.z);
-                        o.w = l0[ky] * (m0 * v00.w + m1 * v01.w) + l1[ky] * (m0 * v10.w + m1 * v11.w);
-                        v[ky] = o;
+                        // vertical blend once per source cell (torch blends horizontally first: same value up to the
+                        // last bit of a convex combination, far inside the 1e-4 budget)
+                        vj0[ky] = make_float4(l0[ky] * v00.x + l1[ky] * v10.x, l0[ky] * v00.y + l1[ky] * v10.y,
+                                              l0[ky] * v00.z + l1[ky] * v10.z, l0[ky] * v00.w + l1[ky] * v10.w);
+                        vj1[ky] = make_float4(l0[ky] * v01.x + l1[ky] * v11.x, l0[ky] * v01.y + l1[ky] * v11.y,
+                                              l0[ky] * v01.z + l1[ky] * v11.z, l0[ky] * v01.w + l1[ky] * v11.w);
+                    }
+                }
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (cok && rok[ky]) {
+                        const float4 a0 = vj0[ky], a1 = vj1[ky];
+                        v[ky] = make_float4(m0 * a0.x + m1 * a1.x, m0 * a0.y + m1 * a1.y, m0 * a0.z + m1 * a1.z, m0 * a0.w + m1 * a1.w);
                     } else {
                         v[ky] = zero;
                     }

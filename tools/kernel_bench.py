@@ -149,6 +149,10 @@ def main():
     attn_case("attention d32 stage1 (131072 q x 2048 k, 1 head)", 1, (H // 4) * (W // 4), (H // 32) * (W // 32))
     attn_case("attention d32 stage3 (8192 q x 2048 k, 5 heads)", 5, (H // 16) * (W // 16), (H // 32) * (W // 32))
 
+    a_lo = torch.randn(B, H // 16, W // 16, 256, device=dev); hi48 = torch.randn(B, H // 4, W // 4, 48, device=dev); w304 = torch.randn(9, 304, device=dev)
+    cases["dwconv3x3_upcat (decoder: up x4 + cat + depthwise)"] = (lambda: ops.dwconv3x3_upcat(a_lo, hi48, w304), "hbm",
+                                                                   4.0 * B * ((H // 16) * (W // 16) * 256 + (H // 4) * (W // 4) * (48 + 304)))
+
     only = [s for s in a.only.split(",") if s]
     rows = []
     for name, (fn, bound, work) in cases.items():

@@ -48,6 +48,7 @@ SIGNATURES = {
     "awseg_gemm_tune": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i64, c_i, c_i, c_p, C.c_size_t, c_p]),
     "awseg_dwconv3x3_upcat_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_attention_d32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "awseg_attention_d32_split": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "awseg_depth_upsample_combine": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "awseg_lut3_apply": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p]),
     "awseg_local_contrast": (c_i, [c_p, c_i, c_i, c_i, c_p, c_p]),

@@ -153,10 +153,186 @@ void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same attention on the f16 matrix cores with SPLIT operands.  v_mfma_f32_32x32x16_f16 issues 16x the multiply-adds
+// per cycle of v_mfma_f32_32x32x2_f32, so a float32 product is rebuilt from three f16 products at 5.3x the rate:
+//     x = xh + xl / 2048,   xh = f16(x) (11 significant bits),  xl = f16((x - xh) * 2048) (the next 11 bits)
+//     x * y = xh*yh + (xh*yl + xl*yh) / 2048 + O(2^-22 |x y|)          (the xl*yl term is below float32 rounding noise)
+// with two float32 accumulator tiles (main, correction) and float32 accumulation inside the MFMA throughout: 22-bit
+// operands instead of 24-bit, everything else as the kernel above (transposed scores, in-register softmax, the
+// probability tile reused as the B operand).  tests/test_gpu_kernels.py measures both kernels against a float64
+// reference: their errors are of the same order (a few 1e-7 relative), two orders inside the 1e-4 gate.
+// The probabilities are produced pre-scaled by 2^15 (folded into the exponent: exp2(s - m + 15)) so that every one that
+// matters is a NORMAL f16 number; the scale cancels in O / l.  q, k, v must be finite and below 65504 in magnitude
+// (they are LayerNorm -> Linear outputs).
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int SROW = 72;         // halfs per LDS row: 32 hi | 32 lo | 8 pad  (144 B: conflict-free ds_read_b128)
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+// (a, b) -> packed f16 high parts and packed scaled residuals.  Round-toward-zero is fine: the residual is exact.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo)
+{
+    const auto hp = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const h2 hh = __builtin_bit_cast(h2, hp);
+    const float ra = (a - (float)hh.x) * kLoScale, rb = (b - (float)hh.y) * kLoScale;
+    hi = __builtin_bit_cast(unsigned, hp);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+__device__ __forceinline__ void split8(const float* x, h8& hi, h8& lo)
+{
+    u32x4 H, L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned h, l; split_pair(x[2 * i], x[2 * i + 1], h, l); H[i] = h; L[i] = l; }
+    hi = __builtin_bit_cast(h8, H); lo = __builtin_bit_cast(h8, L);
+}
+// k-slot of tile key `key` in the PV product: element j of lane half h of k-step s is accumulator row
+// 16 s + 8 (j >> 2) + 4 h + (j & 3) (the C/D layout read as an operand); slot = 16 s + 8 h + j
+__device__ __forceinline__ constexpr int pv_slot(int key)
+{
+    return (key & 16) | (((key >> 2) & 1) << 3) | (((key >> 3) & 1) << 2) | (key & 3);
+}
+
+__global__ __launch_bounds__(AT, 2)
+void attention_d32_split_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sK[2][TK * SROW];      // [key][hi d 0..31 | lo d 0..31]
+    __shared__ __attribute__((aligned(16))) _Float16 sV[2][D * SROW];       // [d][hi slot 0..31 | lo slot 0..31]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int C = heads * D;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    const float* kb = k + ((size_t)b * nkv * heads + h) * D;
+    const float* vb = v + ((size_t)b * nkv * heads + h) * D;
+
+    // Q fragments: B operand of S^T = K Q^T, lane (query li, half hk) holds d = 16 s + 8 hk + j
+    h8 qh[2], ql[2];
+    {
+        const int qi = q0 + li;
+        const float* qp = q + ((size_t)b * nq + (qi < nq ? qi : nq - 1)) * C + h * D;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float4 a4 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * hk);
+            const float4 b4 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * hk + 4);
+            const float x[8] = { a4.x * scale_log2e, a4.y * scale_log2e, a4.z * scale_log2e, a4.w * scale_log2e,
+                                 b4.x * scale_log2e, b4.y * scale_log2e, b4.z * scale_log2e, b4.w * scale_log2e };
+            split8(x, qh[s], ql[s]);
+        }
+    }
+    // tile staging role of this thread: key = tid / 8, 4 consecutive d = 4c .. 4c+3
+    const int lkey = tid >> 3, lc = tid & 7;
+    const size_t g_off = (size_t)lkey * C + 4 * lc;
+    const int wk0 = lkey * SROW + 4 * lc;
+    const int wv0 = (4 * lc) * SROW + pv_slot(lkey);
+    auto stage = [&](int buf, const float4& kk4, const float4& vv4) {
+        u32x2 H, L; unsigned hh, ll;
+        split_pair(kk4.x, kk4.y, hh, ll); H[0] = hh; L[0] = ll;
+        split_pair(kk4.z, kk4.w, hh, ll); H[1] = hh; L[1] = ll;
+        *reinterpret_cast<u32x2*>(&sK[buf][wk0]) = H;
+        *reinterpret_cast<u32x2*>(&sK[buf][wk0 + 32]) = L;
+        unsigned vh01, vl01, vh23, vl23;
+        split_pair(vv4.x, vv4.y, vh01, vl01);
+        split_pair(vv4.z, vv4.w, vh23, vl23);
+        unsigned short* sv = reinterpret_cast<unsigned short*>(&sV[buf][wv0]);
+        sv[0] = (unsigned short)vh01;            sv[32] = (unsigned short)vl01;
+        sv[SROW] = (unsigned short)(vh01 >> 16); sv[SROW + 32] = (unsigned short)(vl01 >> 16);
+        sv[2 * SROW] = (unsigned short)vh23;     sv[2 * SROW + 32] = (unsigned short)vl23;
+        sv[3 * SROW] = (unsigned short)(vh23 >> 16); sv[3 * SROW + 32] = (unsigned short)(vl23 >> 16);
+    };
+    const int ntiles = nkv / TK;
+    float4 kreg = *reinterpret_cast<const float4*>(kb + g_off), vreg = *reinterpret_cast<const float4*>(vb + g_off);
+    stage(0, kreg, vreg);
+    if (ntiles > 1) {
+        kreg = *reinterpret_cast<const float4*>(kb + (size_t)TK * C + g_off);
+        vreg = *reinterpret_cast<const float4*>(vb + (size_t)TK * C + g_off);
+    }
+    __syncthreads();
+
+    f32x16 om, oc;                   // O^T: main and correction (x 2048) accumulators
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { om[r] = 0.f; oc[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+    const int a_off = li * SROW + 8 * hk;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        const h8* kr = reinterpret_cast<const h8*>(&sK[buf][a_off]);
+        const h8 kh0 = kr[0], kh1 = kr[2], kl0 = kr[4], kl1 = kr[6];          // +0, +16, +32, +48 halfs
+        f32x16 sm, sc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; }
+        sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], sm, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], sc, 0, 0, 0);
+        sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], sm, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], sc, 0, 0, 0);
+        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], sc, 0, 0, 0);
+        const h8* vr = reinterpret_cast<const h8*>(&sV[buf][a_off]);
+        const h8 vh0 = vr[0], vh1 = vr[2], vl0 = vr[4], vl1 = vr[6];
+        // ---- online softmax, one query per lane
+        float s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = fmaf(sc[r], kLoInv, sm[r]);
+        float mt = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+        for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float m_sh = m_new - 15.0f;                  // probabilities scaled by 2^15 (see the header)
+        float p[16], ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r] - m_sh); ls += p[r]; }
+        ls += __shfl_xor(ls, 32, 64);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { om[r] *= alpha; oc[r] *= alpha; }
+        }
+        // ---- O^T += V^T P^T: the probability tile, split, is the B operand: registers 8 s .. 8 s + 7 = k-step s
+        h8 ph0, pl0, ph1, pl1;
+        split8(p, ph0, pl0);
+        split8(p + 8, ph1, pl1);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, ph0, om, 0, 0, 0);
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl0, oc, 0, 0, 0);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph1, om, 0, 0, 0);
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl1, oc, 0, 0, 0);
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph0, oc, 0, 0, 0);
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph1, oc, 0, 0, 0);
+        if (t + 1 < ntiles) {
+            stage(buf ^ 1, kreg, vreg);
+            if (t + 2 < ntiles) {
+                kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * C + g_off);
+                vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * C + g_off);
+            }
+        }
+        __syncthreads();
+    }
+
+    const int qi = q0 + li;
+    if (qi < nq) {
+        const float inv = 1.0f / l_run;
+        float* op = out + ((size_t)b * nq + qi) * C + h * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(op + 8 * g + 4 * hk) =
+                make_float4(fmaf(oc[4 * g], kLoInv, om[4 * g]) * inv, fmaf(oc[4 * g + 1], kLoInv, om[4 * g + 1]) * inv,
+                            fmaf(oc[4 * g + 2], kLoInv, om[4 * g + 2]) * inv, fmaf(oc[4 * g + 3], kLoInv, om[4 * g + 3]) * inv);
+    }
+}
+
 }  // namespace
 
-AWSEG_API int awseg_attention_d32(const float* q, const float* k, const float* v, float* out, int batch, int heads,
-                                  int n_queries, int n_keys, float scale, awseg_stream_t stream)
+namespace {
+template <typename K>
+int launch_attention(K kernel, const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                     int n_queries, int n_keys, float scale, awseg_stream_t stream)
 {
     if (batch == 0 || n_queries == 0) return 0;
     if (!q || !k || !v || !out || batch < 0 || heads < 1 || n_queries < 0 || n_keys < TK) return AWSEG_EINVAL;
@@ -164,8 +340,21 @@ AWSEG_API int awseg_attention_d32(const float* q, const float* k, const float* v
     if (heads > 65535 || batch > 65535) return AWSEG_ERANGE;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15)) return AWSEG_EALIGN;
     dim3 grid((unsigned)((n_queries + 127) / 128), (unsigned)heads, (unsigned)batch);
-    hipLaunchKernelGGL(attention_d32_kernel, grid, dim3(AT), 0, awseg_s(stream), q, k, v, out, n_queries, n_keys, heads,
+    hipLaunchKernelGGL(kernel, grid, dim3(AT), 0, awseg_s(stream), q, k, v, out, n_queries, n_keys, heads,
                        scale * 1.4426950408889634f);
     AWSEG_LAUNCH_CHECK();
     return 0;
+}
+}  // namespace
+
+AWSEG_API int awseg_attention_d32(const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                                  int n_queries, int n_keys, float scale, awseg_stream_t stream)
+{
+    return launch_attention(attention_d32_kernel, q, k, v, out, batch, heads, n_queries, n_keys, scale, stream);
+}
+
+AWSEG_API int awseg_attention_d32_split(const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                                        int n_queries, int n_keys, float scale, awseg_stream_t stream)
+{
+    return launch_attention(attention_d32_split_kernel, q, k, v, out, batch, heads, n_queries, n_keys, scale, stream);
 }

@@ -477,12 +477,21 @@ def dwconv3x3_upcat(a: torch.Tensor, hi: torch.Tensor, w9: torch.Tensor) -> torc
     return out
 
 
-def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
-    """softmax(q k^T * scale) v for head_dim 32: q [B,Nq,heads*32], k / v [B,Nkv,heads*32] (token-major) -> [B,Nq,heads*32]."""
+# default attention kernel: 1 = split-operand f16 MFMA (22-bit operands, float32 accumulation: float32-grade results at
+# twice the speed, csrc/attn.hip), 0 = float32-input MFMA
+ATTENTION_SPLIT = os.environ.get("AWSEG_ATTN_SPLIT", "1") != "0"
+
+
+def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, scale: float,
+                  split: Optional[bool] = None) -> torch.Tensor:
+    """softmax(q k^T * scale) v for head_dim 32: q [B,Nq,heads*32], k / v [B,Nkv,heads*32] (token-major) -> [B,Nq,heads*32].
+    split=True runs the split-operand f16-MFMA kernel (22-bit operands, float32 accumulation), False the float32-MFMA
+    kernel; None takes the process default (ATTENTION_SPLIT, env AWSEG_ATTN_SPLIT=0/1)."""
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     b, nq, c = q.shape
     out = torch.empty_like(q)
-    N.call("awseg_attention_d32", N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), b, heads, nq, k.shape[1], float(scale), N.stream())
+    sym = "awseg_attention_d32_split" if (ATTENTION_SPLIT if split is None else split) else "awseg_attention_d32"
+    N.call(sym, N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), b, heads, nq, k.shape[1], float(scale), N.stream())
     return out
 
 

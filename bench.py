@@ -38,6 +38,7 @@ import torch
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
+MFMA_F16_PEAK_TFLOPS = 2516.6  # MI355X_MICROARCH.md: f16 / bf16 dense peak (256 CUs x 4 SIMDs x 1024 FLOP/cycle x 2.4 GHz)
 
 
 class KernelClock:
@@ -80,6 +81,10 @@ def launch_work(name, args):
         # (q, k, v, out, batch, heads, n_queries, n_keys, ...): QK^T and PV, head_dim 32
         b, heads, nq, nkv = args[4:8]
         return "mfma", 4.0 * b * heads * nq * nkv * 32
+    if name == "awseg_attention_d32_split":
+        # the same products, each issued as THREE f16 MFMA products (split operands): priced as issued, against the f16 peak
+        b, heads, nq, nkv = args[4:8]
+        return "mfma_f16", 3 * 4.0 * b * heads * nq * nkv * 32
     if name == "awseg_dwconv3x3_nhwc":
         # (x, batch, H, W, C, ...): read + write of the activation
         _, b, h, w, c = args[:5]
@@ -283,6 +288,8 @@ def main():
             continue
         if bound == "hbm":
             achieved, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+        elif bound == "mfma_f16":
+            achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "TFLOP/s"
         else:
             achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
         kernels.append({"kernel": name, "launches": count, "avg_ms": round(avg_ms, 4), "bound": bound,
@@ -311,6 +318,7 @@ def main():
             "config": {"workload": f"ensemble_eval_{H}x{W}_5cond (BASELINE.json configs[1]: SegFormer-B0 + DeepLabV3+-R50, "
                                    "all 5 weather conditions round-robin)", "per_gpu_batch": B, "global_batch": B * world,
                        "include_depth": not args.no_depth, "weather_rng": "philox (in-kernel)", "ensemble_logits_materialised": False,
+                       "attention": ("split-operand f16 MFMA (22-bit operands, f32 accumulate)" if ops.ATTENTION_SPLIT else "f32 MFMA"),
                        "weights": "random init (no checkpoints offline)", "parallelism": f"batch-sharded x{world}, one int64 counter all-reduce"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "miou": {k: round(v, 6) for k, v in results.items()},

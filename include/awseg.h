@@ -452,6 +452,14 @@ int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_width, int a_
 int awseg_attention_d32(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                         int n_queries, int n_keys, float scale, awseg_stream_t stream);
 
+/* awseg_attention_d32_split: the same operator with both GEMMs on the f16 matrix cores and SPLIT float32 operands
+ * (x = f16(x) + f16((x - f16(x)) * 2048) / 2048: 22 significant bits, three f16 products per float32 product, float32
+ * accumulation) — 16x the MFMA rate per product, so 5.3x per float32-grade product.  Same arguments, layouts and error
+ * codes as awseg_attention_d32; inputs must be finite and below 65504 in magnitude.  Its error against a float64
+ * reference is of the same order as the float32 kernel's (tests/test_gpu_kernels.py). */
+int awseg_attention_d32_split(const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                              int n_queries, int n_keys, float scale, awseg_stream_t stream);
+
 /* awseg_depth_upsample_combine: the depth tail of the ensemble in one pass — d2_full = bilinear upsample
  * (align_corners=False) of the stride-16 DeepLab depth map d2_low [B,h,w] to [B,H,W] (PKG/models/model.py:368-371) and
  * d_out = weights[0]*d1 + weights[1]*d2_full, or (d1 + d2_full)/2 when weights is NULL (model.py:471-478).

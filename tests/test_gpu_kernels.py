@@ -675,6 +675,63 @@ def test_attention_d32_matches_sdpa(ops, shape):
     assert (got.double() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 1, 200, 64), (1, 2, 128, 32), (2, 5, 300, 2048), (1, 8, 64, 96)])
+def test_attention_d32_split_operands_float32_grade(ops, shape):
+    """The split-operand f16-MFMA attention (22-bit operands, float32 accumulation) against float64, next to the
+    float32-MFMA kernel on the same inputs: same gates, and its error may not exceed a small multiple of the float32
+    kernel's.  Includes values that are subnormal as f16 (|x| < 6.1e-5) and large logits."""
+    B, nh, nq, nkv = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + 1)
+    C = nh * 32
+    q = torch.randn(B, nq, C, device="cuda", generator=g)
+    k = torch.randn(B, nkv, C, device="cuda", generator=g)
+    v = torch.randn(B, nkv, C, device="cuda", generator=g)
+    k[:, ::3, ::5] *= 1e-5                       # f16-subnormal high parts
+    v[:, 1::4, 3::7] *= 3e-6
+    scale = 32 ** -0.5
+    qh, kh, vh = (t.double().view(B, -1, nh, 32).transpose(1, 2) for t in (q, k, v))
+    for mult, gate in ((1.0, 2e-5), (8.0, 1e-4)):
+        ref = (torch.softmax(qh @ kh.transpose(-1, -2) * (mult * mult * scale), dim=-1) @ vh).transpose(1, 2).reshape(B, nq, C)
+        e32 = (ops.attention_d32(q * mult, k * mult, v, nh, scale, split=False).double() - ref).abs().max().item()
+        esp = (ops.attention_d32(q * mult, k * mult, v, nh, scale, split=True).double() - ref).abs().max().item()
+        print(f"attention {shape} x{mult}: |err| float32 kernel {e32:.3e}, split kernel {esp:.3e}")
+        assert esp < gate
+        assert esp < 4 * e32 + 1e-6
+
+
+def test_attention_d32_split_flat_softmax(ops):
+    """2048 keys with nearly equal scores: every probability is ~5e-4 of the row sum — the case that would lose mass if
+    small probabilities were flushed in f16."""
+    g = torch.Generator(device="cuda").manual_seed(7)
+    q = torch.randn(1, 256, 32, device="cuda", generator=g) * 0.01
+    k = torch.randn(1, 2048, 32, device="cuda", generator=g)
+    v = torch.randn(1, 2048, 32, device="cuda", generator=g)
+    k[:, 5] *= 400.0                             # one dominant key: the others sit ~e^-20 below the maximum for some rows
+    ref = (torch.softmax(q.double() @ k.double().transpose(-1, -2) * 32 ** -0.5, dim=-1) @ v.double())
+    got = ops.attention_d32(q, k, v, 1, 32 ** -0.5, split=True)
+    assert (got.double() - ref).abs().max().item() < 2e-5
+
+
+def test_attention_d32_split_tiny_operands(ops):
+    """Whole tensors below the f16 normal range (|x| ~ 1e-5): the high parts are f16 SUBNORMALS, so this fails by
+    ~100 % if the f16 matrix cores flushed subnormal inputs; the relative error must stay at float32 level."""
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q = torch.randn(1, 128, 64, device="cuda", generator=g)
+    k = torch.randn(1, 256, 64, device="cuda", generator=g)
+    v = torch.randn(1, 256, 64, device="cuda", generator=g) * 1e-5
+    qh, kh, vh = (t.double().view(1, -1, 2, 32).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * 32 ** -0.5, dim=-1) @ vh).transpose(1, 2).reshape(1, 128, 64)
+    got = ops.attention_d32(q, k, v, 2, 32 ** -0.5, split=True).double()
+    assert ((got - ref).abs().max() / ref.abs().max()).item() < 5e-6
+    # tiny keys: scores ~1e-5, the softmax is uniform up to 1e-5 — flushing would make it exactly uniform
+    k2 = k * 1e-5
+    v2 = torch.randn(1, 256, 64, device="cuda", generator=g)
+    ref = torch.softmax(qh @ (kh * 1e-5).transpose(-1, -2) * 32 ** -0.5, dim=-1) @ v2.double().view(1, -1, 2, 32).transpose(1, 2)
+    uni = v2.double().view(1, -1, 2, 32).transpose(1, 2).mean(dim=2, keepdim=True)
+    got = ops.attention_d32(q, k2, v2, 2, 32 ** -0.5, split=True).double().view(1, 128, 2, 32).transpose(1, 2)
+    assert (got - ref).abs().max().item() < 0.05 * (ref - uni).abs().max().item()
+
+
 @pytest.mark.parametrize("shape", [(2, 4, 8, 64, 128), (1, 3, 5, 37, 61), (1, 64, 128, 1024, 2048)])
 def test_depth_upsample_combine_matches_torch(ops, shape):
     B, h, w, H, W = shape

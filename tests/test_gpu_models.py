@@ -54,14 +54,19 @@ def test_segformer_model_hip_vs_as_written(P):
     assert (out["depth"].cpu() - ref["depth"]).abs().max().item() < 1e-4
 
 
-def test_segformer_model_hip_vs_as_written_own_attention_path(P):
-    """256x256: every MiT stage has 64 keys (a multiple of 32), so the encoder runs awseg_attention_d32, not the
-    SDPA fall-back the smaller sizes take."""
+@pytest.mark.parametrize("split", [False, True])
+def test_segformer_model_hip_vs_as_written_own_attention_path(P, split, monkeypatch):
+    """256x256: every MiT stage has 64 keys (a multiple of 32), so the encoder runs awseg_attention_d32 (float32 MFMA)
+    or awseg_attention_d32_split (split-operand f16 MFMA), not the SDPA fall-back the smaller sizes take; both against
+    the as-written CPU graph at the same 1e-4 gate."""
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import ops as O
+    monkeypatch.setattr(O, "ATTENTION_SPLIT", split)
     torch.manual_seed(3)
     m = calibrate_bn(P.SegFormerModel(num_classes=19, include_depth=True, pretrained=False)).cuda().eval()
     x = torch.randn(1, 3, 256, 256, device="cuda")
     out = m(x)
     ref = as_written_cpu(m, x)
+    print(f"segformer 256x256 split={split}: logits rel err {rel_err(out['segmentation'].cpu(), ref['segmentation']):.3e}")
     assert rel_err(out["segmentation"].cpu(), ref["segmentation"]) < 1e-4
     assert (out["depth"].cpu() - ref["depth"]).abs().max().item() < 1e-4
 

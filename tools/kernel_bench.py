@@ -143,7 +143,8 @@ def main():
     def attn_case(name, nh, nq, nkv):
         qa = torch.randn(B, nq, nh * 32, device=dev); ka = torch.randn(B, nkv, nh * 32, device=dev); va = torch.randn(B, nkv, nh * 32, device=dev)
         fl = 4.0 * B * nh * nq * nkv * 32
-        cases[name] = (lambda: ops.attention_d32(qa, ka, va, nh, 32 ** -0.5), "mfma", fl)
+        cases[name] = (lambda: ops.attention_d32(qa, ka, va, nh, 32 ** -0.5, split=False), "mfma", fl)
+        cases[name + " [split f16x3, issued flops]"] = (lambda: ops.attention_d32(qa, ka, va, nh, 32 ** -0.5, split=True), "mfma_f16", 3 * fl)
         qh, kh, vh = (t.view(B, -1, nh, 32).transpose(1, 2) for t in (qa, ka, va))
         cases[name + " [torch SDPA]"] = (lambda: torch.nn.functional.scaled_dot_product_attention(qh, kh, vh, scale=32 ** -0.5), "mfma", fl)
     attn_case("attention d32 stage1 (131072 q x 2048 k, 1 head)", 1, (H // 4) * (W // 4), (H // 32) * (W // 32))
@@ -161,6 +162,8 @@ def main():
         med, best = timeit(fn, a.iters)
         if bound == "hbm":
             ach, peak, unit = work / (med * 1e-3) / 1e9, HBM, "GB/s"
+        elif bound == "mfma_f16":
+            ach, peak, unit = work / (med * 1e-3) / 1e12, 2516.6, "TFLOP/s"
         else:
             ach, peak, unit = work / (med * 1e-3) / 1e12, MFMA, "TFLOP/s"
         rows.append({"kernel": name, "median_ms": round(med, 4), "min_ms": round(best, 4), "bound": bound,

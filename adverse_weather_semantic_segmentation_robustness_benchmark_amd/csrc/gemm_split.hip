@@ -1,0 +1,295 @@
+// gemm_split.hip — out[M,N] = act(x[M,K] . w[N,K]^T + bias[N] (+ residual[M,N])) in float32 grade on the f16 matrix
+// cores: the compute-bound 1x1 convolutions of the ResNet-50 encoder (layer3 / layer4), the ASPP projections and the
+// decoder (PKG/models/model.py:349) — the same operator as awseg_gemm_bias_act (gemm.hip, hipBLASLt on the
+// float32-input MFMA), which stays the path for the HBM-bound shapes.
+//
+// v_mfma_f32_32x32x16_f16 issues 16x the multiply-adds per cycle of the float32-input MFMA, and a float32 product is
+// three f16 products once both operands are SPLIT (attn.hip has the same scheme, measured there against float64):
+//     x = xh + xl / 2048,  xh = f16(x),  xl = f16((x - xh) * 2048)            (22 significant bits)
+//     x * w = xh*wh + (xh*wl + xl*wh) / 2048                                  (+ O(2^-22 |x w|), dropped)
+// Every f16 product is exact in the float32 accumulator and the accumulation itself is float32, so the result differs
+// from a float32 GEMM by operand rounding at 2^-22 instead of 2^-24 — the same order as the difference between two
+// float32 summation orders (tests/test_gpu_kernels.py prices both against float64).
+//   * weights are split once (awseg_gemm_split_weights -> [2][N][K] f16), activations at tile-load time;
+//   * block = 128 x 128 outputs, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles with a main and a correction
+//     accumulator (128 accumulator registers); K tiles of 32, double-buffered in LDS, next tile's global loads in
+//     flight during the MFMAs; LDS rows = 32 hi | 32 lo | pad halfs (144 B: conflict-free ds_read_b128);
+//   * lanes own output COLUMNS (n), so a store instruction writes 128 contiguous bytes per output row;
+//   * persistent blocks (two per CU) walk the tiles XCD-aware (the turns of one XCD sweep the n-tiles of one m-tile
+//     band, whose x rows stay in that XCD's L2) and fetch the next tile's first K tile before their own epilogue, so
+//     the epilogue's stores and the next prologue's load latency overlap.
+// Inputs must be finite and below 65504 in magnitude.
+#include "awseg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GT = 256;          // threads
+constexpr int GBM = 128, GBN = 128, GKT = 32;
+constexpr int GROW = 72;         // halfs per LDS row: 32 hi | 32 lo | 8 pad
+constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
+
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo)
+{
+    const auto hp = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const h2 hh = __builtin_bit_cast(h2, hp);
+    const float ra = (a - (float)hh.x) * kLoScale, rb = (b - (float)hh.y) * kLoScale;
+    hi = __builtin_bit_cast(unsigned, hp);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
+}
+
+__global__ __launch_bounds__(GT)
+void split_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_t* __restrict__ out)
+{
+    const int64_t i = ((int64_t)blockIdx.x * GT + threadIdx.x) * 2;
+    if (i >= n_elems) return;
+    const float a = w[i], b = (i + 1 < n_elems) ? w[i + 1] : 0.f;
+    unsigned hi, lo;
+    split_pair(a, b, hi, lo);
+    out[i] = (uint16_t)hi; out[n_elems + i] = (uint16_t)lo;
+    if (i + 1 < n_elems) { out[i + 1] = (uint16_t)(hi >> 16); out[n_elems + i + 1] = (uint16_t)(lo >> 16); }
+}
+
+struct gemm_args {
+    const float* x; const _Float16* wh; const _Float16* wl; const float* bias; const float* residual; float* out;
+    int64_t M; int N, K, act, ntm, ntm8, ntn;
+};
+
+__device__ __forceinline__ constexpr int acc_row(int r, int hk) { return (r & 3) + 8 * (r >> 2) + 4 * hk; }
+
+template <bool KTAIL>
+__global__ __launch_bounds__(GT, 2)
+void gemm_split_kernel(gemm_args a)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][GBM * GROW];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][GBN * GROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int K = a.K;
+    const int ntiles = a.ntm8 * a.ntn;                           // tile slots (m-tiles rounded up to 8 per group)
+
+    // staging roles.  A: 128 rows x 8 float4 (k = 4c .. 4c+3); thread -> rows (tid>>3) + 32 i, column group c = tid & 7
+    const int ar = tid >> 3, ac = tid & 7;
+    // B: 128 rows x (4 hi + 4 lo) 16-byte chunks; chunk q = tid + 256 i: part = q >> 9, row = (q & 511) >> 2, c8 = q & 3
+    int bdst[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + 256 * i, part = q >> 9, r = (q & 511) >> 2, c8 = q & 3;
+        bdst[i] = r * GROW + part * 32 + 8 * c8;
+    }
+    // persistent walk over the tiles, XCD-aware: slot % 8 is the XCD (gridDim.x is a multiple of 8); consecutive turns
+    // of one XCD sweep the n-tiles of one m-tile, so the x rows it re-reads are in that XCD's L2
+    auto tile_of = [&](int slot, int64_t& m0, int& n0) -> bool {
+        const int xcd = slot & 7, jj = slot >> 3;
+        const int nt_i = jj % a.ntn, mt_i = (jj / a.ntn) * 8 + xcd;
+        m0 = (int64_t)mt_i * GBM; n0 = nt_i * GBN;
+        return mt_i < a.ntm;
+    };
+    // operand addresses of the tile being fetched: block-uniform bases (scalar registers) + 32-bit lane offsets
+    const float* xb = nullptr; const _Float16* whb = nullptr; const _Float16* wlb = nullptr;
+    int aoff[4], boff[2];
+    auto point = [&](int64_t m0, int n0) {
+        xb = a.x + m0 * K; whb = a.wh + (int64_t)n0 * K; wlb = a.wl + (int64_t)n0 * K;
+        const int64_t mleft = a.M - m0;                          // clamped rows are computed and never stored
+        const int nleft = a.N - n0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = ar + 32 * i;
+            aoff[i] = (int)(row < mleft ? row : mleft - 1) * K + 4 * ac;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                            // chunks i and i + 2 are the hi / lo halves of one row
+            const int r = ((tid + 256 * i) & 511) >> 2, c8 = tid & 3;
+            boff[i] = (r < nleft ? r : nleft - 1) * K + 8 * c8;
+        }
+    };
+    float4 areg[4]; u32x4 breg[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            if (KTAIL && k0 + 4 * ac >= K) areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            else areg[i] = *reinterpret_cast<const float4*>(xb + aoff[i] + k0);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c8 = tid & 3;
+            if (KTAIL && k0 + 8 * c8 >= K) breg[i] = u32x4{0u, 0u, 0u, 0u};
+            else breg[i] = *reinterpret_cast<const u32x4*>((i < 2 ? whb : wlb) + boff[i & 1] + k0);
+        }
+    };
+    auto stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u32x2 H, L; unsigned hh, ll;
+            split_pair(areg[i].x, areg[i].y, hh, ll); H[0] = hh; L[0] = ll;
+            split_pair(areg[i].z, areg[i].w, hh, ll); H[1] = hh; L[1] = ll;
+            _Float16* d = &sA[buf][(ar + 32 * i) * GROW + 4 * ac];
+            *reinterpret_cast<u32x2*>(d) = H;
+            *reinterpret_cast<u32x2*>(d + 32) = L;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&sB[buf][bdst[i]]) = breg[i];
+    };
+
+    const int nkt = (K + GKT - 1) / GKT;
+    const int fa = (wm * 64 + li) * GROW + 8 * hk;               // this lane's fragment row in sA (m-tile 0)
+    const int fb = (wn * 64 + li) * GROW + 8 * hk;
+
+    // first live tile of this block
+    int slot = blockIdx.x;
+    int64_t m0 = 0; int n0 = 0;
+    while (slot < ntiles && !tile_of(slot, m0, n0)) slot += gridDim.x;
+    if (slot >= ntiles) return;                                  // block-uniform, before any barrier
+    point(m0, n0);
+    fetch(0);
+
+    while (true) {
+        // next live tile (its first K tile is fetched while this tile's last K tiles compute / its epilogue stores)
+        int nslot = slot + gridDim.x;
+        int64_t nm0 = 0; int nn0 = 0;
+        while (nslot < ntiles && !tile_of(nslot, nm0, nn0)) nslot += gridDim.x;
+        const bool has_next = nslot < ntiles;
+
+        f32x16 am[2][2], ac2[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { am[i][j][r] = 0.f; ac2[i][j][r] = 0.f; }
+
+        stage(0);
+        if (nkt > 1) fetch(GKT);
+        else if (has_next) { point(nm0, nn0); fetch(0); }
+        __syncthreads();
+
+        for (int t = 0; t < nkt; ++t) {
+            const int buf = t & 1;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                h8 Ah[2], Al[2], Bh[2], Bl[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const _Float16* pa = &sA[buf][fa + i * 32 * GROW + 16 * ks];
+                    Ah[i] = *reinterpret_cast<const h8*>(pa); Al[i] = *reinterpret_cast<const h8*>(pa + 32);
+                    const _Float16* pb = &sB[buf][fb + i * 32 * GROW + 16 * ks];
+                    Bh[i] = *reinterpret_cast<const h8*>(pb); Bl[i] = *reinterpret_cast<const h8*>(pb + 32);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bh[j], am[i][j], 0, 0, 0);
+                        ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bl[j], ac2[i][j], 0, 0, 0);
+                        ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i], Bh[j], ac2[i][j], 0, 0, 0);
+                    }
+            }
+            if (t + 1 < nkt) {
+                stage(buf ^ 1);
+                if (t + 2 < nkt) fetch((t + 2) * GKT);
+                else if (has_next) { point(nm0, nn0); fetch(0); }
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue: lane = output column n, registers = rows m.  Raw-buffer accesses relative to the tile: one lane
+        // offset per column group (out-of-range columns get an out-of-range VECTOR offset and are dropped) plus a scalar
+        // row offset.  The hardware range check covers the vector offset only, so the one tile band with rows past M
+        // takes the guarded form (row folded into the vector offset).  The residual loads of 8 rows are issued before
+        // their stores (residual may alias out: element-wise the same thread reads, then writes).
+        {
+            const int64_t tile_off = m0 * a.N + n0;
+            const int64_t rem = ((int64_t)a.M * a.N - tile_off) * 4;
+            const int nrec = rem > 0x7fffffff ? 0x7fffffff : (int)rem;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + tile_off), 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.residual ? a.residual : a.out) + tile_off), 0, nrec, 0x00020000);
+            const bool has_res = a.residual != nullptr;
+            const bool ragged = m0 + GBM > a.M;                  // block-uniform
+            const int mleft = ragged ? (int)(a.M - m0) : GBM;
+            const int vrow = (wm * 64 + 4 * hk) * a.N;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int nl = wn * 64 + j * 32 + li;
+                const bool n_ok = n0 + nl < a.N;
+                const float bv = (a.bias && n_ok) ? a.bias[n0 + nl] : 0.f;
+                const int voff = n_ok ? (vrow + nl) * 4 : (int)0x80000000;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        float rv[8]; int vo[8], so[8];
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = 8 * half + r8;
+                            const int rowc = i * 32 + (r & 3) + 8 * (r >> 2);                 // + wm * 64 + 4 * hk (in vrow)
+                            if (ragged) {
+                                vo[r8] = (wm * 64 + 4 * hk + rowc < mleft) ? voff + rowc * a.N * 4 : (int)0x80000000;
+                                so[r8] = 0;
+                            } else { vo[r8] = voff; so[r8] = rowc * a.N * 4; }
+                            rv[r8] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vo[r8], so[r8], 0)) : 0.f;
+                        }
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = 8 * half + r8;
+                            float vv = fmaf(ac2[i][j][r], kLoInv, am[i][j][r]) + bv + rv[r8];
+                            if (a.act == 1) vv = fmaxf(vv, 0.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, vo[r8], so[r8], 0);
+                        }
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        slot = nslot; m0 = nm0; n0 = nn0;
+    }
+}
+
+}  // namespace
+
+AWSEG_API int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w_split, awseg_stream_t stream)
+{
+    if (n == 0 || k == 0) return 0;
+    if (!w || !w_split || n < 0 || k < 0) return AWSEG_EINVAL;
+    const int64_t ne = (int64_t)n * k;
+    const int64_t blocks = (ne / 2 + GT) / GT;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(GT), 0, awseg_s(stream), w, ne, w_split);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split, const float* bias, const float* residual,
+                                        int act, float* out, int64_t m, int n, int k, awseg_stream_t stream)
+{
+    if (m == 0 || n == 0) return 0;
+    if (!x || !w_split || !out || m < 0 || n < 0 || k < 8 || act < 0 || act > 1) return AWSEG_EINVAL;
+    if (k % 8) return AWSEG_ERANGE;                              // 16-byte operand chunks
+    if (((uintptr_t)x & 15) || ((uintptr_t)w_split & 15)) return AWSEG_EALIGN;
+    gemm_args a;
+    a.x = x; a.wh = reinterpret_cast<const _Float16*>(w_split); a.wl = a.wh + (int64_t)n * k;
+    a.bias = bias; a.residual = residual; a.out = out; a.M = m; a.N = n; a.K = k; a.act = act;
+    const int64_t ntm = (m + GBM - 1) / GBM;
+    a.ntn = (n + GBN - 1) / GBN;
+    const int64_t ntm8 = (ntm + 7) / 8 * 8;                      // 8 m-tiles (one per XCD) x all n-tiles per group
+    if (ntm8 * a.ntn > 0x7fffffff || (int64_t)GBM * n > 0x7fffffff) return AWSEG_ERANGE;
+    a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
+    const int64_t slots = ntm8 * a.ntn;
+    static int cus = 0;                                          // CU count of the (single, per-process) device, read once
+    if (cus == 0) {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
+        cus = n_cu;
+    }
+    int64_t blocks = (int64_t)cus * 2 / 8 * 8;                   // persistent: two blocks per CU, a multiple of 8
+    if (blocks < 8) blocks = 8;
+    if (blocks > slots) blocks = slots;                          // slots is a multiple of 8
+    if (k % GKT) hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)blocks), dim3(GT), 0, awseg_s(stream), a);
+    else hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)blocks), dim3(GT), 0, awseg_s(stream), a);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

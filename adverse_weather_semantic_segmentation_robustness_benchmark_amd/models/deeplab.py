@@ -196,8 +196,15 @@ class DeepLabV3PlusDecoder(nn.Module):
         ps, pb = _bn_fold(aspp.project[1])
 
         def branch(inp, wmat, bn):
-            s, b = _bn_fold(bn)
-            return ops.gemm_bias_act(inp, wmat * s[:, None], b, 1)          # GEMM with bias + ReLU in the epilogue
+            from . import fused
+            want = ops.gemm_wants_split(inp.shape[0], wmat.shape[0], wmat.shape[1])
+
+            def fold():
+                s, b = _bn_fold(bn)
+                wf = (wmat * s[:, None]).contiguous()
+                return wf, b.contiguous(), (ops.gemm_split_weights(wf) if want else None)
+            wf, b, ws = fused.cached(bn, "aspp_fold%d" % int(want), (wmat, bn.weight, bn.bias, bn.running_mean, bn.running_var), fold)
+            return ops.gemm_bias_act(inp, wf, b, 1, w_split=ws)             # GEMM with bias + ReLU in the epilogue
 
         acc = None
         # branch 0: 1x1
@@ -231,7 +238,8 @@ class DeepLabV3PlusDecoder(nn.Module):
         d = ops.dwconv3x3_upcat(fused.nhwc_view(a), fused.nhwc_view(hi), fused.dw_taps(dwc))
         B, H4, W4, Cc = d.shape
         w, shift = fused.folded_conv_bn(pwc, self.block2[1])
-        y = ops.gemm_bias_act(d.view(B * H4 * W4, Cc), w.view(w.shape[0], Cc), shift, N.ACT_RELU)
+        w2 = w.view(w.shape[0], Cc)
+        y = ops.gemm_bias_act(d.view(B * H4 * W4, Cc), w2, shift, N.ACT_RELU, w_split=fused.split_weights(pwc, w2, B * H4 * W4))
         return y.view(B, H4, W4, -1).permute(0, 3, 1, 2)
 
 

@@ -58,6 +58,13 @@ def cached(module: nn.Module, name: str, tensors, fn):
     return val
 
 
+def split_weights(owner: nn.Module, w2: torch.Tensor, m: int):
+    """gemm_split_weights(w2) cached on `owner` (None when the problem stays on the library GEMM)."""
+    if not ops.gemm_wants_split(m, w2.shape[0], w2.shape[1]):
+        return None
+    return cached(owner, "wsplit", (w2,), lambda: ops.gemm_split_weights(w2))
+
+
 def dw_taps(conv: nn.Conv2d) -> torch.Tensor:
     """[C,1,3,3] depthwise weight -> [9, C] tap-major."""
     return cached(conv, "w9", [conv.weight], lambda: conv.weight.view(conv.weight.shape[0], 9).t().contiguous())
@@ -113,7 +120,8 @@ def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, 
         w2 = w.view(Cout, Cin)
         if act in (N.ACT_RELU, N.ACT_NONE):
             r2 = None if residual is None else nhwc_view(residual).reshape(B * H * W, Cout)
-            y2 = ops.gemm_bias_act(x2, w2, shift, act, residual=r2, out=r2 if (r2 is not None and residual_is_scratch) else None)
+            y2 = ops.gemm_bias_act(x2, w2, shift, act, residual=r2, out=r2 if (r2 is not None and residual_is_scratch) else None,
+                                   w_split=split_weights(conv, w2, B * H * W))
         else:
             y2 = torch.addmm(shift, x2, w2.t()) if residual is None else torch.addmm(nhwc_view(residual).reshape(B * H * W, Cout), x2, w2.t())
             ops.bias_act_nhwc_(y2, torch.zeros_like(shift) if residual is None else shift, None, act)
@@ -171,7 +179,8 @@ def separable_bn_relu(x: torch.Tensor, sep, bn: nn.BatchNorm2d) -> torch.Tensor:
     B, H, W, C = xl.shape
     d = ops.dwconv3x3_nhwc(xl, dw_taps(dwc), None, N.ACT_NONE, dilation=dwc.dilation[0])
     w, shift = folded_conv_bn(pwc, bn)                                   # [Cout,Cin,1,1]
-    y = ops.gemm_bias_act(d.view(B * H * W, C), w.view(w.shape[0], C), shift, N.ACT_RELU)
+    w2 = w.view(w.shape[0], C)
+    y = ops.gemm_bias_act(d.view(B * H * W, C), w2, shift, N.ACT_RELU, w_split=split_weights(pwc, w2, B * H * W))
     return y.view(B, H, W, -1).permute(0, 3, 1, 2)                       # NCHW view, channels_last memory
 
 
@@ -188,7 +197,7 @@ def _linear_residual(x2: torch.Tensor, lin: nn.Linear, tok: torch.Tensor) -> tor
     if lin.bias is None or not tok.is_contiguous():
         return tok + F.linear(x2, lin.weight, lin.bias).view_as(tok)
     t2 = tok.view(-1, tok.shape[-1])
-    ops.gemm_bias_act(x2, lin.weight, lin.bias, N.ACT_NONE, residual=t2, out=t2)
+    ops.gemm_bias_act(x2, lin.weight, lin.bias, N.ACT_NONE, residual=t2, out=t2, w_split=split_weights(lin, lin.weight, x2.shape[0]))
     return tok
 
 

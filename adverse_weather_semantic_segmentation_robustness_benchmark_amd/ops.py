@@ -441,14 +441,18 @@ _gemm_tuned = set()
 
 
 def gemm_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int = 0, residual: Optional[torch.Tensor] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """act(x[M,K] @ w[N,K]^T + bias (+ residual[M,N])) in one hipBLASLt call (epilogue-fused); `out` may be `residual`.
-    With AWSEG_GEMM_TUNE=1 the first call of a new (M,N,K,residual,act) times the library's candidate algorithms
-    on a scratch output (synchronising, once) and keeps the fastest."""
+                  out: Optional[torch.Tensor] = None, w_split: Optional[torch.Tensor] = None, split: Optional[bool] = None) -> torch.Tensor:
+    """act(x[M,K] @ w[N,K]^T + bias (+ residual[M,N])) in one launch with the epilogue fused; `out` may be `residual`.
+    Problems gemm_wants_split() accepts run on the split-operand f16-MFMA kernel (float32-grade, csrc/gemm_split.hip;
+    pass `w_split = gemm_split_weights(w)` to reuse the split weights, else they are split on the fly); the rest is one
+    hipBLASLt float32 call.  split=True/False overrides the choice.  With AWSEG_GEMM_TUNE=1 the first hipBLASLt call
+    of a new (M,N,K,residual,act) times the library's candidate algorithms (synchronising, once)."""
     x, w = x.contiguous(), w.contiguous()
     m, k = x.shape
     n = w.shape[0]
     bias = bias.contiguous()
+    if gemm_wants_split(m, n, k) if split is None else split:
+        return gemm_split_bias_act(x, w_split if w_split is not None else gemm_split_weights(w), bias, act, residual=residual, out=out)
     ws = N.workspace.get(x.device, GEMM_WORKSPACE_BYTES, tag="gemm")
     key = (str(x.device), m, n, k, residual is not None, act)
     if GEMM_TUNE and m > 0 and key not in _gemm_tuned:
@@ -463,6 +467,38 @@ def gemm_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int
         out = torch.empty(m, n, dtype=torch.float32, device=x.device)
     N.call("awseg_gemm_bias_act", N.ptr(x), N.ptr(w), N.ptr(bias), N.ptr(residual), act, N.ptr(out), m, n, k,
            N.ptr(ws), GEMM_WORKSPACE_BYTES, N.stream())
+    return out
+
+
+# 1x1 convolutions / Linear layers on the split-operand f16-MFMA GEMM (csrc/gemm_split.hip): faster than hipBLASLt's
+# float32 kernels on every ResNet / ASPP / decoder shape measured (tools/kernel_bench.py "gemm"), including the HBM-bound
+# ones; narrow outputs (N < 128 = one block tile) stay on the library.  AWSEG_GEMM_SPLIT=0 turns the split path off.
+GEMM_SPLIT = os.environ.get("AWSEG_GEMM_SPLIT", "1") != "0"
+GEMM_SPLIT_MIN_M, GEMM_SPLIT_MIN_N, GEMM_SPLIT_MIN_K = 128, 128, 64
+
+
+def gemm_wants_split(m: int, n: int, k: int) -> bool:
+    return GEMM_SPLIT and m >= GEMM_SPLIT_MIN_M and n >= GEMM_SPLIT_MIN_N and k >= GEMM_SPLIT_MIN_K and k % 8 == 0
+
+
+def gemm_split_weights(w: torch.Tensor) -> torch.Tensor:
+    """w float32 [N,K] -> int16 [2,N,K]: f16 bit patterns of the high parts and of the scaled low parts."""
+    w = w.contiguous()
+    n, k = w.shape
+    out = torch.empty(2, n, k, dtype=torch.int16, device=w.device)
+    N.call("awseg_gemm_split_weights", N.ptr(w), n, k, N.ptr(out), N.stream())
+    return out
+
+
+def gemm_split_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
+                        residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x[M,K] @ w[N,K]^T + bias (+ residual[M,N])) with w given as gemm_split_weights(w); `out` may be `residual`."""
+    x = x.contiguous()
+    m, k = x.shape
+    n = w_split.shape[1]
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    N.call("awseg_gemm_split_bias_act", N.ptr(x), N.ptr(w_split), N.ptr(bias), N.ptr(residual), act, N.ptr(out), m, n, k, N.stream())
     return out
 
 

@@ -85,6 +85,10 @@ def launch_work(name, args):
         # the same products, each issued as THREE f16 MFMA products (split operands): priced as issued, against the f16 peak
         b, heads, nq, nkv = args[4:8]
         return "mfma_f16", 3 * 4.0 * b * heads * nq * nkv * 32
+    if name == "awseg_gemm_split_bias_act":
+        # (x, w_split, bias, residual, act, out, m, n, k): three f16 MFMA products per float32-grade product, priced as issued
+        m, n, k = args[6:9]
+        return "mfma_f16", 3 * 2.0 * m * n * k
     if name == "awseg_dwconv3x3_nhwc":
         # (x, batch, H, W, C, ...): read + write of the activation
         _, b, h, w, c = args[:5]
@@ -319,6 +323,7 @@ def main():
                                    "all 5 weather conditions round-robin)", "per_gpu_batch": B, "global_batch": B * world,
                        "include_depth": not args.no_depth, "weather_rng": "philox (in-kernel)", "ensemble_logits_materialised": False,
                        "attention": ("split-operand f16 MFMA (22-bit operands, f32 accumulate)" if ops.ATTENTION_SPLIT else "f32 MFMA"),
+                       "gemm_1x1": ("split-operand f16 MFMA (22-bit operands, f32 accumulate)" if ops.GEMM_SPLIT else "hipBLASLt f32"),
                        "weights": "random init (no checkpoints offline)", "parallelism": f"batch-sharded x{world}, one int64 counter all-reduce"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "miou": {k: round(v, 6) for k, v in results.items()},

@@ -436,6 +436,19 @@ int awseg_gemm_tune(const float* x, const float* w, const float* bias, int has_r
                     float* scratch_out, int64_t m, int n, int k, void* workspace, size_t workspace_bytes,
                     awseg_stream_t stream);
 
+/* awseg_gemm_split_weights / awseg_gemm_split_bias_act: the operator of awseg_gemm_bias_act computed in float32 grade
+ * on the f16 matrix cores with SPLIT operands (x = f16(x) + f16((x - f16(x)) * 2048) / 2048: 22 significant bits;
+ * x*w = xh*wh + (xh*wl + xl*wh)/2048 as three f16 MFMA products, float32 accumulation) — for the compute-bound 1x1
+ * convolutions (ResNet layer3 / layer4, ASPP, decoder; PKG/models/model.py:349), where it runs at several times the
+ * float32-input MFMA rate.  awseg_gemm_split_weights writes w_split = uint16 [2][N][K] (f16 bit patterns: high parts,
+ * then scaled low parts) from w float32 [N][K], once per weight.  awseg_gemm_split_bias_act: x float32 [M][K],
+ * bias float32 [N] or NULL, residual float32 [M][N] or NULL (may alias out), act 0 none / 1 ReLU, out float32 [M][N].
+ * K % 8 == 0; x and w_split 16-byte aligned; operands finite and below 65504 in magnitude.  No workspace, no host
+ * state. */
+int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w_split, awseg_stream_t stream);
+int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split, const float* bias, const float* residual, int act,
+                              float* out, int64_t m, int n, int k, awseg_stream_t stream);
+
 /* awseg_dwconv3x3_upcat_nhwc: the depthwise 3x3 (stride 1, zero padding 1, no bias) of the DeepLabV3+ decoder's
  * block2 applied to cat(UpsamplingBilinear2d(align_corners=True)(a), hi) without materialising the upsampled
  * map or the concatenation: a float32 [B,h,w,Ca] (the ASPP branch at stride 16), hi float32 [B,H,W,Ch] (the

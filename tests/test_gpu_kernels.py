@@ -712,6 +712,45 @@ def test_attention_d32_split_flat_softmax(ops):
     assert (got.double() - ref).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72)])
+@pytest.mark.parametrize("res_act", [(False, 0), (True, 1)])
+def test_gemm_split_float32_grade(ops, shape, res_act):
+    """Split-operand f16-MFMA GEMM against float64, next to the hipBLASLt float32 GEMM on the same inputs: ragged M and
+    N, K not a multiple of the 32-wide K tile, bias / residual / ReLU epilogue, residual aliasing the output."""
+    M, Nn, K = shape
+    has_res, act = res_act
+    g = torch.Generator(device="cuda").manual_seed(M + Nn + K)
+    x = torch.randn(M, K, device="cuda", generator=g) * 2.0
+    w = torch.randn(Nn, K, device="cuda", generator=g) * 0.05
+    x[::7, ::3] *= 1e-5                                         # f16-subnormal high parts
+    bias = torch.randn(Nn, device="cuda", generator=g)
+    res = torch.randn(M, Nn, device="cuda", generator=g) if has_res else None
+    ref = x.double() @ w.double().t() + bias.double()
+    if has_res:
+        ref = ref + res.double()
+    if act:
+        ref = ref.clamp_min(0)
+    ws = ops.gemm_split_weights(w)
+    assert ws.shape == (2, Nn, K)
+    out = res.clone() if has_res else None
+    got = ops.gemm_split_bias_act(x, ws, bias, act, residual=out, out=out)
+    lib = ops.gemm_bias_act(x, w, bias, act, residual=res)
+    e_split = (got.double() - ref).abs().max().item()
+    e_lib = (lib.double() - ref).abs().max().item()
+    print(f"gemm {shape} res={has_res}: |err| hipBLASLt f32 {e_lib:.3e}, split {e_split:.3e}")
+    assert e_split < 1e-5 * max(1.0, ref.abs().max().item())
+    assert e_split < 4 * e_lib + 1e-6
+
+
+def test_gemm_split_abi_checks(ops):
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import _native as N
+    x = torch.zeros(8, 12, device="cuda"); ws = torch.zeros(2, 4, 12, dtype=torch.int16, device="cuda"); o = torch.zeros(8, 4, device="cuda")
+    rc = N.lib().awseg_gemm_split_bias_act(N.ptr(x), N.ptr(ws), None, None, 0, N.ptr(o), 8, 4, 12, N.stream())
+    assert rc != 0                                              # K % 8 != 0
+    rc = N.lib().awseg_gemm_split_bias_act(N.ptr(x), N.ptr(ws), None, None, 0, N.ptr(o), 0, 4, 16, N.stream())
+    assert rc == 0                                              # empty problem
+
+
 def test_attention_d32_split_tiny_operands(ops):
     """Whole tensors below the f16 normal range (|x| ~ 1e-5): the high parts are f16 SUBNORMALS, so this fails by
     ~100 % if the f16 matrix cores flushed subnormal inputs; the relative error must stay at float32 level."""

@@ -140,6 +140,29 @@ def main():
     wino_case("winograd 512->512 d2 @1/16 (resnet l4)", B, H // 16, W // 16, 512, 512, 2, False)
     wino_case("winograd 2048->256 @1/16 (deeplab depth)", B, H // 16, W // 16, 2048, 256, 1, False)
 
+    def gemm_case(name, m, n, k, res):
+        xg = torch.randn(m, k, device=dev); wg = torch.randn(n, k, device=dev) * 0.05; bg = torch.randn(n, device=dev)
+        rg = torch.randn(m, n, device=dev) if res else None
+        og = torch.empty(m, n, device=dev)
+        wsg = ops.gemm_split_weights(wg)
+        fl = 2.0 * m * n * k
+        by = 4.0 * (m * k + m * n * (2 if res else 1))
+        cases[f"gemm {name} M={m} N={n} K={k} [hipBLASLt f32]"] = (lambda: ops.gemm_bias_act(xg, wg, bg, 1, residual=rg, out=og), "mfma", fl)
+        cases[f"gemm {name} M={m} N={n} K={k} [split f16x3, issued flops]"] = (lambda: ops.gemm_split_bias_act(xg, wsg, bg, 1, residual=rg, out=og), "mfma_f16", 3 * fl)
+        cases[f"gemm {name} M={m} N={n} K={k} [split, as HBM bytes]"] = (lambda: ops.gemm_split_bias_act(xg, wsg, bg, 1, residual=rg, out=og), "hbm", by)
+    px4, px8, px16 = B * (H // 4) * (W // 4), B * (H // 8) * (W // 8), B * (H // 16) * (W // 16)
+    gemm_case("l1 conv3", px4, 256, 64, True)
+    gemm_case("l2 conv1", px8, 128, 512, False)
+    gemm_case("l2 conv3", px8, 512, 128, True)
+    gemm_case("l3 conv1", px16, 256, 1024, False)
+    gemm_case("l3 conv3", px16, 1024, 256, True)
+    gemm_case("l4 conv1", px16, 512, 2048, False)
+    gemm_case("l4 conv3", px16, 2048, 512, True)
+    gemm_case("aspp 1x1", px16, 256, 2048, False)
+    gemm_case("aspp project", px16, 256, 1280, False)
+    gemm_case("decoder pw1", px4, 256, 304, False)
+    gemm_case("decoder pw2", px4, 256, 256, False)
+
     def attn_case(name, nh, nq, nkv):
         qa = torch.randn(B, nq, nh * 32, device=dev); ka = torch.randn(B, nkv, nh * 32, device=dev); va = torch.randn(B, nkv, nh * 32, device=dev)
         fl = 4.0 * B * nh * nq * nkv * 32

@@ -11,9 +11,10 @@
 // from a float32 GEMM by operand rounding at 2^-22 instead of 2^-24 — the same order as the difference between two
 // float32 summation orders (tests/test_gpu_kernels.py prices both against float64).
 //   * weights are split once (awseg_gemm_split_weights -> [2][N][K] f16), activations at tile-load time;
-//   * block = 128 x 128 outputs, 4 waves as 2 x 2, each 64 x 64 = 2 x 2 MFMA tiles with a main and a correction
-//     accumulator (128 accumulator registers); K tiles of 32, double-buffered in LDS, next tile's global loads in
-//     flight during the MFMAs; LDS rows = 32 hi | 32 lo | pad halfs (144 B: conflict-free ds_read_b128);
+//   * block = 128 x 128 outputs, 8 waves as 4 x 2, each 32 x 64 = 1 x 2 MFMA tiles with a main and a correction
+//     accumulator (64 accumulator registers, ~120 VGPRs: four waves per SIMD, which is what hides the global-load
+//     latency of the K pipeline); K tiles of 32, double-buffered in LDS, next tile's global loads in flight during the
+//     MFMAs; LDS rows = 32 hi | 32 lo | pad halfs (144 B: conflict-free ds_read_b128);
 //   * lanes own output COLUMNS (n), so a store instruction writes 128 contiguous bytes per output row;
 //   * persistent blocks (two per CU) walk the tiles XCD-aware (the turns of one XCD sweep the n-tiles of one m-tile
 //     band, whose x rows stay in that XCD's L2) and fetch the next tile's first K tile before their own epilogue, so
@@ -29,7 +30,8 @@ typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int GT = 256;          // threads
+constexpr int GT = 512;          // threads of a GEMM block (8 waves)
+constexpr int SWT = 256;         // threads of the weight-split kernel
 constexpr int GBM = 128, GBN = 128, GKT = 32;
 constexpr int GROW = 72;         // halfs per LDS row: 32 hi | 32 lo | 8 pad
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
@@ -43,10 +45,10 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
-__global__ __launch_bounds__(GT)
+__global__ __launch_bounds__(SWT)
 void split_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_t* __restrict__ out)
 {
-    const int64_t i = ((int64_t)blockIdx.x * GT + threadIdx.x) * 2;
+    const int64_t i = ((int64_t)blockIdx.x * SWT + threadIdx.x) * 2;
     if (i >= n_elems) return;
     const float a = w[i], b = (i + 1 < n_elems) ? w[i + 1] : 0.f;
     unsigned hi, lo;
@@ -63,26 +65,21 @@ struct gemm_args {
 __device__ __forceinline__ constexpr int acc_row(int r, int hk) { return (r & 3) + 8 * (r >> 2) + 4 * hk; }
 
 template <bool KTAIL>
-__global__ __launch_bounds__(GT, 2)
+__global__ __launch_bounds__(GT, 4)
 void gemm_split_kernel(gemm_args a)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][GBM * GROW];
     __shared__ __attribute__((aligned(16))) _Float16 sB[2][GBN * GROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = lane >> 5, li = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves, each 32 rows x 64 columns
     const int K = a.K;
     const int ntiles = a.ntm8 * a.ntn;                           // tile slots (m-tiles rounded up to 8 per group)
 
-    // staging roles.  A: 128 rows x 8 float4 (k = 4c .. 4c+3); thread -> rows (tid>>3) + 32 i, column group c = tid & 7
+    // staging roles.  A: 128 rows x 8 float4 (k = 4c .. 4c+3); thread -> rows (tid>>3) + 64 i, column group c = tid & 7
     const int ar = tid >> 3, ac = tid & 7;
-    // B: 128 rows x (4 hi + 4 lo) 16-byte chunks; chunk q = tid + 256 i: part = q >> 9, row = (q & 511) >> 2, c8 = q & 3
-    int bdst[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = tid + 256 * i, part = q >> 9, r = (q & 511) >> 2, c8 = q & 3;
-        bdst[i] = r * GROW + part * 32 + 8 * c8;
-    }
+    // B: 128 rows x (4 hi + 4 lo) 16-byte chunks; thread -> row tid >> 2, chunk c8 = tid & 3, both halves (i = 0 hi, 1 lo)
+    const int bdst0 = (tid >> 2) * GROW + 8 * (tid & 3);
     // persistent walk over the tiles, XCD-aware: slot % 8 is the XCD (gridDim.x is a multiple of 8); consecutive turns
     // of one XCD sweep the n-tiles of one m-tile, so the x rows it re-reads are in that XCD's L2
     auto tile_of = [&](int slot, int64_t& m0, int& n0) -> bool {
@@ -93,52 +90,48 @@ void gemm_split_kernel(gemm_args a)
     };
     // operand addresses of the tile being fetched: block-uniform bases (scalar registers) + 32-bit lane offsets
     const float* xb = nullptr; const _Float16* whb = nullptr; const _Float16* wlb = nullptr;
-    int aoff[4], boff[2];
+    int aoff[2], boff;
     auto point = [&](int64_t m0, int n0) {
         xb = a.x + m0 * K; whb = a.wh + (int64_t)n0 * K; wlb = a.wl + (int64_t)n0 * K;
         const int64_t mleft = a.M - m0;                          // clamped rows are computed and never stored
         const int nleft = a.N - n0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = ar + 32 * i;
+        for (int i = 0; i < 2; ++i) {
+            const int row = ar + 64 * i;
             aoff[i] = (int)(row < mleft ? row : mleft - 1) * K + 4 * ac;
         }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {                            // chunks i and i + 2 are the hi / lo halves of one row
-            const int r = ((tid + 256 * i) & 511) >> 2, c8 = tid & 3;
-            boff[i] = (r < nleft ? r : nleft - 1) * K + 8 * c8;
-        }
+        const int r = tid >> 2;
+        boff = (r < nleft ? r : nleft - 1) * K + 8 * (tid & 3);
     };
-    float4 areg[4]; u32x4 breg[4];
+    float4 areg[2]; u32x4 breg[2];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             if (KTAIL && k0 + 4 * ac >= K) areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             else areg[i] = *reinterpret_cast<const float4*>(xb + aoff[i] + k0);
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c8 = tid & 3;
-            if (KTAIL && k0 + 8 * c8 >= K) breg[i] = u32x4{0u, 0u, 0u, 0u};
-            else breg[i] = *reinterpret_cast<const u32x4*>((i < 2 ? whb : wlb) + boff[i & 1] + k0);
+        for (int i = 0; i < 2; ++i) {
+            if (KTAIL && k0 + 8 * (tid & 3) >= K) breg[i] = u32x4{0u, 0u, 0u, 0u};
+            else breg[i] = *reinterpret_cast<const u32x4*>((i == 0 ? whb : wlb) + boff + k0);
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 2; ++i) {
             u32x2 H, L; unsigned hh, ll;
             split_pair(areg[i].x, areg[i].y, hh, ll); H[0] = hh; L[0] = ll;
             split_pair(areg[i].z, areg[i].w, hh, ll); H[1] = hh; L[1] = ll;
-            _Float16* d = &sA[buf][(ar + 32 * i) * GROW + 4 * ac];
+            _Float16* d = &sA[buf][(ar + 64 * i) * GROW + 4 * ac];
             *reinterpret_cast<u32x2*>(d) = H;
             *reinterpret_cast<u32x2*>(d + 32) = L;
         }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(&sB[buf][bdst[i]]) = breg[i];
+        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&sB[buf][bdst0 + 32 * i]) = breg[i];
     };
 
     const int nkt = (K + GKT - 1) / GKT;
-    const int fa = (wm * 64 + li) * GROW + 8 * hk;               // this lane's fragment row in sA (m-tile 0)
+    const int fa = (wm * 32 + li) * GROW + 8 * hk;               // this lane's fragment row in sA
     const int fb = (wn * 64 + li) * GROW + 8 * hk;
 
     // first live tile of this block
@@ -156,13 +149,11 @@ void gemm_split_kernel(gemm_args a)
         while (nslot < ntiles && !tile_of(nslot, nm0, nn0)) nslot += gridDim.x;
         const bool has_next = nslot < ntiles;
 
-        f32x16 am[2][2], ac2[2][2];
+        f32x16 am[2], ac2[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { am[i][j][r] = 0.f; ac2[i][j][r] = 0.f; }
+            for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac2[j][r] = 0.f; }
 
         stage(0);
         if (nkt > 1) fetch(GKT);
@@ -173,22 +164,20 @@ void gemm_split_kernel(gemm_args a)
             const int buf = t & 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                h8 Ah[2], Al[2], Bh[2], Bl[2];
+                const _Float16* pa = &sA[buf][fa + 16 * ks];
+                const h8 Ah = *reinterpret_cast<const h8*>(pa), Al = *reinterpret_cast<const h8*>(pa + 32);
+                h8 Bh[2], Bl[2];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const _Float16* pa = &sA[buf][fa + i * 32 * GROW + 16 * ks];
-                    Ah[i] = *reinterpret_cast<const h8*>(pa); Al[i] = *reinterpret_cast<const h8*>(pa + 32);
-                    const _Float16* pb = &sB[buf][fb + i * 32 * GROW + 16 * ks];
-                    Bh[i] = *reinterpret_cast<const h8*>(pb); Bl[i] = *reinterpret_cast<const h8*>(pb + 32);
+                for (int j = 0; j < 2; ++j) {
+                    const _Float16* pb = &sB[buf][fb + j * 32 * GROW + 16 * ks];
+                    Bh[j] = *reinterpret_cast<const h8*>(pb); Bl[j] = *reinterpret_cast<const h8*>(pb + 32);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bh[j], am[i][j], 0, 0, 0);
-                        ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bl[j], ac2[i][j], 0, 0, 0);
-                        ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i], Bh[j], ac2[i][j], 0, 0, 0);
-                    }
+                for (int j = 0; j < 2; ++j) {
+                    am[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[j], am[j], 0, 0, 0);
+                    ac2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[j], ac2[j], 0, 0, 0);
+                    ac2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[j], ac2[j], 0, 0, 0);
+                }
             }
             if (t + 1 < nkt) {
                 stage(buf ^ 1);
@@ -212,7 +201,7 @@ void gemm_split_kernel(gemm_args a)
             const bool has_res = a.residual != nullptr;
             const bool ragged = m0 + GBM > a.M;                  // block-uniform
             const int mleft = ragged ? (int)(a.M - m0) : GBM;
-            const int vrow = (wm * 64 + 4 * hk) * a.N;
+            const int vrow = (wm * 32 + 4 * hk) * a.N;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 const int nl = wn * 64 + j * 32 + li;
@@ -220,27 +209,24 @@ void gemm_split_kernel(gemm_args a)
                 const float bv = (a.bias && n_ok) ? a.bias[n0 + nl] : 0.f;
                 const int voff = n_ok ? (vrow + nl) * 4 : (int)0x80000000;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
+                for (int half = 0; half < 2; ++half) {
+                    float rv[8]; int vo[8], so[8];
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        float rv[8]; int vo[8], so[8];
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = 8 * half + r8;
+                        const int rowc = (r & 3) + 8 * (r >> 2);                              // + wm * 32 + 4 * hk (in vrow)
+                        if (ragged) {
+                            vo[r8] = (wm * 32 + 4 * hk + rowc < mleft) ? voff + rowc * a.N * 4 : (int)0x80000000;
+                            so[r8] = 0;
+                        } else { vo[r8] = voff; so[r8] = rowc * a.N * 4; }
+                        rv[r8] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vo[r8], so[r8], 0)) : 0.f;
+                    }
 #pragma unroll
-                        for (int r8 = 0; r8 < 8; ++r8) {
-                            const int r = 8 * half + r8;
-                            const int rowc = i * 32 + (r & 3) + 8 * (r >> 2);                 // + wm * 64 + 4 * hk (in vrow)
-                            if (ragged) {
-                                vo[r8] = (wm * 64 + 4 * hk + rowc < mleft) ? voff + rowc * a.N * 4 : (int)0x80000000;
-                                so[r8] = 0;
-                            } else { vo[r8] = voff; so[r8] = rowc * a.N * 4; }
-                            rv[r8] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vo[r8], so[r8], 0)) : 0.f;
-                        }
-#pragma unroll
-                        for (int r8 = 0; r8 < 8; ++r8) {
-                            const int r = 8 * half + r8;
-                            float vv = fmaf(ac2[i][j][r], kLoInv, am[i][j][r]) + bv + rv[r8];
-                            if (a.act == 1) vv = fmaxf(vv, 0.f);
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, vo[r8], so[r8], 0);
-                        }
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = 8 * half + r8;
+                        float vv = fmaf(ac2[j][r], kLoInv, am[j][r]) + bv + rv[r8];
+                        if (a.act == 1) vv = fmaxf(vv, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, vo[r8], so[r8], 0);
                     }
                 }
             }
@@ -257,8 +243,8 @@ AWSEG_API int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w
     if (n == 0 || k == 0) return 0;
     if (!w || !w_split || n < 0 || k < 0) return AWSEG_EINVAL;
     const int64_t ne = (int64_t)n * k;
-    const int64_t blocks = (ne / 2 + GT) / GT;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(GT), 0, awseg_s(stream), w, ne, w_split);
+    const int64_t blocks = (ne / 2 + SWT) / SWT;
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(SWT), 0, awseg_s(stream), w, ne, w_split);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

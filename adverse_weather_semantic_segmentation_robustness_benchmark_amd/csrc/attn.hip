@@ -182,6 +182,21 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     hi = __builtin_bit_cast(unsigned, hp);
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
+// the same without scaling the residual: for values whose low part is a normal (or harmlessly subnormal) f16 as is
+__device__ __forceinline__ void split_pair_unscaled(float a, float b, unsigned& hi, unsigned& lo)
+{
+    const auto hp = __builtin_amdgcn_cvt_pkrtz(a, b);
+    const h2 hh = __builtin_bit_cast(h2, hp);
+    hi = __builtin_bit_cast(unsigned, hp);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)hh.x, b - (float)hh.y));
+}
+__device__ __forceinline__ void split8_unscaled(const float* x, h8& hi, h8& lo)
+{
+    u32x4 H, L;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { unsigned h, l; split_pair_unscaled(x[2 * i], x[2 * i + 1], h, l); H[i] = h; L[i] = l; }
+    hi = __builtin_bit_cast(h8, H); lo = __builtin_bit_cast(h8, L);
+}
 __device__ __forceinline__ void split8(const float* x, h8& hi, h8& lo)
 {
     u32x4 H, L;
@@ -296,15 +311,18 @@ void attention_d32_split_kernel(const float* __restrict__ q, const float* __rest
             for (int r = 0; r < 16; ++r) { om[r] *= alpha; oc[r] *= alpha; }
         }
         // ---- O^T += V^T P^T: the probability tile, split, is the B operand: registers 8 s .. 8 s + 7 = k-step s
+        // The probabilities are pre-scaled to (0, 2^15], so their low parts need no scaling: p - f16(p) is a normal f16
+        // for p >= 2^-3 and below that a subnormal worth < 2^-40 of the row maximum (the f16 matrix cores keep
+        // subnormals) -> V_hi P_lo goes to the main accumulator, only V_lo' P_hi to the scaled correction.
         h8 ph0, pl0, ph1, pl1;
-        split8(p, ph0, pl0);
-        split8(p + 8, ph1, pl1);
+        split8_unscaled(p, ph0, pl0);
+        split8_unscaled(p + 8, ph1, pl1);
         om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, ph0, om, 0, 0, 0);
-        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl0, oc, 0, 0, 0);
-        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph1, om, 0, 0, 0);
-        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl1, oc, 0, 0, 0);
         oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph0, oc, 0, 0, 0);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph1, om, 0, 0, 0);
         oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph1, oc, 0, 0, 0);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl0, om, 0, 0, 0);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl1, om, 0, 0, 0);
         if (t + 1 < ntiles) {
             stage(buf ^ 1, kreg, vreg);
             if (t + 2 < ntiles) {

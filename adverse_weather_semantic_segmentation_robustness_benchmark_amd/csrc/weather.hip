@@ -283,6 +283,23 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<aw
     const int x0 = blockIdx.x * FTW, y0 = blockIdx.y * FTH;
     const float inv_h = 100.0f / (float)H;
     const bool interior_x = (x0 - FR >= 0) && (x0 + FTW + FR <= W);
+    // the source pixels of this thread's output quads (phase 3) are requested now, so the load latency hides behind the
+    // noise synthesis and the two filter passes instead of sitting in front of the blend
+    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
+    uint32_t pre[2][3] = { { 0u, 0u, 0u }, { 0u, 0u, 0u } };
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int q = threadIdx.x + it * kFogFastThreads;
+        if (q < FTH * (FTW / 4)) {
+            const int ty = q / (FTW / 4), tq = q - ty * (FTW / 4);
+            const int gy = y0 + ty, gx = x0 + tq * 4;
+            const int64_t p = (int64_t)gy * W + gx;
+            if (gy < H && gx + 4 <= W && (((p * 3) & 3) == 0)) {
+                const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
+                pre[it][0] = s4[0]; pre[it][1] = s4[1]; pre[it][2] = s4[2];
+            }
+        }
+    }
 
     // phase 1: (y/H)*100 + N(0,10) for the tile and its halo; one Philox call = 8 normals = 8 columns
     const int64_t Wo = (W + 7) / 8;
@@ -328,12 +345,14 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<aw
     }
     __syncthreads();
     // phase 3: axis-1 pass (4 adjacent outputs per lane) + transmission / blend / quantise
-    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
     double* ddst = depth_out ? depth_out + (int64_t)(job0 + blockIdx.z) * hw : nullptr;
     const float beta = (float)job.beta, A32 = (float)job.atmos;
-    for (int q = threadIdx.x; q < FTH * (FTW / 4); q += kFogFastThreads) {
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int q = threadIdx.x + it * kFogFastThreads;
+        if (q >= FTH * (FTW / 4)) break;
         const int ty = q / (FTW / 4), tq = q - ty * (FTW / 4);
         const int gy = y0 + ty, gx = x0 + tq * 4;
         if (gy >= H || gx >= W) continue;
@@ -358,8 +377,7 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<aw
         uint8_t px[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, res[12];
         const bool vec = (nvalid == 4) && (((p * 3) & 3) == 0);
         if (vec) {
-            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
-            uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
+            const uint32_t w0 = pre[it][0], w1 = pre[it][1], w2 = pre[it][2];
 #pragma unroll
             for (int k = 0; k < 4; ++k) { px[k] = (w0 >> (8 * k)) & 0xFF; px[4 + k] = (w1 >> (8 * k)) & 0xFF; px[8 + k] = (w2 >> (8 * k)) & 0xFF; }
         } else {

@@ -100,7 +100,8 @@ def winograd_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
 
 
 def _is_pointwise(conv: nn.Conv2d) -> bool:
-    return conv.kernel_size == (1, 1) and conv.stride == (1, 1) and conv.padding == (0, 0) and conv.groups == 1
+    # (dilation is irrelevant for a 1x1 kernel: smp's make_dilated sets it on every conv of the stage)
+    return conv.kernel_size == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (0, 0) and conv.groups == 1
 
 
 def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, residual: torch.Tensor = None,
@@ -114,6 +115,10 @@ def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, 
     MFMA kernel; the rest (7x7, strided) stays on MIOpen with the one-pass HIP epilogue."""
     w, shift = folded_conv_bn(conv, bn)
     if _is_pointwise(conv) and x.is_contiguous(memory_format=CL):
+        if conv.stride == (2, 2):
+            # a strided 1x1 (the ResNet downsample branches) reads every other pixel: gather them (one small copy,
+            # a quarter of x) and it is the same GEMM
+            x = x[:, :, ::2, ::2].contiguous(memory_format=CL)
         B, Cin, H, W = x.shape
         Cout = w.shape[0]
         x2 = x.permute(0, 2, 3, 1).reshape(B * H * W, Cin)

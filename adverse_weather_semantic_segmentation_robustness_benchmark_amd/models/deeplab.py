@@ -206,23 +206,34 @@ class DeepLabV3PlusDecoder(nn.Module):
             wf, b, ws = fused.cached(bn, "aspp_fold%d" % int(want), (wmat, bn.weight, bn.bias, bn.running_mean, bn.running_var), fold)
             return ops.gemm_bias_act(inp, wf, b, 1, w_split=ws)             # GEMM with bias + ReLU in the epilogue
 
-        acc = None
+        # projection: project(cat(b_0..b_4)) -> BN -> ReLU = relu(sum_i b_i (ps * P_i)^T + ps * (g P_4^T) + pb).  The pooled
+        # branch g is one row per image, so it enters as the initial value of the accumulator; the four pixel branches are
+        # GEMMs that accumulate in place (residual = out), the last one with the ReLU in its epilogue.
+        pbn = aspp.project[1]
+
+        def fold_proj():
+            Pf = (P * ps[:, None]).contiguous()
+            parts = [Pf[:, i * Cout:(i + 1) * Cout].contiguous() for i in range(5)]
+            want = ops.gemm_wants_split(B * h * w, Cout, Cout)
+            return parts, [ops.gemm_split_weights(pp) if want else None for pp in parts[:4]], torch.zeros(Cout, device=P.device)
+        from . import fused
+        parts, psplit, zero_bias = fused.cached(aspp.project[0], "proj_fold%d" % int(ops.gemm_wants_split(B * h * w, Cout, Cout)),
+                                                (aspp.project[0].weight, pbn.weight, pbn.bias, pbn.running_mean, pbn.running_var), fold_proj)
+        # pooling branch: global mean -> 1x1 -> BN -> ReLU; bilinear upsample of a 1x1 map is a broadcast
+        pool = aspp.convs[4]
+        g = branch(xl.mean(dim=(1, 2)), pool[1].weight.view(Cout, Cin), pool[2])       # [B,256]
+        acc = (g @ parts[4].t() + pb)[:, None, :].expand(B, h * w, Cout).contiguous().view(B * h * w, Cout)
         # branch 0: 1x1
         y = branch(flat, aspp.convs[0][0].weight.view(Cout, Cin), aspp.convs[0][1])
-        acc = y @ P[:, 0:Cout].t()
+        ops.gemm_bias_act(y, parts[0], zero_bias, 0, residual=acc, out=acc, w_split=psplit[0])
         # branches 1-3: depthwise (HIP, all three rates at once) then pointwise GEMM
         wdw = torch.stack([aspp.convs[1 + r][0][0].weight.view(Cin, 9).t() for r in range(3)]).contiguous()  # [3,9,C]
         dw = ops.aspp_depthwise3(xl, wdw, aspp.rates).view(3, B * h * w, Cin)
         for r in range(3):
             mod = aspp.convs[1 + r]
             y = branch(dw[r], mod[0][1].weight.view(Cout, Cin), mod[1])
-            acc.addmm_(y, P[:, (1 + r) * Cout:(2 + r) * Cout].t())
-        # pooling branch: global mean -> 1x1 -> BN -> ReLU; bilinear upsample of a 1x1 map is a broadcast
-        pool = aspp.convs[4]
-        g = branch(xl.mean(dim=(1, 2)), pool[1].weight.view(Cout, Cin), pool[2])       # [B,256]
-        gproj = g @ P[:, 4 * Cout:5 * Cout].t()                                       # [B,256]
-        acc = acc.view(B, h * w, Cout) + gproj[:, None, :]
-        out = (acc * ps + pb).relu_()                                                 # project BN + ReLU (Dropout: eval)
+            ops.gemm_bias_act(y, parts[1 + r], zero_bias, 1 if r == 2 else 0, residual=acc, out=acc, w_split=psplit[1 + r])
+        out = acc                                                                     # project BN + ReLU done (Dropout: eval)
         return out.view(B, h, w, Cout).permute(0, 3, 1, 2)                            # NCHW view, channels_last memory
 
     @torch.no_grad()

@@ -422,9 +422,11 @@ def test_conv3x3_winograd_abi_checks(ops, native):
 
 
 @pytest.mark.parametrize("shape", [(4096, 64, 256), (1000, 48, 304), (8 * 64 * 128, 256, 1024), (37, 19, 64)])
-def test_gemm_bias_act_epilogues(ops, shape):
-    """1x1 convolution as one hipBLASLt call: bias, residual (also in place) and ReLU in the epilogue, against
-    a float64 reference; 1e-4 abs on O(1) outputs."""
+@pytest.mark.parametrize("split", [False, None])
+def test_gemm_bias_act_epilogues(ops, shape, split):
+    """1x1 convolution as one launch — split=False: the hipBLASLt float32 call; None: whatever the dispatcher picks
+    (the split-operand kernel for the wide shapes) — bias, residual (also in place) and ReLU in the epilogue, against a
+    float64 reference; 1e-4 abs on O(1) outputs."""
     M, Nn, K = shape
     g = torch.Generator(device="cuda").manual_seed(M + Nn + K)
     x = torch.randn(M, K, device="cuda", generator=g)
@@ -432,13 +434,13 @@ def test_gemm_bias_act_epilogues(ops, shape):
     b = torch.randn(Nn, device="cuda", generator=g)
     r = torch.randn(M, Nn, device="cuda", generator=g)
     ref = x.double() @ w.double().t() + b.double()
-    assert (ops.gemm_bias_act(x, w, b, 0).double() - ref).abs().max().item() < 1e-4
-    assert (ops.gemm_bias_act(x, w, b, 1).double() - ref.clamp_min(0)).abs().max().item() < 1e-4
-    assert (ops.gemm_bias_act(x, w, b, 1, residual=r).double() - (ref + r.double()).clamp_min(0)).abs().max().item() < 1e-4
+    assert (ops.gemm_bias_act(x, w, b, 0, split=split).double() - ref).abs().max().item() < 1e-4
+    assert (ops.gemm_bias_act(x, w, b, 1, split=split).double() - ref.clamp_min(0)).abs().max().item() < 1e-4
+    assert (ops.gemm_bias_act(x, w, b, 1, residual=r, split=split).double() - (ref + r.double()).clamp_min(0)).abs().max().item() < 1e-4
     r2 = r.clone()
-    out = ops.gemm_bias_act(x, w, b, 0, residual=r2, out=r2)                  # accumulate over the residual's buffer
+    out = ops.gemm_bias_act(x, w, b, 0, residual=r2, out=r2, split=split)     # accumulate over the residual's buffer
     assert out.data_ptr() == r2.data_ptr() and (r2.double() - (ref + r.double())).abs().max().item() < 1e-4
-    assert ops.gemm_bias_act(x[:0], w, b, 1).shape == (0, Nn)
+    assert ops.gemm_bias_act(x[:0], w, b, 1, split=split).shape == (0, Nn)
 
 
 def test_aspp_depthwise3(ops):
@@ -712,7 +714,7 @@ def test_attention_d32_split_flat_softmax(ops):
     assert (got.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72)])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72), (200, 160, 264), (1100, 384, 1024)])
 @pytest.mark.parametrize("res_act", [(False, 0), (True, 1)])
 def test_gemm_split_float32_grade(ops, shape, res_act):
     """Split-operand f16-MFMA GEMM against float64, next to the hipBLASLt float32 GEMM on the same inputs: ragged M and
@@ -734,7 +736,7 @@ def test_gemm_split_float32_grade(ops, shape, res_act):
     assert ws.shape == (2, Nn, K)
     out = res.clone() if has_res else None
     got = ops.gemm_split_bias_act(x, ws, bias, act, residual=out, out=out)
-    lib = ops.gemm_bias_act(x, w, bias, act, residual=res)
+    lib = ops.gemm_bias_act(x, w, bias, act, residual=res, split=False)
     e_split = (got.double() - ref).abs().max().item()
     e_lib = (lib.double() - ref).abs().max().item()
     print(f"gemm {shape} res={has_res}: |err| hipBLASLt f32 {e_lib:.3e}, split {e_split:.3e}")

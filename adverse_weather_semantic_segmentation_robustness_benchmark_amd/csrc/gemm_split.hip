@@ -12,9 +12,9 @@
 // float32 summation orders (tests/test_gpu_kernels.py prices both against float64).
 //   * weights are split once (awseg_gemm_split_weights -> [2][N][K] f16), activations at tile-load time;
 //   * block = 128 x 128 outputs, 8 waves as 4 x 2, each 32 x 64 = 1 x 2 MFMA tiles with a main and a correction
-//     accumulator (64 accumulator registers, ~120 VGPRs: four waves per SIMD, which is what hides the global-load
-//     latency of the K pipeline); K tiles of 32, double-buffered in LDS, next tile's global loads in flight during the
-//     MFMAs; LDS rows = 32 hi | 32 lo | pad halfs (144 B: conflict-free ds_read_b128);
+//     accumulator (64 accumulator registers, 128 VGPRs: four waves per SIMD); K tiles of 32, double-buffered in LDS,
+//     next tile's global loads in flight during the MFMAs; LDS rows = 32 hi | 32 lo | pad halfs (144 B: conflict-free
+//     ds_read_b128).  Measured limit: the operand-fetch rate, not the MFMA, LDS or vector pipes;
 //   * lanes own output COLUMNS (n), so a store instruction writes 128 contiguous bytes per output row;
 //   * persistent blocks (two per CU) walk the tiles XCD-aware (the turns of one XCD sweep the n-tiles of one m-tile
 //     band, whose x rows stay in that XCD's L2) and fetch the next tile's first K tile before their own epilogue, so

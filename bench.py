@@ -210,12 +210,18 @@ def main():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--no-depth", action="store_true", help="build the ensemble with include_depth=False")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fp32-mfma", action="store_true",
+                    help="attention and 1x1 convolutions on the float32-input MFMA kernels (own fp32 attention, hipBLASLt fp32) "
+                         "instead of the split-operand f16-MFMA ones (DESIGN.md 5b); same as AWSEG_ATTN_SPLIT=0 AWSEG_GEMM_SPLIT=0")
     ap.add_argument("--conv-search", type=int, default=int(os.environ.get("AWSEG_CONV_SEARCH", "0")),
                     help="1: let MIOpen time its solvers per convolution shape during warm-up (torch.backends.cudnn.benchmark)")
     args = ap.parse_args()
     torch.backends.cudnn.benchmark = bool(args.conv_search)
 
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd import ops, parallel
+    if args.fp32_mfma:
+        ops.ATTENTION_SPLIT = False
+        ops.GEMM_SPLIT = False
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import EnsembleModel
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd.evaluation.metrics import RobustnessMetrics
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data.preprocessing import WeatherDegradationTransforms

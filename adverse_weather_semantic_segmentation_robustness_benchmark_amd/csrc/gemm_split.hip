@@ -32,7 +32,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GT = 512;          // threads of a GEMM block (8 waves)
 constexpr int SWT = 256;         // threads of the weight-split kernel
-constexpr int GBM = 128, GBN = 128, GKT = 32;
+constexpr int GKT = 32;          // K tile
 constexpr int GROW = 72;         // halfs per LDS row: 32 hi | 32 lo | 8 pad
 constexpr float kLoScale = 2048.0f, kLoInv = 1.0f / 2048.0f;
 
@@ -64,61 +64,72 @@ struct gemm_args {
 
 __device__ __forceinline__ constexpr int acc_row(int r, int hk) { return (r & 3) + 8 * (r >> 2) + 4 * hk; }
 
-template <bool KTAIL>
-__global__ __launch_bounds__(GT, 4)
+// MT x NT MFMA tiles per wave, WM x WN waves per block (8 waves): block tile (32 MT WM) x (32 NT WN).
+//   <1, 2, 4, 2>: 128 x 128, 64 accumulator registers per lane, four waves per SIMD, two blocks per CU
+//   <2, 2, 2, 4>: 128 x 256, 128 accumulator registers, two waves per SIMD, one block per CU: 25 % fewer operand bytes
+//                 fetched per multiply-add (the measured limit) for the shapes with N >= 256
+template <int MT, int NT, int WM, int WN, bool KTAIL>
+__global__ __launch_bounds__(GT, (MT * NT <= 2 ? 4 : 2))
 void gemm_split_kernel(gemm_args a)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 sA[2][GBM * GROW];
-    __shared__ __attribute__((aligned(16))) _Float16 sB[2][GBN * GROW];
+    static_assert(WM * WN == 8, "eight waves");
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
+    constexpr int NA = BM / 64;                                  // float4 of x per thread per K tile
+    constexpr int NB = BN / 64;                                  // 16-byte chunks of w per thread per K tile (hi and lo)
+    __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * GROW];
+    __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * GROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = lane >> 5, li = lane & 31;
-    const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves, each 32 rows x 64 columns
+    const int wm = wave / WN, wn = wave % WN;                    // WM x WN waves, each (32 MT) rows x (32 NT) columns
     const int K = a.K;
     const int ntiles = a.ntm8 * a.ntn;                           // tile slots (m-tiles rounded up to 8 per group)
 
     // staging roles.  A: 128 rows x 8 float4 (k = 4c .. 4c+3); thread -> rows (tid>>3) + 64 i, column group c = tid & 7
     const int ar = tid >> 3, ac = tid & 7;
-    // B: 128 rows x (4 hi + 4 lo) 16-byte chunks; thread -> row tid >> 2, chunk c8 = tid & 3, both halves (i = 0 hi, 1 lo)
+    // B: BN rows x (4 hi + 4 lo) 16-byte chunks; thread -> rows (tid >> 2) + 128 (i >> 1), chunk c8 = tid & 3, half i & 1
     const int bdst0 = (tid >> 2) * GROW + 8 * (tid & 3);
     // persistent walk over the tiles, XCD-aware: slot % 8 is the XCD (gridDim.x is a multiple of 8); consecutive turns
     // of one XCD sweep the n-tiles of one m-tile, so the x rows it re-reads are in that XCD's L2
     auto tile_of = [&](int slot, int64_t& m0, int& n0) -> bool {
         const int xcd = slot & 7, jj = slot >> 3;
         const int nt_i = jj % a.ntn, mt_i = (jj / a.ntn) * 8 + xcd;
-        m0 = (int64_t)mt_i * GBM; n0 = nt_i * GBN;
+        m0 = (int64_t)mt_i * BM; n0 = nt_i * BN;
         return mt_i < a.ntm;
     };
     // operand addresses of the tile being fetched: block-uniform bases (scalar registers) + 32-bit lane offsets
     const float* xb = nullptr; const _Float16* whb = nullptr; const _Float16* wlb = nullptr;
-    int aoff[2], boff;
+    int aoff[NA], boff[NB / 2];
     auto point = [&](int64_t m0, int n0) {
         xb = a.x + m0 * K; whb = a.wh + (int64_t)n0 * K; wlb = a.wl + (int64_t)n0 * K;
         const int64_t mleft = a.M - m0;                          // clamped rows are computed and never stored
         const int nleft = a.N - n0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             const int row = ar + 64 * i;
             aoff[i] = (int)(row < mleft ? row : mleft - 1) * K + 4 * ac;
         }
-        const int r = tid >> 2;
-        boff = (r < nleft ? r : nleft - 1) * K + 8 * (tid & 3);
+#pragma unroll
+        for (int i = 0; i < NB / 2; ++i) {
+            const int r = (tid >> 2) + 128 * i;
+            boff[i] = (r < nleft ? r : nleft - 1) * K + 8 * (tid & 3);
+        }
     };
-    float4 areg[2]; u32x4 breg[2];
+    float4 areg[NA]; u32x4 breg[NB];
     auto fetch = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             if (KTAIL && k0 + 4 * ac >= K) areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             else areg[i] = *reinterpret_cast<const float4*>(xb + aoff[i] + k0);
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NB; ++i) {
             if (KTAIL && k0 + 8 * (tid & 3) >= K) breg[i] = u32x4{0u, 0u, 0u, 0u};
-            else breg[i] = *reinterpret_cast<const u32x4*>((i == 0 ? whb : wlb) + boff + k0);
+            else breg[i] = *reinterpret_cast<const u32x4*>(((i & 1) == 0 ? whb : wlb) + boff[i >> 1] + k0);
         }
     };
     auto stage = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < NA; ++i) {
             u32x2 H, L; unsigned hh, ll;
             split_pair(areg[i].x, areg[i].y, hh, ll); H[0] = hh; L[0] = ll;
             split_pair(areg[i].z, areg[i].w, hh, ll); H[1] = hh; L[1] = ll;
@@ -127,12 +138,12 @@ void gemm_split_kernel(gemm_args a)
             *reinterpret_cast<u32x2*>(d + 32) = L;
         }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4*>(&sB[buf][bdst0 + 32 * i]) = breg[i];
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(&sB[buf][bdst0 + (i >> 1) * 128 * GROW + 32 * (i & 1)]) = breg[i];
     };
 
     const int nkt = (K + GKT - 1) / GKT;
-    const int fa = (wm * 32 + li) * GROW + 8 * hk;               // this lane's fragment row in sA
-    const int fb = (wn * 64 + li) * GROW + 8 * hk;
+    const int fa = (wm * 32 * MT + li) * GROW + 8 * hk;          // this lane's fragment row in sA (m-tile 0)
+    const int fb = (wn * 32 * NT + li) * GROW + 8 * hk;
 
     // first live tile of this block
     int slot = blockIdx.x;
@@ -149,11 +160,13 @@ void gemm_split_kernel(gemm_args a)
         while (nslot < ntiles && !tile_of(nslot, nm0, nn0)) nslot += gridDim.x;
         const bool has_next = nslot < ntiles;
 
-        f32x16 am[2], ac2[2];
+        f32x16 am[MT][NT], ac2[MT][NT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { am[j][r] = 0.f; ac2[j][r] = 0.f; }
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { am[i][j][r] = 0.f; ac2[i][j][r] = 0.f; }
 
         stage(0);
         if (nkt > 1) fetch(GKT);
@@ -164,20 +177,25 @@ void gemm_split_kernel(gemm_args a)
             const int buf = t & 1;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const _Float16* pa = &sA[buf][fa + 16 * ks];
-                const h8 Ah = *reinterpret_cast<const h8*>(pa), Al = *reinterpret_cast<const h8*>(pa + 32);
-                h8 Bh[2], Bl[2];
+                h8 Ah[MT], Al[MT], Bh[NT], Bl[NT];
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int i = 0; i < MT; ++i) {
+                    const _Float16* pa = &sA[buf][fa + i * 32 * GROW + 16 * ks];
+                    Ah[i] = *reinterpret_cast<const h8*>(pa); Al[i] = *reinterpret_cast<const h8*>(pa + 32);
+                }
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
                     const _Float16* pb = &sB[buf][fb + j * 32 * GROW + 16 * ks];
                     Bh[j] = *reinterpret_cast<const h8*>(pb); Bl[j] = *reinterpret_cast<const h8*>(pb + 32);
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    am[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[j], am[j], 0, 0, 0);
-                    ac2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[j], ac2[j], 0, 0, 0);
-                    ac2[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[j], ac2[j], 0, 0, 0);
-                }
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bh[j], am[i][j], 0, 0, 0);
+                        ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bl[j], ac2[i][j], 0, 0, 0);
+                        ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i], Bh[j], ac2[i][j], 0, 0, 0);
+                    }
             }
             if (t + 1 < nkt) {
                 stage(buf ^ 1);
@@ -199,34 +217,37 @@ void gemm_split_kernel(gemm_args a)
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + tile_off), 0, nrec, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.residual ? a.residual : a.out) + tile_off), 0, nrec, 0x00020000);
             const bool has_res = a.residual != nullptr;
-            const bool ragged = m0 + GBM > a.M;                  // block-uniform
-            const int mleft = ragged ? (int)(a.M - m0) : GBM;
-            const int vrow = (wm * 32 + 4 * hk) * a.N;
+            const bool ragged = m0 + BM > a.M;                   // block-uniform
+            const int mleft = ragged ? (int)(a.M - m0) : BM;
+            const int vrow = (wm * 32 * MT + 4 * hk) * a.N;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int nl = wn * 64 + j * 32 + li;
+            for (int j = 0; j < NT; ++j) {
+                const int nl = wn * 32 * NT + j * 32 + li;
                 const bool n_ok = n0 + nl < a.N;
                 const float bv = (a.bias && n_ok) ? a.bias[n0 + nl] : 0.f;
                 const int voff = n_ok ? (vrow + nl) * 4 : (int)0x80000000;
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float rv[8]; int vo[8], so[8];
+                for (int i = 0; i < MT; ++i) {
 #pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = 8 * half + r8;
-                        const int rowc = (r & 3) + 8 * (r >> 2);                              // + wm * 32 + 4 * hk (in vrow)
-                        if (ragged) {
-                            vo[r8] = (wm * 32 + 4 * hk + rowc < mleft) ? voff + rowc * a.N * 4 : (int)0x80000000;
-                            so[r8] = 0;
-                        } else { vo[r8] = voff; so[r8] = rowc * a.N * 4; }
-                        rv[r8] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vo[r8], so[r8], 0)) : 0.f;
-                    }
+                    for (int half = 0; half < 2; ++half) {
+                        float rv[8]; int vo[8], so[8];
 #pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = 8 * half + r8;
-                        float vv = fmaf(ac2[j][r], kLoInv, am[j][r]) + bv + rv[r8];
-                        if (a.act == 1) vv = fmaxf(vv, 0.f);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, vo[r8], so[r8], 0);
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = 8 * half + r8;
+                            const int rowc = i * 32 + (r & 3) + 8 * (r >> 2);                 // + wm * 32 MT + 4 * hk (in vrow)
+                            if (ragged) {
+                                vo[r8] = (wm * 32 * MT + 4 * hk + rowc < mleft) ? voff + rowc * a.N * 4 : (int)0x80000000;
+                                so[r8] = 0;
+                            } else { vo[r8] = voff; so[r8] = rowc * a.N * 4; }
+                            rv[r8] = has_res ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vo[r8], so[r8], 0)) : 0.f;
+                        }
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = 8 * half + r8;
+                            float vv = fmaf(ac2[i][j][r], kLoInv, am[i][j][r]) + bv + rv[r8];
+                            if (a.act == 1) vv = fmaxf(vv, 0.f);
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, vo[r8], so[r8], 0);
+                        }
                     }
                 }
             }
@@ -259,23 +280,34 @@ AWSEG_API int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split,
     gemm_args a;
     a.x = x; a.wh = reinterpret_cast<const _Float16*>(w_split); a.wl = a.wh + (int64_t)n * k;
     a.bias = bias; a.residual = residual; a.out = out; a.M = m; a.N = n; a.K = k; a.act = act;
-    const int64_t ntm = (m + GBM - 1) / GBM;
-    a.ntn = (n + GBN - 1) / GBN;
-    const int64_t ntm8 = (ntm + 7) / 8 * 8;                      // 8 m-tiles (one per XCD) x all n-tiles per group
-    if (ntm8 * a.ntn > 0x7fffffff || (int64_t)GBM * n > 0x7fffffff) return AWSEG_ERANGE;
-    a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
-    const int64_t slots = ntm8 * a.ntn;
     static int cus = 0;                                          // CU count of the (single, per-process) device, read once
     if (cus == 0) {
         int dev = 0, n_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
         cus = n_cu;
     }
-    int64_t blocks = (int64_t)cus * 2 / 8 * 8;                   // persistent: two blocks per CU, a multiple of 8
+    static int tile_mode = -1;                                   // AWSEG_GEMM_SPLIT_TILE = 128 / 256 forces the block-tile width (measurements)
+    if (tile_mode < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_TILE"); tile_mode = !e ? 0 : (atoi(e) == 256 ? 2 : (atoi(e) == 128 ? 1 : 0)); }
+    // the 128 x 256 tile when N fills it and there are enough tiles for every CU
+    const bool wide = tile_mode == 2 || (tile_mode == 0 && n % 256 == 0 && ((m + 127) / 128) * (int64_t)(n / 256) >= cus);
+    const int bn = wide ? 256 : 128;
+    const int64_t ntm = (m + 127) / 128;
+    a.ntn = (n + bn - 1) / bn;
+    const int64_t ntm8 = (ntm + 7) / 8 * 8;                      // 8 m-tiles (one per XCD) x all n-tiles per group
+    if (ntm8 * a.ntn > 0x7fffffff || (int64_t)128 * n > 0x7fffffff) return AWSEG_ERANGE;
+    a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
+    const int64_t slots = ntm8 * a.ntn;
+    int64_t blocks = (int64_t)cus * (wide ? 1 : 2) / 8 * 8;      // persistent: one (128 x 256) or two (128 x 128) blocks per CU
     if (blocks < 8) blocks = 8;
     if (blocks > slots) blocks = slots;                          // slots is a multiple of 8
-    if (k % GKT) hipLaunchKernelGGL(gemm_split_kernel<true>, dim3((unsigned)blocks), dim3(GT), 0, awseg_s(stream), a);
-    else hipLaunchKernelGGL(gemm_split_kernel<false>, dim3((unsigned)blocks), dim3(GT), 0, awseg_s(stream), a);
+    const dim3 grid((unsigned)blocks), block(GT);
+    if (wide) {
+        if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, 4, true>), grid, block, 0, awseg_s(stream), a);
+        else hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, 4, false>), grid, block, 0, awseg_s(stream), a);
+    } else {
+        if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<1, 2, 4, 2, true>), grid, block, 0, awseg_s(stream), a);
+        else hipLaunchKernelGGL((gemm_split_kernel<1, 2, 4, 2, false>), grid, block, 0, awseg_s(stream), a);
+    }
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -714,11 +714,12 @@ def test_attention_d32_split_flat_softmax(ops):
     assert (got.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72), (200, 160, 264), (1100, 384, 1024)])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72), (200, 160, 264), (1100, 384, 1024), (38400, 256, 128), (38500, 512, 104)])
 @pytest.mark.parametrize("res_act", [(False, 0), (True, 1)])
 def test_gemm_split_float32_grade(ops, shape, res_act):
     """Split-operand f16-MFMA GEMM against float64, next to the hipBLASLt float32 GEMM on the same inputs: ragged M and
-    N, K not a multiple of the 32-wide K tile, bias / residual / ReLU epilogue, residual aliasing the output."""
+    N, K not a multiple of the 32-wide K tile, bias / residual / ReLU epilogue, residual aliasing the output; the last
+    two shapes have enough tiles for the 128 x 256 block-tile configuration (N % 256 == 0, >= one tile per CU)."""
     M, Nn, K = shape
     has_res, act = res_act
     g = torch.Generator(device="cuda").manual_seed(M + Nn + K)

@@ -57,6 +57,13 @@ void split_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_t
     if (i + 1 < n_elems) { out[i + 1] = (uint16_t)(hi >> 16); out[n_elems + i + 1] = (uint16_t)(lo >> 16); }
 }
 
+#ifdef AWSEG_GEMM_STAMP
+// tools/probe_gemm_stamps.hip: cycle stamps of one wave's K loop (block 0, wave 0): [reads+MFMAs, wait for the next
+// tile's global loads, split + LDS writes, load issue, barrier, iterations]
+__device__ unsigned long long g_gemm_stamp[8];
+#define STAMP(var) const unsigned long long var = __builtin_readcyclecounter()
+#endif
+
 struct gemm_args {
     const float* x; const _Float16* wh; const _Float16* wl; const float* bias; const float* residual; float* out;
     int64_t M; int N, K, act, ntm, ntm8, ntn;
@@ -173,8 +180,34 @@ void gemm_split_kernel(gemm_args a)
         else if (has_next) { point(nm0, nn0); fetch(0); }
         __syncthreads();
 
+#ifdef AWSEG_GEMM_STAMP
+        unsigned long long st_mma = 0, st_wait = 0, st_stage = 0, st_fetch = 0, st_bar = 0, st_n = 0;
+#endif
         for (int t = 0; t < nkt; ++t) {
             const int buf = t & 1;
+            // K tile t+1 (in registers since the previous iteration) is split and staged FIRST, and the loads of tile t+2
+            // are issued right behind it, so the vector-memory unit works through them during this tile's MFMAs.  Issued
+            // after the MFMAs (the obvious order) the 8 waves of a block hit the unit together just before the barrier:
+            // cycle stamps (tools/probe_gemm_stamps.hip) put 21 % of a K tile into issuing those loads and 32 % into the
+            // barrier behind them.  (Ring slot buf^1 was last read before the previous barrier.)
+#ifdef AWSEG_GEMM_STAMP
+            STAMP(c0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            STAMP(c1);
+            if (t + 1 < nkt) stage(buf ^ 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            STAMP(c2);
+#else
+            if (t + 1 < nkt) stage(buf ^ 1);
+#endif
+            if (t + 1 < nkt) {
+                if (t + 2 < nkt) fetch((t + 2) * GKT);
+                else if (has_next) { point(nm0, nn0); fetch(0); }
+            }
+#ifdef AWSEG_GEMM_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(c3);
+#endif
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 h8 Ah[MT], Al[MT], Bh[NT], Bl[NT];
@@ -197,13 +230,21 @@ void gemm_split_kernel(gemm_args a)
                         ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i], Bh[j], ac2[i][j], 0, 0, 0);
                     }
             }
-            if (t + 1 < nkt) {
-                stage(buf ^ 1);
-                if (t + 2 < nkt) fetch((t + 2) * GKT);
-                else if (has_next) { point(nm0, nn0); fetch(0); }
-            }
+#ifdef AWSEG_GEMM_STAMP
+            __builtin_amdgcn_sched_barrier(0);
+            STAMP(c4);
+            __syncthreads();
+            STAMP(c5);
+            st_wait += c1 - c0; st_stage += c2 - c1; st_fetch += c3 - c2; st_mma += c4 - c3; st_bar += c5 - c4; st_n += 1;
+        }
+        if (blockIdx.x == 0 && tid == 0) {
+            g_gemm_stamp[0] += st_mma; g_gemm_stamp[1] += st_wait; g_gemm_stamp[2] += st_stage; g_gemm_stamp[3] += st_fetch;
+            g_gemm_stamp[4] += st_bar; g_gemm_stamp[5] += st_n;
+        }
+#else
             __syncthreads();
         }
+#endif
 
         // ---- epilogue: lane = output column n, registers = rows m.  Raw-buffer accesses relative to the tile: one lane
         // offset per column group (out-of-range columns get an out-of-range VECTOR offset and are dropped) plus a scalar

@@ -38,41 +38,53 @@ class CityscapesKITTIDataset:
         self.device = torch.device(device)
         self.weather_schedule = weather_schedule          # 'random' (loader.py:265) or 'round_robin' (bench)
         self.num_samples = num_samples if num_samples is not None else (100 if split == "train" else 20)
+        self.seed = int(seed)
         self.weather_transforms = WeatherDegradationTransforms(rng=rng, device=self.device)
+        self.weather_transforms._frame_seed = self.seed            # per-frame streams keyed by (seed, global index); no global reseed
         self.depth_preprocessor = DepthEstimationPreprocessor(self.device) if include_depth else None   # loader.py:68-69
         self._gen = torch.Generator(device=self.device)
-        self._gen.manual_seed(seed)
-        self._host_rng = np.random.RandomState(seed)
         logger.info("Generated %d synthetic samples for testing", self.num_samples)
 
     def __len__(self) -> int:
         return self.num_samples
 
-    def synth_raw(self, n: int):
-        """uint8 frames / labels generated on device (shapes and ranges of loader.py:206, 231)."""
+    def _sample_key(self, index: int) -> int:
+        split_salt = {"train": 0, "val": 1, "test": 2}.get(self.split, 3)
+        return (self.seed * 1000003 + split_salt * 7919 + int(index) * 0x9E3779B1) & 0x7FFFFFFFFFFFFFFF
+
+    def synth_raw(self, start: int, n: int):
+        """uint8 frames / labels generated on device (shapes and ranges of loader.py:206, 231).  Sample i
+        is a function of (seed, split, i) only, so every rank of a sharded run — and the single-process
+        run — sees the same sample under the same global index."""
         h, w = self.image_size
-        imgs = torch.randint(0, 255, (n, h, w, 3), dtype=torch.uint8, device=self.device, generator=self._gen)
-        labels = torch.randint(0, 19, (n, h, w), dtype=torch.uint8, device=self.device, generator=self._gen)
+        imgs = torch.empty(n, h, w, 3, dtype=torch.uint8, device=self.device)
+        labels = torch.empty(n, h, w, dtype=torch.uint8, device=self.device)
+        for k in range(n):
+            self._gen.manual_seed(self._sample_key(start + k))
+            imgs[k] = torch.randint(0, 255, (h, w, 3), dtype=torch.uint8, device=self.device, generator=self._gen)
+            labels[k] = torch.randint(0, 19, (h, w), dtype=torch.uint8, device=self.device, generator=self._gen)
         return imgs, labels
 
     def choose_conditions(self, start: int, n: int) -> List[str]:
         if self.weather_schedule == "round_robin":
             return [self.weather_conditions[(start + i) % len(self.weather_conditions)] for i in range(n)]
-        return [str(self._host_rng.choice(self.weather_conditions)) for _ in range(n)]
+        # loader.py:265 draws per __getitem__; here the draw is keyed by the global sample index
+        return [str(np.random.RandomState(self._sample_key(start + i) & 0xFFFFFFFF).choice(self.weather_conditions)) for i in range(n)]
 
     def make_batch(self, start: int, n: int, raw=None) -> Dict[str, object]:
-        imgs, labels = raw if raw is not None else self.synth_raw(n)
+        imgs, labels = raw if raw is not None else self.synth_raw(start, n)
         conds = self.choose_conditions(start, n)
+        ids = list(range(start, start + n)) if self.weather_transforms.rng == "philox" else None   # numpy mode keeps the reference's global stream
         h, w = self.image_size
         image = torch.empty(n, 3, h, w, dtype=torch.float32, device=self.device)
         batch = {"image": image, "label": labels, "weather_condition": conds, "dataset": ["synthetic"] * n}
         if self.depth_preprocessor is None:
-            self.weather_transforms.apply_batch(imgs, conds, norm_out=image)
+            self.weather_transforms.apply_batch(imgs, conds, norm_out=image, frame_ids=ids)
         else:
             # the depth target is estimated from the CORRUPTED uint8 frame (loader.py:264-272), so
             # the transforms also write their uint8 output
             frames = torch.empty_like(imgs)
-            self.weather_transforms.apply_batch(imgs, conds, out=frames, norm_out=image)
+            self.weather_transforms.apply_batch(imgs, conds, out=frames, norm_out=image, frame_ids=ids)
             batch["depth"] = self.depth_preprocessor.estimate_depth_batch(frames)
         return batch
 

@@ -31,51 +31,52 @@ WEATHER_TYPES = ("clean", "fog", "rain", "snow", "night")
 
 
 # --- host-side parameter draws, in the reference's RNG call order ---------------------------
-def draw_fog(h: int, w: int, intensity=None, per_pixel: bool = True):
-    """depth noise first (preprocessing.py:239 via :104), then intensity (:108)."""
-    noise = np.random.normal(0, 10, (h, w)) if per_pixel else None
+def draw_fog(h: int, w: int, intensity=None, per_pixel: bool = True, rs=np.random):
+    """depth noise first (preprocessing.py:239 via :104), then intensity (:108).  `rs`: the numpy
+    global legacy RNG (the reference's stream) or a RandomState with the same methods."""
+    noise = rs.normal(0, 10, (h, w)) if per_pixel else None
     if intensity is None:
-        intensity = np.random.uniform(0.3, 0.9)
+        intensity = rs.uniform(0.3, 0.9)
     return noise, intensity
 
 
-def draw_night(h: int, w: int, intensity=None, per_pixel: bool = True):
+def draw_night(h: int, w: int, intensity=None, per_pixel: bool = True, rs=np.random):
     """intensity (:207), brightness factor (:212), noise (:222)."""
     if intensity is None:
-        intensity = np.random.uniform(0.4, 0.8)
-    brightness = 1 - intensity * np.random.uniform(0.2, 0.6)
-    noise = np.random.normal(0, 5.0 / 255.0, (h, w, 3)) if per_pixel else None
+        intensity = rs.uniform(0.4, 0.8)
+    brightness = 1 - intensity * rs.uniform(0.2, 0.6)
+    noise = rs.normal(0, 5.0 / 255.0, (h, w, 3)) if per_pixel else None
     return intensity, brightness, noise
 
 
-def draw_rain(h: int, w: int, intensity=None):
+def draw_rain(h: int, w: int, intensity=None, rs=np.random):
     """intensity (:128); per drop x, y, length, thickness in {1,3}, angle (:144-148); end point
     truncated toward zero and clipped into the image (:151-156)."""
     if intensity is None:
-        intensity = np.random.uniform(0.2, 0.8)
+        intensity = rs.uniform(0.2, 0.8)
     n = int(100 + intensity * (500 - 100))
     drops = np.empty((n, 5), dtype=np.int32)
     for i in range(n):
-        x = np.random.randint(0, w)
-        y = np.random.randint(0, h)
-        length = np.random.randint(5, 20)
-        thickness = np.random.choice((1, 3))
-        angle = np.random.uniform(-15, 15)
+        x = rs.randint(0, w)
+        y = rs.randint(0, h)
+        length = rs.randint(5, 20)
+        thickness = rs.choice((1, 3))
+        angle = rs.uniform(-15, 15)
         ex = np.clip(int(x + length * np.sin(np.radians(angle))), 0, w - 1)
         ey = np.clip(int(y + length * np.cos(np.radians(angle))), 0, h - 1)
         drops[i] = (x, y, ex, ey, thickness)
     return intensity, drops
 
 
-def draw_snow(h: int, w: int, intensity=None):
+def draw_snow(h: int, w: int, intensity=None, rs=np.random):
     """intensity (:173); per flake x, y, radius in {2,8} (:189-191); blur kernel in {3,7} (:197)."""
     if intensity is None:
-        intensity = np.random.uniform(0.2, 0.7)
+        intensity = rs.uniform(0.2, 0.7)
     n = int(50 + intensity * (200 - 50))
     flakes = np.empty((n, 3), dtype=np.int32)
     for i in range(n):
-        flakes[i] = (np.random.randint(0, w), np.random.randint(0, h), np.random.choice((2, 8)))
-    k = int(np.random.choice((3, 7)))
+        flakes[i] = (rs.randint(0, w), rs.randint(0, h), rs.choice((2, 8)))
+    k = int(rs.choice((3, 7)))
     return intensity, flakes, (k + 1 if k % 2 == 0 else k)
 
 
@@ -90,6 +91,7 @@ class WeatherDegradationTransforms:
         self.rng = rng
         self.device = torch.device(device)
         self._philox_seed = 0x5EED if seed is None else int(seed)
+        self._frame_seed = 0x5EED if seed is None else int(seed)      # base of the per-frame streams (apply_batch frame_ids)
         self.fog_parameters = {"beta_range": (0.005, 0.05), "A_range": (0.7, 1.0), "depth_scale": 100.0}
         self.rain_parameters = {"intensity_range": (0.1, 0.8), "drop_size_range": (1, 3), "angle_range": (-15, 15),
                                 "num_drops_range": (100, 500)}
@@ -116,11 +118,22 @@ class WeatherDegradationTransforms:
         return out.cpu().numpy() if is_np else out
 
     # ---- batched device API (one launch per condition present in the batch) -----------------
+    def frame_stream(self, frame_id: int):
+        """(RandomState, Philox seed) of one GLOBAL sample index: every scalar draw and every per-pixel
+        noise value of that frame is a function of (seed, frame_id) only — not of the batch it lands in,
+        the rank that owns it or the order of earlier calls — so a sharded run reproduces the
+        single-process run frame for frame (pooled mIoU identical at any GPU count)."""
+        key = (self._frame_seed * 0x9E3779B97F4A7C15 + (int(frame_id) + 1) * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        return np.random.RandomState([key & 0xFFFFFFFF, key >> 32]), key
+
     def apply_batch(self, imgs: torch.Tensor, conditions: Sequence[str], intensities: Optional[Sequence] = None,
-                    out: Optional[torch.Tensor] = None, norm_out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+                    out: Optional[torch.Tensor] = None, norm_out: Optional[torch.Tensor] = None,
+                    frame_ids: Optional[Sequence[int]] = None) -> Optional[torch.Tensor]:
         """imgs uint8 [B,H,W,3] on device.  Writes the corrupted uint8 frames to `out` (allocated
         when both outputs are None) and/or the normalised float32 [B,3,H,W] tensor to `norm_out`
-        (the loader's Normalize+ToTensorV2, fused).  'clean' frames are copied / normalised."""
+        (the loader's Normalize+ToTensorV2, fused).  'clean' frames are copied / normalised.
+        `frame_ids` (global sample indices): draw each frame's randomness from frame_stream(id)
+        instead of the shared sequential stream."""
         B, H, W, _ = imgs.shape
         if intensities is None:
             intensities = [None] * B
@@ -134,17 +147,26 @@ class WeatherDegradationTransforms:
                 raise ValueError(f"Unknown weather type: {c}")
             groups[c].append(b)
         # the reference handles samples one after another, so draws happen in sample order
-        draws = {}
+        draws, seeds = {}, {}
         for b, c in enumerate(conditions):
             c = str(c)
+            if c == "clean":
+                continue
+            if frame_ids is None:
+                rs, seeds[b] = np.random, None
+            else:
+                rs, seeds[b] = self.frame_stream(frame_ids[b])
             if c == "fog":
-                draws[b] = draw_fog(H, W, intensities[b], per_pixel)
+                draws[b] = draw_fog(H, W, intensities[b], per_pixel, rs)
             elif c == "night":
-                draws[b] = draw_night(H, W, intensities[b], per_pixel)
+                draws[b] = draw_night(H, W, intensities[b], per_pixel, rs)
             elif c == "rain":
-                draws[b] = draw_rain(H, W, intensities[b])
+                draws[b] = draw_rain(H, W, intensities[b], rs)
             elif c == "snow":
-                draws[b] = draw_snow(H, W, intensities[b])
+                draws[b] = draw_snow(H, W, intensities[b], rs)
+
+        def philox(idx):
+            return [seeds[b] if seeds[b] is not None else self._next_seed() for b in idx]
         dev = imgs.device
         if groups["clean"]:
             idx = groups["clean"]
@@ -154,12 +176,12 @@ class WeatherDegradationTransforms:
                 ops.normalize(imgs, out=norm_out, sel=torch.tensor(idx, dtype=torch.int32).to(dev, non_blocking=True))
         if groups["fog"]:
             idx = groups["fog"]
-            jobs = ops.fog_jobs(idx, [draws[b][1] for b in idx], [self._next_seed() for _ in idx])
+            jobs = ops.fog_jobs(idx, [draws[b][1] for b in idx], philox(idx))
             noise = torch.from_numpy(np.stack([draws[b][0] for b in idx])).to(dev, non_blocking=True) if per_pixel else None
             ops.fog(imgs, jobs, noise=noise, out=out, norm_out=norm_out)
         if groups["night"]:
             idx = groups["night"]
-            jobs = ops.night_jobs(idx, [draws[b][1] for b in idx], [draws[b][0] for b in idx], [self._next_seed() for _ in idx])
+            jobs = ops.night_jobs(idx, [draws[b][1] for b in idx], [draws[b][0] for b in idx], philox(idx))
             noise = torch.from_numpy(np.stack([draws[b][2] for b in idx])).to(dev, non_blocking=True) if per_pixel else None
             ops.night(imgs, jobs, noise=noise, out=out, norm_out=norm_out)
         if groups["rain"] or groups["snow"]:

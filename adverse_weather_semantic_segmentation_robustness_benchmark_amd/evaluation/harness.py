@@ -91,6 +91,40 @@ class EvalState:
 
 
 @torch.no_grad()
+def eval_batch(model, st: EvalState, images: torch.Tensor, labels: torch.Tensor, conds, metrics: RobustnessMetrics,
+               with_stats: bool = True) -> None:
+    """One batch of the evaluation loop (evaluate.py:166-200 + the per-batch share of :203-255): forward, argmax,
+    confusion per condition, and (with_stats) the ECE bins and the disagreement histogram — all into `st`'s
+    device counters.  Nothing per-pixel survives the call."""
+    cond = st.acc.cond_ids(conds)
+    if labels.dtype not in (torch.uint8, torch.int64):
+        labels = labels.long()
+    if st.auroc is not None:
+        strategy = getattr(model, "ensemble_strategy", "weighted_average")
+        fused_stats = metrics.num_classes == 19 and strategy != "max_confidence" and images[0, 0].numel() % 4 == 0
+        need_logits = with_stats and not fused_stats
+        res = model.forward_eval(images, labels, st.acc.counts, st.acc.oob, cond, want_logits=need_logits, want_pred=False)
+        if with_stats and fused_stats:
+            # ECE of the combined logits + disagreement histogram in ONE pass over the member logits:
+            # the ensemble logits are never materialised
+            mode = N.COMBINE_WEIGHTED if strategy == "weighted_average" else N.COMBINE_MEAN
+            w = F.softmax(model.ensemble_weights, dim=0) if mode == N.COMBINE_WEIGHTED else None
+            T = model.temperature if getattr(model, "temperature_scaling", False) else None
+            ops.ensemble_eval_stats(res["segformer_seg"], res["deeplabv3plus_seg"], mode, w, T, labels, cond, st.edges, st.ece,
+                                    st.auroc, AUROC_LO, AUROC_HI)
+        elif with_stats:
+            st.update_auroc(res["segformer_seg"], res["deeplabv3plus_seg"], labels)
+            ops.ece_accumulate(res["segmentation"], labels, st.ece, st.edges, cond)
+    else:
+        logits = model(images)["segmentation"].float().contiguous()
+        ops.combine_argmax_confusion(logits, None, 3, want_logits=False, label=labels.contiguous(), counts=st.acc.counts,
+                                     oob=st.acc.oob, cond=cond)
+        if with_stats:
+            ops.ece_accumulate(logits, labels, st.ece, st.edges, cond)
+    st.samples += images.size(0)
+
+
+@torch.no_grad()
 def evaluate_model(model: torch.nn.Module, test_loader, metrics: RobustnessMetrics, device, config) -> Dict[str, Any]:
     model.eval()
     conditions = list(_cfg(config, "data.weather_conditions", []))
@@ -100,31 +134,7 @@ def evaluate_model(model: torch.nn.Module, test_loader, metrics: RobustnessMetri
     for batch in test_loader:
         images = batch["image"].to(device)
         labels = batch["label"].to(device)
-        if labels.dtype not in (torch.uint8, torch.int64):
-            labels = labels.long()
-        conds = batch.get("weather_condition", ["clean"] * images.size(0))
-        cond = st.acc.cond_ids(conds)
-        if is_ensemble:
-            strategy = getattr(model, "ensemble_strategy", "weighted_average")
-            fused_stats = metrics.num_classes == 19 and strategy != "max_confidence" and images[0, 0].numel() % 4 == 0
-            res = model.forward_eval(images, labels, st.acc.counts, st.acc.oob, cond, want_logits=not fused_stats, want_pred=False)
-            if fused_stats:
-                # ECE of the combined logits + disagreement histogram in ONE pass over the member logits:
-                # the ensemble logits are never materialised
-                mode = N.COMBINE_WEIGHTED if strategy == "weighted_average" else N.COMBINE_MEAN
-                w = F.softmax(model.ensemble_weights, dim=0) if mode == N.COMBINE_WEIGHTED else None
-                T = model.temperature if getattr(model, "temperature_scaling", False) else None
-                ops.ensemble_eval_stats(res["segformer_seg"], res["deeplabv3plus_seg"], mode, w, T, labels, cond, st.edges, st.ece,
-                                        st.auroc, AUROC_LO, AUROC_HI)
-            else:
-                st.update_auroc(res["segformer_seg"], res["deeplabv3plus_seg"], labels)
-                ops.ece_accumulate(res["segmentation"], labels, st.ece, st.edges, cond)
-        else:
-            logits = model(images)["segmentation"].float().contiguous()
-            ops.combine_argmax_confusion(logits, None, 3, want_logits=False, label=labels.contiguous(), counts=st.acc.counts,
-                                         oob=st.acc.oob, cond=cond)
-            ops.ece_accumulate(logits, labels, st.ece, st.edges, cond)
-        st.samples += images.size(0)
+        eval_batch(model, st, images, labels, batch.get("weather_condition", ["clean"] * images.size(0)), metrics)
     return finalize(st, metrics)
 
 

@@ -45,6 +45,10 @@ def folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
         shift = shift + conv.bias * scale
     w = (conv.weight * scale.view(-1, 1, 1, 1)).contiguous(memory_format=CL)
     conv._awseg_fold = (key, w, shift.contiguous())
+    # everything derived from the folded weights dies with them: the split-operand image is keyed on the folded tensor's
+    # (address, version), and a re-folded tensor can land on the same address with the same version
+    if hasattr(conv, "_awseg_wsplit"):
+        del conv._awseg_wsplit
     return w, shift.contiguous()
 
 

@@ -434,6 +434,9 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, shift: torch.Tensor, act:
     return out
 
 
+# 3x3 convolutions: 1 = Winograd on split-operand f16 MFMA (csrc/wino_split.hip), 0 = Winograd on float32-input MFMA
+WINO_SPLIT = os.environ.get("AWSEG_WINO_SPLIT", "0") != "0"     # default flips to 1 once wino_split.hip is in
+
 GEMM_WORKSPACE_BYTES = 32 << 20
 GEMM_TUNE = os.environ.get("AWSEG_GEMM_TUNE", "0") != "0"      # opt-in: time hipBLASLt's candidates once per new problem shape
 # (measured on the bench step: 102.0 vs 101.8 images/s — the library's first-ranked algorithm is already the fastest here)
@@ -529,6 +532,22 @@ def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     sym = "awseg_attention_d32_split" if (ATTENTION_SPLIT if split is None else split) else "awseg_attention_d32"
     N.call(sym, N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), b, heads, nq, k.shape[1], float(scale), N.stream())
     return out
+
+
+def set_split(on: bool) -> None:
+    """Process-wide switch between the split-operand f16-MFMA kernels (float32-grade results) and
+    their float32-input MFMA counterparts, for every operator that has both."""
+    global ATTENTION_SPLIT, GEMM_SPLIT, WINO_SPLIT
+    ATTENTION_SPLIT = GEMM_SPLIT = WINO_SPLIT = bool(on)
+
+
+def split_state() -> dict:
+    return {"attention": ATTENTION_SPLIT, "gemm_1x1": GEMM_SPLIT, "winograd_3x3": WINO_SPLIT}
+
+
+def restore_split(state: dict) -> None:
+    global ATTENTION_SPLIT, GEMM_SPLIT, WINO_SPLIT
+    ATTENTION_SPLIT, GEMM_SPLIT, WINO_SPLIT = bool(state["attention"]), bool(state["gemm_1x1"]), bool(state["winograd_3x3"])
 
 
 def depth_upsample_combine(d1: torch.Tensor, d2_low: torch.Tensor, weights: Optional[torch.Tensor]):

@@ -66,44 +66,125 @@ def barrier() -> None:
         dist.barrier()
 
 
+def broadcast_module_(module: torch.nn.Module, src: int = 0) -> None:
+    """Every parameter and buffer of `module` from rank `src` to all ranks (one message per dtype).  Data parallelism
+    averages GRADIENTS only, so the replicas must start identical; the backbones are random-init offline."""
+    if not is_dist():
+        return
+    by_dtype = {}
+    for t in list(module.parameters()) + list(module.buffers()):
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for group in by_dtype.values():
+            flat = torch.cat([t.detach().reshape(-1) for t in group])
+            dist.broadcast(flat, src=src)
+            off = 0
+            for t in group:
+                n = t.numel()
+                t.copy_(flat[off:off + n].view_as(t))
+                off += n
+
+
 class GradientBuckets:
     """Bucketed gradient averaging for the trainer (classic DP; BatchNorm stays per rank, as the
-    reference has no SyncBN).  Parameters are grouped into ~`bucket_mb` flat buckets in reverse
-    registration order (≈ backward order) and each bucket is all-reduced asynchronously on RCCL's
-    stream as soon as it is packed; `finish()` waits and scatters the averages back.  With ~36 M
-    fp32 parameters (144 MB) and 7 x 153 GB/s xGMI links, 25-50 MB buckets keep every link busy
-    without serialising behind one giant message."""
+    reference has no SyncBN), overlapped with backward.
+
+    The trainable parameters — a FIXED list, the same on every rank — are packed in reverse registration
+    order (≈ the order backward produces them) into flat float32 buckets of ~`bucket_mb`; each parameter's
+    `.grad` is a VIEW into its bucket, so autograd accumulates straight into the message buffer and nothing
+    is packed or scattered.  A post-accumulate-grad hook per parameter counts its bucket down; the bucket
+    whose last gradient has just landed is all-reduced asynchronously (RCCL's own stream) while backward
+    continues with earlier layers.  `finish()` launches whatever has not fired (parameters that took no part
+    in this step keep zero gradients, so message sizes never depend on a rank's control flow), waits, and
+    scales by 1/world.  With ~36 M fp32 parameters (144 MB) and 7 x 153 GB/s xGMI links, 25-50 MB buckets
+    keep every link busy without serialising behind one giant message."""
 
     def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 32.0) -> None:
         self.params = [p for p in params if p.requires_grad]
         cap = int(bucket_mb * 1024 * 1024 / 4)
-        self.buckets, cur, size = [], [], 0
+        groups, cur, size = [], [], 0
         for p in reversed(self.params):
             cur.append(p)
             size += p.numel()
             if size >= cap:
-                self.buckets.append(cur)
+                groups.append(cur)
                 cur, size = [], 0
         if cur:
-            self.buckets.append(cur)
+            groups.append(cur)
+        self.buckets = groups
+        self.flat, self._bucket_of, self._views, self._view = [], {}, [], {}
+        for bi, group in enumerate(groups):
+            dt, dev = group[0].dtype, group[0].device
+            flat = torch.zeros(sum(p.numel() for p in group), dtype=dt, device=dev)
+            off = 0
+            for p in group:
+                n = p.numel()
+                self._views.append((p, flat[off:off + n].view_as(p)))
+                self._view[id(p)] = self._views[-1][1]
+                self._bucket_of[id(p)] = bi
+                off += n
+            self.flat.append(flat)
+        self._pending = [0] * len(groups)
+        self._next = 0
+        self._work = [None] * len(groups)
+        self._armed = False
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
-    def all_reduce_(self) -> None:
+    def zero_grad(self) -> None:
+        """Zero every bucket and (re-)attach the parameters' .grad views; arms the hooks for one backward."""
+        for flat in self.flat:
+            flat.zero_()
+        for p, view in self._views:
+            p.grad = view
+        self._pending = [len(g) for g in self.buckets]
+        self._work = [None] * len(self.buckets)
+        self._next = 0
+        self._armed = True
+
+    def _launch(self, bi: int) -> None:
+        if self._work[bi] is None and is_dist():
+            self._work[bi] = dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+
+    def _on_grad(self, p: torch.nn.Parameter) -> None:
+        if not self._armed:
+            return
+        bi = self._bucket_of[id(p)]
+        view = self._view[id(p)]
+        if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
+            # autograd replaced the view instead of accumulating into it: copy the gradient back into the bucket
+            view.copy_(p.grad)
+            p.grad = view
+        self._pending[bi] -= 1
+        # collectives must be issued in the SAME order on every rank: launch strictly by bucket index, so a bucket that
+        # fills early waits for its predecessors (a rank whose control flow skipped a parameter launches that bucket,
+        # and everything behind it, in finish())
+        while self._next < len(self.buckets) and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next += 1
+
+    def finish(self) -> None:
+        """All buckets reduced and averaged; call after backward, before clipping / the optimizer step."""
+        self._armed = False
         if not is_dist():
             return
         world = dist.get_world_size()
-        pending = []
-        for bucket in self.buckets:
-            grads = [p.grad for p in bucket if p.grad is not None]
-            if not grads:
-                continue
-            flat = torch.cat([g.reshape(-1) for g in grads])
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
-            pending.append((work, flat, grads))
-        for work, flat, grads in pending:
+        for bi in range(len(self.buckets)):
+            self._launch(bi)                       # buckets with parameters that got no gradient this step
+        for bi, work in enumerate(self._work):
             work.wait()
-            flat.div_(world)
-            off = 0
-            for g in grads:
-                n = g.numel()
-                g.copy_(flat[off:off + n].view_as(g))
-                off += n
+            self.flat[bi].div_(world)
+
+    def all_reduce_(self) -> None:
+        """Non-overlapped form for callers that ran backward without zero_grad(): gather whatever .grad holds (zeros
+        for missing ones — fixed message sizes on every rank), reduce, scatter."""
+        if not is_dist():
+            return
+        if not self._armed:
+            for p, view in self._views:
+                if p.grad is None:
+                    view.zero_()
+                elif p.grad.data_ptr() != view.data_ptr():
+                    view.copy_(p.grad)
+                p.grad = view
+            self._work = [None] * len(self.buckets)
+        self.finish()

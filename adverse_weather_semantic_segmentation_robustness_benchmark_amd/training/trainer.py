@@ -93,7 +93,11 @@ class AdverseWeatherTrainer:
         self.global_step = 0
         self.best_val_loss = float("inf")
         self.best_val_miou = 0.0
-        self._density_seed = int(config.get("seed", 42))
+        rank = torch.distributed.get_rank() if parallel.is_dist() else 0
+        self._density_seed = int(config.get("seed", 42)) + 7919 * rank      # ranks see different samples: different density noise too
+        # data parallelism averages gradients only: the replicas must START identical (the backbones are random-init
+        # offline), so rank 0's parameters and buffers are broadcast once
+        parallel.broadcast_module_(self.model)
         self._buckets = parallel.GradientBuckets(list(self.model.parameters())) if parallel.is_dist() else None
         logger.info("Initialized AdverseWeatherTrainer with %s", type(model).__name__)
 
@@ -164,10 +168,13 @@ class AdverseWeatherTrainer:
         samples = 0
         for batch in self.train_loader:
             outputs, labels, loss, seg_loss, depth_loss = self._step_losses(batch)
-            self.optimizer.zero_grad()
+            if self._buckets is not None:
+                self._buckets.zero_grad()            # .grad = views into the flat buckets; hooks all-reduce each bucket as it fills
+            else:
+                self.optimizer.zero_grad()
             loss.backward()
             if self._buckets is not None:
-                self._buckets.all_reduce_()
+                self._buckets.finish()
             clip = self.config.get("grad_clip", 1.0)
             if clip > 0:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), clip)

@@ -1,30 +1,39 @@
 #!/usr/bin/env python3
 """bench.py — images/s of the north-star hot path on MI355X.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus N --steps K --warmup W          # N > 1: starts its own N rank processes
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W      # or under a launcher (env RANK/WORLD_SIZE)
 
 One "step" = one pass of the hot path over one batch of B synthetic 1024x2048 frames that are
 already resident in HBM as uint8 HWC (+ uint8 labels):
 
-    weather corruption (round-robin clean/fog/rain/snow/night, in-kernel Philox noise)
-      -> fused Normalize/ToTensor -> SegFormer-B0 + DeepLabV3+-R50 ensemble forward (fp32)
+    weather corruption (condition = global frame index mod 5, in-kernel Philox noise)
+      -> fused Normalize/ToTensor -> SegFormer-B0 + DeepLabV3+-R50 ensemble forward (float32 results)
       -> combine / temperature / argmax / 19x19 confusion (overall + per condition) in one pass
+      -> ECE bins + ensemble-disagreement histogram of the same logits (REF/scripts/evaluate.py:230-255)
 
-After the K timed steps the int64 counters are SUM-all-reduced over ranks (RCCL) and the mIoU /
-degradation ratios are finished on the host — inside the timed region.  Weak scaling: every rank
-runs its own B frames per step; value = N*B*K / max-over-ranks time.
-
-The line also carries `roofline` for the dominant hand-written kernel (HIP events recorded around
-every launch of it on the launching stream, inside the timed region) and `cpu_baseline` (the CPU
-oracle path timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+The samples are a FIXED GLOBAL SET of 160 frames (C2/C3 N=160 = 8 GPUs x 5 conditions x 4):
+frame g — pixels, labels, weather condition, every random draw — is a function of (seed, g) only.  Rank r
+owns the contiguous block parallel.shard_range(160, r, N) and keeps it resident in HBM.
+  * timed region (weak scaling): every rank runs K steps of B frames, cycling through its block; after the
+    K steps the int64 counters are SUM-all-reduced over ranks (RCCL) and the mIoUs finished on the host,
+    inside the timed region.  value = N*B*K / max-over-ranks time.
+  * parity pass (untimed): every global frame is evaluated exactly ONCE by its owner, counters all-reduced:
+    the reported `miou` dict is therefore bit-identical at any N (integer sums are order-independent).
+  * per-kernel pass (untimed): a few more steps with HIP event pairs around every C-ABI launch on the
+    launching stream -> `roofline` (dominant hand-written kernel) and `kernels`.
+  * fp32 pass (N=1): a few steps with every split-operand f16-MFMA kernel replaced by its float32-input
+    counterpart -> `fp32_mfma`.
+`cpu_baseline` = the CPU oracle path timed on this box's host cores on a bounded sample (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -33,8 +42,8 @@ ROOT = Path(__file__).resolve().parent
 if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
-import numpy as np
-import torch
+np = None       # numpy / torch are imported by main() AFTER the self-launch decision: the parent of a
+torch = None    # self-launched multi-rank run never loads the GPU runtime
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_F32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32-input MFMA dense peak
@@ -135,22 +144,29 @@ DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_kernel"}
 
 
+TRAFFIC_TABLES = ["r02_kernel_bench_stats_and_traffic.csv", "r01_kernel_bench_v4_stats_and_traffic.csv"]   # newest first
+
+
 def pmc_traffic(name):
-    """HBM bytes per launch of `name` from the committed PMC passes (profiles/: separate rocprofv3
+    """(HBM bytes per launch of `name`, source) from the committed PMC passes (profiles/: separate rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/kernel_bench.py at this same problem size;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads).  None if the
-    profile is not there — bench.py itself does not collect counters."""
+    FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads).  (None, None) if no
+    committed profile has the kernel — bench.py itself does not collect counters."""
     import csv
-    path = ROOT / "profiles" / "r01_kernel_bench_v4_stats_and_traffic.csv"
     key = DEVICE_KERNEL.get(name)
-    if not key or not path.exists():
-        return None
-    with open(path) as f:
-        rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
-    for r in rows:
-        if key in r["kernel"] and r["FETCH_SIZE_KB"] and r["WRITE_SIZE_KB"]:
-            return int((2.0 * float(r["FETCH_SIZE_KB"]) + float(r["WRITE_SIZE_KB"])) * 1024)
-    return None
+    if not key:
+        return None, None
+    for fname in TRAFFIC_TABLES:
+        path = ROOT / "profiles" / fname
+        if not path.exists():
+            continue
+        with open(path) as f:
+            rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
+        for r in rows:
+            if key in r["kernel"] and r["FETCH_SIZE_KB"] and r["WRITE_SIZE_KB"]:
+                return (int((2.0 * float(r["FETCH_SIZE_KB"]) + float(r["WRITE_SIZE_KB"])) * 1024),
+                        f"profiles/{fname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/kernel_bench.py; largest launch shape of this kernel)")
+    return None, None
 
 
 def cpu_baseline(model, H, W, C, seed=0, fwd_div=1, max_threads=16):
@@ -200,7 +216,11 @@ def cpu_baseline(model, H, W, C, seed=0, fwd_div=1, max_threads=16):
                       f"({cores} torch threads); oracle argmax+confusion on 1 frame {H}x{W} ({t_metric:.2f} s, 1 thread)"}
 
 
-def main():
+GLOBAL_FRAMES = 160          # C2 / C3 evaluate N = 160 frames (8 GPUs x 5 conditions x 4)
+CONDITIONS = ["clean", "fog", "rain", "snow", "night"]
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -208,89 +228,226 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step (README.md:125 batch size)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--frames", type=int, default=GLOBAL_FRAMES, help="size of the fixed global sample set")
     ap.add_argument("--no-depth", action="store_true", help="build the ensemble with include_depth=False")
+    ap.add_argument("--no-stats", action="store_true", help="leave ECE + disagreement-AUROC accumulation (evaluate.py:230-255) out of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-pass", action="store_true", help="skip the untimed pass over the whole global sample set (miou is then the timed region's)")
+    ap.add_argument("--kernel-steps", type=int, default=2, help="steps of the untimed per-kernel HIP-event pass (0: no roofline / kernels)")
+    ap.add_argument("--fp32-steps", type=int, default=3, help="steps of the float32-input-MFMA comparison pass at N=1 (0: skip)")
     ap.add_argument("--fp32-mfma", action="store_true",
-                    help="attention and 1x1 convolutions on the float32-input MFMA kernels (own fp32 attention, hipBLASLt fp32) "
-                         "instead of the split-operand f16-MFMA ones (DESIGN.md 5b); same as AWSEG_ATTN_SPLIT=0 AWSEG_GEMM_SPLIT=0")
+                    help="run the MAIN measurement on the float32-input MFMA kernels (own fp32 attention, hipBLASLt fp32, fp32 Winograd) "
+                         "instead of the split-operand f16-MFMA ones (DESIGN.md 5b); same as AWSEG_ATTN_SPLIT=0 AWSEG_GEMM_SPLIT=0 AWSEG_WINO_SPLIT=0")
+    ap.add_argument("--model", choices=["b0_r50", "b5_r101"], default="b0_r50",
+                    help="b0_r50: BASELINE configs[1] (float32 results); b5_r101: configs[4] (SegFormer-B5 + DeepLabV3+-R101, bf16 MFMA path)")
     ap.add_argument("--conv-search", type=int, default=int(os.environ.get("AWSEG_CONV_SEARCH", "0")),
                     help="1: let MIOpen time its solvers per convolution shape during warm-up (torch.backends.cudnn.benchmark)")
-    args = ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rendezvous only (gloo, CPU): every rank reports its block of the global sample set, rank 0 prints the pooled "
+                         "frame count — exercises the self-launch / sharding path where there is no GPU (tests/)")
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)      # tests: this rank exits 3 right after start-up
+    return ap.parse_args(argv)
+
+
+def dry_run(args) -> None:
+    import torch
+    import torch.distributed as dist
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import parallel
+    os.environ["AWSEG_DIST_BACKEND"] = "gloo"
+    rank, _, world = parallel.init_from_env(backend="gloo")
+    if rank == args.fail_rank:
+        raise SystemExit(3)
+    mine = parallel.shard_range(args.frames, rank, world)
+    t = torch.zeros(args.frames, dtype=torch.int64)
+    t[list(mine)] = 1
+    if parallel.is_dist():
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "frames": args.frames, "frames_owned_once": bool((t == 1).all().item()),
+                          "frames_rank0": len(mine), "backend": dist.get_backend() if parallel.is_dist() else "none"}), flush=True)
+    if parallel.is_dist():
+        dist.destroy_process_group()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N rank processes (children of a parent that never
+    touches the GPU), rank 0 inherits stdout so its JSON line is this command's output.  Returns the exit code."""
+    n = args.gpus
+    with socket.socket() as sk:                       # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               AWSEG_SELF_LAUNCHED="1")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()), *sys.argv[1:]], env=e,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    print(f"bench.py: rank {r} exited with code {code}; stopping the other ranks", file=sys.stderr)
+                    for q in pending:
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def main():
+    global np, torch
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if args.dry_run:
+        return dry_run(args)
+    import numpy as np                     # noqa: F811
+    import torch                           # noqa: F811
     torch.backends.cudnn.benchmark = bool(args.conv_search)
 
-    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import ops, parallel
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import _native, ops, parallel
     if args.fp32_mfma:
-        ops.ATTENTION_SPLIT = False
-        ops.GEMM_SPLIT = False
+        ops.set_split(False)
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import EnsembleModel
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd.evaluation.metrics import RobustnessMetrics
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.evaluation.harness import EvalState, eval_batch, finalize
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data.preprocessing import WeatherDegradationTransforms
 
+    n_dev = torch.cuda.device_count()      # does not initialise the GPU runtime
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env > max(n_dev, 1) and "AWSEG_DIST_BACKEND" not in os.environ:
+        # more ranks than GPUs (rehearsal on a 1-GPU box): RCCL cannot put two ranks on one device
+        os.environ["AWSEG_DIST_BACKEND"] = "gloo"
     rank, local, world = parallel.init_from_env()
-    assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local % max(torch.cuda.device_count(), 1))     # ranks beyond the device count share GPUs (rehearsal only)
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    dev = torch.device("cuda", local % max(n_dev, 1))
     torch.cuda.set_device(dev)
+    backend = torch.distributed.get_backend() if parallel.is_dist() else "none"
     B, H, W, C = args.batch, args.height, args.width, 19
-    conds_all = ["clean", "fog", "rain", "snow", "night"]
+    bf16 = args.model == "b5_r101"
 
-    torch.manual_seed(42)
-    np.random.seed(42 + rank)
-    model = EnsembleModel(num_classes=C, include_depth=not args.no_depth, pretrained=False).to(dev).eval()
-    metrics = RobustnessMetrics(num_classes=C, weather_conditions=conds_all)
-    acc = metrics.new_accumulator(dev)
-    tf = WeatherDegradationTransforms(seed=1234 + rank, rng="philox", device=dev)
+    torch.manual_seed(42)                  # identical weights on every rank
+    np.random.seed(42)
+    kw = {}
+    if bf16:
+        kw = {"segformer_name": "nvidia/segformer-b5-finetuned-cityscapes-1024-1024", "deeplab_backbone": "resnet101", "compute_dtype": "bf16"}
+    model = EnsembleModel(num_classes=C, include_depth=not args.no_depth, pretrained=False, **kw).to(dev).eval()
+    metrics = RobustnessMetrics(num_classes=C, weather_conditions=CONDITIONS)
+    tf = WeatherDegradationTransforms(seed=None, rng="philox", device=dev)
+    tf._frame_seed = 1234
+
+    # ---- the rank's block of the fixed global sample set, resident in HBM ---------------------------------------
+    mine = list(parallel.shard_range(args.frames, rank, world))
+    if not mine:
+        raise SystemExit(f"bench.py: rank {rank} owns no frame of a {args.frames}-frame set")
     gen = torch.Generator(device=dev)
-    gen.manual_seed(42 + rank)
-    raw = torch.randint(0, 255, (B, H, W, 3), dtype=torch.uint8, device=dev, generator=gen)      # loader.py:206
-    labels = torch.randint(0, C, (B, H, W), dtype=torch.uint8, device=dev, generator=gen)        # loader.py:231
+    raw = torch.empty(len(mine), H, W, 3, dtype=torch.uint8, device=dev)
+    labels = torch.empty(len(mine), H, W, dtype=torch.uint8, device=dev)
+    for k, g in enumerate(mine):
+        gen.manual_seed(42 * 1000003 + g)
+        raw[k] = torch.randint(0, 255, (H, W, 3), dtype=torch.uint8, device=dev, generator=gen)      # loader.py:206
+        labels[k] = torch.randint(0, C, (H, W), dtype=torch.uint8, device=dev, generator=gen)        # loader.py:231
     image = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
-    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import _native
     _native.launch_hook = CLOCK.hook
     info = {}
+    with_stats = not args.no_stats
 
-    def step(i):
-        start = (rank * B + i * B * world) % len(conds_all)
-        conds = [conds_all[(start + k) % len(conds_all)] for k in range(B)]
+    def new_state():
+        return EvalState(metrics, CONDITIONS, dev, 15, ensemble=True)
+
+    def run_frames(st, local_idx):
+        """One step over the rank's resident frames `local_idx` (positions in its block)."""
+        ids = [mine[k] for k in local_idx]
+        conds = [CONDITIONS[g % len(CONDITIONS)] for g in ids]
         info.update({"awseg_fog_fused": conds.count("fog"), "awseg_night_apply": conds.count("night"),
                      "awseg_rain_apply": conds.count("rain"), "awseg_snow_apply": conds.count("snow"),
-                     "awseg_normalize": conds.count("clean")})
-        tf.apply_batch(raw, conds, norm_out=image)
-        model.forward_eval(image, labels, acc.counts, acc.oob, acc.cond_ids(conds), want_logits=False, want_pred=False)
+                     "awseg_normalize": conds.count("clean"), "awseg_weather_batch": len(ids)})
+        sel = torch.tensor(local_idx, dtype=torch.int64, device=dev)
+        contiguous = local_idx == list(range(local_idx[0], local_idx[0] + len(local_idx)))
+        r = raw[local_idx[0]:local_idx[0] + len(local_idx)] if contiguous else raw.index_select(0, sel)
+        l = labels[local_idx[0]:local_idx[0] + len(local_idx)] if contiguous else labels.index_select(0, sel)
+        img = image[:len(ids)]
+        tf.apply_batch(r, conds, norm_out=img, frame_ids=ids)
+        eval_batch(model, st, img, l, conds, metrics, with_stats=with_stats)
 
-    with torch.no_grad():
-        def finish():
-            """Counters -> mIoUs (inside the timed region: the job is not done until the metric exists)."""
-            acc.all_reduce()
-            acc.check()
-            res = {"overall_miou": acc.miou(0)}
-            for k, name in enumerate(conds_all):
-                if acc.present(1 + k):
-                    res[f"miou_{name}"] = acc.miou(1 + k)
-            return res
+    def step(st, i):
+        run_frames(st, [(i * B + k) % len(mine) for k in range(B)])
 
-        for i in range(args.warmup):
-            step(i)
-        finish()                                  # warm the host-side finalisation too (first-use costs of the CPU ops)
-        acc.counts.zero_()
+    def finish(st):
+        """Counters -> all-reduce -> the result dict (host math of evaluate.py:214-271)."""
+        return finalize(st, metrics)
+
+    def timed(n_steps, first):
+        st = new_state()
         torch.cuda.synchronize()
         parallel.barrier()
-        CLOCK.enabled = True
         t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        results = finish()
+        for i in range(n_steps):
+            step(st, first + i)
+        res = finish(st)                           # inside the timed region: the job is not done until the metric exists
         torch.cuda.synchronize()
         parallel.barrier()
         dt = time.perf_counter() - t0
-        CLOCK.enabled = False
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if parallel.is_dist():
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        return float(tmax.item()), res
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if parallel.is_dist():
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
+    with torch.no_grad():
+        st = new_state()
+        for i in range(args.warmup):
+            step(st, i)
+        finish(st)                                 # warm the host-side finalisation too (first-use costs of the CPU ops)
+        dt, timed_results = timed(args.steps, args.warmup)
+
+        # ---- parity pass: every global frame exactly once, by its owner ------------------------------------------
+        results = timed_results
+        if not args.no_parity_pass:
+            st = new_state()
+            for lo in range(0, len(mine), B):
+                run_frames(st, list(range(lo, min(lo + B, len(mine)))))
+            results = finish(st)
+
+        # ---- per-kernel pass: HIP event pairs around every C-ABI launch (untimed) ----------------------------------
+        if args.kernel_steps > 0:
+            st = new_state()
+            torch.cuda.synchronize()
+            CLOCK.enabled = True
+            for i in range(args.kernel_steps):
+                step(st, args.warmup + args.steps + i)
+            torch.cuda.synchronize()
+            CLOCK.enabled = False
+
+        # ---- float32-input MFMA comparison (N = 1) -----------------------------------------------------------------
+        fp32 = None
+        if world == 1 and args.fp32_steps > 0 and not args.fp32_mfma and not bf16:
+            saved = ops.split_state()
+            ops.set_split(False)
+            st = new_state()
+            for i in range(2):
+                step(st, i)
+            dt32, res32 = timed(args.fp32_steps, 2)
+            ops.restore_split(saved)
+            fp32 = {"value": round(B * args.fp32_steps / dt32, 3), "unit": "images/s", "ms_per_step": round(dt32 / args.fp32_steps * 1e3, 3),
+                    "steps": args.fp32_steps, "what": "same step with attention / 1x1 GEMMs / Winograd on the float32-input MFMA kernels "
+                    "(v_mfma_f32_32x32x2_f32, hipBLASLt f32) instead of split-operand f16 MFMA"}
+
     total_images = B * args.steps * world
+    step_ms = dt / args.steps * 1e3
 
-    # ---- roofline of the dominant hand-written kernel (rank 0's launches) ----------------------
+    # ---- roofline of the dominant hand-written kernel (rank 0's launches, untimed pass) ------------
     kernels = []
     for name, (count, avg_ms, own_work) in CLOCK.summary().items():
         bound, work = own_work if own_work is not None else algorithmic_work(name, B, H, W, C, info)
@@ -302,16 +459,18 @@ def main():
             achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F16_PEAK_TFLOPS, "TFLOP/s"
         else:
             achieved, peak, unit = work / (avg_ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-        kernels.append({"kernel": name, "launches": count, "avg_ms": round(avg_ms, 4), "bound": bound,
+        per_step = count / max(args.kernel_steps, 1)
+        kernels.append({"kernel": name, "launches_per_step": round(per_step, 2), "avg_ms": round(avg_ms, 4), "bound": bound,
                         "achieved": round(achieved, 2), "peak": peak, "unit": unit, "frac": round(achieved / peak, 4),
-                        "time_share_of_step": round(count * avg_ms / (dt * 1e3), 4)})
-    kernels.sort(key=lambda k: -k["launches"] * k["avg_ms"])
+                        "time_share_of_step": round(per_step * avg_ms / step_ms, 4)})
+    kernels.sort(key=lambda k: -k["launches_per_step"] * k["avg_ms"])
     roofline = None
     if kernels:
         k0 = kernels[0]
-        roofline = {"kernel": k0["kernel"], "bound": k0["bound"], "achieved": k0["achieved"], "peak": k0["peak"],
-                    "unit": k0["unit"], "frac": k0["frac"], "traffic": pmc_traffic(k0["kernel"]),
-                    "traffic_source": "profiles/r01_kernel_bench_v4_stats_and_traffic.csv (separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/kernel_bench.py; for the Winograd kernel: the full-resolution 128->64 depth-head launch, the largest of its 17 launches per step)"}
+        traffic, tsrc = pmc_traffic(k0["kernel"])
+        roofline = {"kernel": k0["kernel"], "bound": ("mfma" if k0["bound"].startswith("mfma") else "hbm"), "achieved": k0["achieved"],
+                    "peak": k0["peak"], "unit": k0["unit"], "frac": k0["frac"], "traffic": traffic, "traffic_source": tsrc,
+                    "measured": f"HIP events around each launch on the launching stream, {args.kernel_steps} untimed steps after the timed region"}
 
     if rank == 0:
         cpu = None
@@ -320,21 +479,36 @@ def main():
                 cpu = cpu_baseline(model, H, W, C)
             except Exception as e:  # noqa: BLE001
                 cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        split = ops.split_state()
+        if bf16:
+            dtype = "bf16 (bf16 MFMA operands, f32 accumulate)"
+        elif any(split.values()):
+            dtype = "f32 (results float32; " + ", ".join(k for k, v in split.items() if v) + " on 3xf16 split operands: 22-bit operands, f32 accumulate)"
+        else:
+            dtype = "f32"
+        workload = (f"ensemble_eval_{H}x{W}_5cond (BASELINE.json configs[1]: SegFormer-B0 + DeepLabV3+-R50, all 5 weather conditions)" if not bf16 else
+                    f"ensemble_eval_{W}x{H}_b5_r101_bf16 (BASELINE.json configs[4]: SegFormer-B5 + DeepLabV3+-R101, bf16 MFMA path)")
         line = {
             "metric": "images/sec (1024x2048, 5 weather conds, ensemble eval)",
             "value": round(total_images / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ensemble_eval_{H}x{W}_5cond (BASELINE.json configs[1]: SegFormer-B0 + DeepLabV3+-R50, "
-                                   "all 5 weather conditions round-robin)", "per_gpu_batch": B, "global_batch": B * world,
-                       "include_depth": not args.no_depth, "weather_rng": "philox (in-kernel)", "ensemble_logits_materialised": False,
-                       "attention": ("split-operand f16 MFMA (22-bit operands, f32 accumulate)" if ops.ATTENTION_SPLIT else "f32 MFMA"),
-                       "gemm_1x1": ("split-operand f16 MFMA (22-bit operands, f32 accumulate)" if ops.GEMM_SPLIT else "hipBLASLt f32"),
-                       "weights": "random init (no checkpoints offline)", "parallelism": f"batch-sharded x{world}, one int64 counter all-reduce"},
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
-            "miou": {k: round(v, 6) for k, v in results.items()},
+            "warmup": args.warmup, "ms_per_step": round(step_ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
+            "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,
+                       "global_sample_set": args.frames, "frames_per_rank": len(mine),
+                       "include_depth": not args.no_depth, "eval_stats_in_step": with_stats,
+                       "weather_rng": "philox (in-kernel), keyed by global frame index", "ensemble_logits_materialised": False,
+                       "split_operand_kernels": split,
+                       "weights": "random init (no checkpoints offline)",
+                       "parallelism": f"batch-sharded x{world}, one counter all-reduce (int64 confusion + ECE bins + AUROC histogram)",
+                       "dist_backend": backend},
+            "rccl_ranks": world if backend == "nccl" else 0,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32_mfma": fp32, "kernels": kernels,
+            "miou": {k: round(float(v), 6) for k, v in results.items()},
+            "miou_source": ("parity pass: every frame of the global set exactly once, sharded by parallel.shard_range, counters all-reduced"
+                            if not args.no_parity_pass else "timed region"),
+            "timed_region_overall_miou": round(float(timed_results["overall_miou"]), 6),
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if parallel.is_dist():
         torch.distributed.destroy_process_group()
 

@@ -62,10 +62,13 @@ def main():
         setup_logging(config)
         validate_config(config)
         rank, local, world = parallel.init_from_env()
-        set_seed(config.get("seed", 42) + rank)
+        # the SAME seed on every rank while the model is built (identical initial weights; the trainer also broadcasts
+        # rank 0's parameters); the per-rank seed applies afterwards, to the host-side noise streams only
+        set_seed(config.get("seed", 42))
         dev = get_device_config(config.get("device", "auto"))
         device = torch.device(dev, local) if dev.startswith("cuda") and ":" not in dev else torch.device(dev)
         model = create_model(config)
+        set_seed(config.get("seed", 42) + rank)
         size = tuple(config.get("data.image_size", [512, 1024]))
         conds = config.get("data.weather_conditions")
         bs = config.get("training.batch_size", 8)

@@ -246,6 +246,43 @@ for p in net.parameters():
 parallel.GradientBuckets(list(net.parameters()), bucket_mb=0.0001).all_reduce_()
 for p in net.parameters():
     assert torch.allclose(p.grad, torch.full_like(p, (1 + world) / 2.0))
+# --- the overlapped path: identical replicas after broadcast, hooks fire per bucket during backward, one rank lacks a
+# gradient for a parameter (control flow differs per rank): message sizes stay fixed, nothing hangs, and after one
+# optimizer step the state_dicts are equal on every rank
+torch.manual_seed(100 + rank)                                   # DIFFERENT initial weights per rank on purpose
+class Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 16); self.b = torch.nn.Linear(16, 4); self.unused = torch.nn.Linear(8, 3)
+        self.bn = torch.nn.BatchNorm1d(4)
+    def forward(self, x, use_extra):
+        y = self.bn(self.b(torch.relu(self.a(x))))
+        return y.sum() + (self.unused(x).sum() if use_extra else 0.0)
+net = Net()
+parallel.broadcast_module_(net)
+ref0 = [t.clone() for t in net.state_dict().values()]
+gathered = [None] * world
+dist.all_gather_object(gathered, [t.tolist() for t in ref0])
+assert gathered[0] == gathered[1], "broadcast_module_ left the replicas different"
+buckets = parallel.GradientBuckets(list(net.parameters()), bucket_mb=0.0002)
+assert len(buckets.buckets) >= 2
+opt = torch.optim.SGD(net.parameters(), lr=0.1)
+torch.manual_seed(7 + rank)
+x = torch.randn(5, 8)
+buckets.zero_grad()
+net(x, use_extra=(rank == 0)).backward()                        # rank 1 never touches `unused`
+buckets.finish()
+# the averaged gradient equals the mean of the per-rank gradients computed without any bucket machinery
+net2 = Net(); net2.load_state_dict({k: v for k, v in zip(net.state_dict().keys(), ref0)})
+net2(x, use_extra=(rank == 0)).backward()
+for (n1, p1), (n2, p2) in zip(net.named_parameters(), net2.named_parameters()):
+    g = p2.grad.clone() if p2.grad is not None else torch.zeros_like(p2)
+    dist.all_reduce(g); g /= world
+    assert torch.allclose(p1.grad, g, atol=1e-6), n1
+opt.step()
+after = [None] * world
+dist.all_gather_object(after, [p.detach().tolist() for p in net.parameters()])
+assert after[0] == after[1], "replicas diverged after one data-parallel step"
 dist.destroy_process_group()
 print("rank", rank, "ok")
 '''
@@ -266,6 +303,25 @@ def test_two_rank_gloo_counter_allreduce_matches_single_process(tmp_path):
     for p in procs:
         out, _ = p.communicate(timeout=180)
         assert p.returncode == 0, out.decode()[-2000:]
+
+
+def _bench(*argv, timeout=180):
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), *argv], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout,
+                          env={k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")})
+
+
+def test_bench_self_launches_its_ranks_and_shards_the_global_set():
+    """`python bench.py --gpus N` with no launcher starts N rank processes itself; every frame of the
+    fixed global sample set is owned by exactly one rank; a failing rank makes the command fail."""
+    import json
+    for n in (1, 2, 3):
+        r = _bench("--gpus", str(n), "--dry-run")
+        assert r.returncode == 0, r.stderr.decode()[-2000:]
+        line = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][-1])
+        assert line["n_gpus"] == n and line["frames"] == 160 and line["frames_owned_once"] is True
+        assert line["frames_rank0"] == -(-160 // n)
+    r = _bench("--gpus", "2", "--dry-run", "--fail-rank", "1")
+    assert r.returncode == 3 and b"rank 1 exited" in r.stderr
 
 
 def test_checkpoint_key_translation_between_transformers_spellings():

@@ -7,6 +7,9 @@
       x2 correction for wide coalesced reads (MI355X_MICROARCH.md §HBM).
   python tools/make_profiles.py step <trace_dir> <marker_kernel_substring> <out.csv> "<header comment>"
       kernels of ONE bench step, cut out of the kernel trace between two consecutive launches of the marker kernel.
+  python tools/make_profiles.py check-log <kernel_bench.log | bench line .json> [...]
+      fail (exit 1) if any row of a kernel_bench / bench.py JSON line claims more than 100 % of its peak — such a row
+      measured the wrong kernel or priced the wrong work (round 1 committed "181 % of the fp32 MFMA peak" this way).
 """
 import collections
 import csv
@@ -70,8 +73,31 @@ def step(trace_dir, marker, out, header):
             w.writerow([short(k), len(v), round(sum(v) / 1e3, 4), round(sum(v) / len(v), 2)])
 
 
+def check_log(paths):
+    import json
+    bad = []
+    for p in paths:
+        for line in open(p):
+            line = line.strip()
+            if not line.startswith("{"):
+                continue
+            try:
+                d = json.loads(line)
+            except ValueError:
+                continue
+            for r in d.get("rows", []) + d.get("kernels", []) + ([d["roofline"]] if d.get("roofline") else []):
+                frac = r.get("frac_of_peak", r.get("frac"))
+                if frac is not None and frac > 1.0:
+                    bad.append(f"{p}: {r.get('kernel')} frac {frac}")
+    if bad:
+        raise SystemExit("rows above their peak:\n  " + "\n  ".join(bad))
+    print(f"check-log: {len(paths)} file(s), no row above its peak")
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "kernel-table":
+    if sys.argv[1] == "check-log":
+        check_log(sys.argv[2:])
+    elif sys.argv[1] == "kernel-table":
         kernel_table(*sys.argv[2:7])
     elif sys.argv[1] == "step":
         step(*sys.argv[2:6])

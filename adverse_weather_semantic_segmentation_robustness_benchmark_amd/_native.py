@@ -49,6 +49,7 @@ SIGNATURES = {
     "awseg_gemm_split_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "awseg_gemm_split_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
     "awseg_dwconv3x3_upcat_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
+    "awseg_im2col_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "awseg_attention_d32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "awseg_attention_d32_split": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "awseg_depth_upsample_combine": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
@@ -61,7 +62,7 @@ SIGNATURES = {
     "awseg_night_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_rain_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_snow_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "awseg_fog_density_field": (c_i, [c_p, c_i, c_i64, c_u64, c_p, c_p]),
+    "awseg_fog_density_field": (c_i, [c_p, c_i, c_i64, c_u64, c_p, c_p, c_p]),
     "awseg_loss_partials": (c_i64, [c_i64, c_i64]),
     "awseg_fog_ce_forward": (c_i, [c_p, c_p, c_i, c_p, c_i64, c_i, c_i64, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),
     "awseg_fog_ce_backward": (c_i, [c_p, c_p, c_i, c_p, c_i64, c_i, c_i64, c_i, c_f, c_p, c_p, c_p]),

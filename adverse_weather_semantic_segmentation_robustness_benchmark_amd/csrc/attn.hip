@@ -163,8 +163,7 @@ void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__
 // probability tile reused as the B operand).  tests/test_gpu_kernels.py measures both kernels against a float64
 // reference: their errors are of the same order (a few 1e-7 relative), two orders inside the 1e-4 gate.
 // The probabilities are produced pre-scaled by 2^15 (folded into the exponent: exp2(s - m + 15)) so that every one that
-// matters is a NORMAL f16 number; the scale cancels in O / l.  q, k, v must be finite and below 65504 in magnitude
-// (they are LayerNorm -> Linear outputs).
+// matters is a NORMAL f16 number; the scale cancels in O / l.  Any finite float32 q, k, v: see the range guard below.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -211,12 +210,26 @@ __device__ __forceinline__ constexpr int pv_slot(int key)
     return (key & 16) | (((key >> 2) & 1) << 3) | (((key >> 3) & 1) << 2) | (key & 3);
 }
 
-__global__ __launch_bounds__(AT, 2)
-void attention_d32_split_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+// Operand range guard (the same scheme as gemm_split.hip).  A pass runs OPTIMISTICALLY with unscaled operands while
+// every thread tracks max|.| of the q (after the softmax scale), k and v values it splits; if the block has met a value
+// >= 2^15 — where f16(x) or the scaled low part leaves the f16 range — nothing is stored and the block runs the whole
+// query tile again with q * 2^-eq, k * 2^-ek, v * 2^-ev (exact powers of two from the observed maxima), multiplying
+// 2^(eq+ek) back into the scores and 2^ev into the output.  LayerNorm -> Linear outputs never take the second pass.
+constexpr float kSplitLimit = 32768.0f;
+struct attn_scales { float sq, sk, sv, bq, bk, bv; };           // forward scales 2^-e and their inverses 2^e
+
+__device__ __forceinline__ float amax4(float m, const float4& t)
 {
-    __shared__ __attribute__((aligned(16))) _Float16 sK[2][TK * SROW];      // [key][hi d 0..31 | lo d 0..31]
-    __shared__ __attribute__((aligned(16))) _Float16 sV[2][D * SROW];       // [d][hi slot 0..31 | lo slot 0..31]
+    m = __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t.x)), __builtin_fabsf(t.y));
+    return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t.z)), __builtin_fabsf(t.w));
+}
+
+// returns true (block-uniform) when the optimistic pass met an out-of-range operand and stored nothing
+template <bool SCALED>
+__device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e,
+                                                _Float16 (*sK)[TK * SROW], _Float16 (*sV)[D * SROW], unsigned* sMax, const attn_scales sc)
+{
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = lane >> 5, li = lane & 31;
     const int h = blockIdx.y, b = blockIdx.z;
@@ -224,18 +237,23 @@ void attention_d32_split_kernel(const float* __restrict__ q, const float* __rest
     const int q0 = blockIdx.x * 128 + wave * 32;
     const float* kb = k + ((size_t)b * nkv * heads + h) * D;
     const float* vb = v + ((size_t)b * nkv * heads + h) * D;
+    float qmax = 0.f, kmax = 0.f, vmax = 0.f;
 
     // Q fragments: B operand of S^T = K Q^T, lane (query li, half hk) holds d = 16 s + 8 hk + j
     h8 qh[2], ql[2];
     {
         const int qi = q0 + li;
         const float* qp = q + ((size_t)b * nq + (qi < nq ? qi : nq - 1)) * C + h * D;
+        const float qs = SCALED ? scale_log2e * sc.sq : scale_log2e;           // (x * s) * 2^-e == x * (s * 2^-e): exact factor
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             const float4 a4 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * hk);
             const float4 b4 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * hk + 4);
-            const float x[8] = { a4.x * scale_log2e, a4.y * scale_log2e, a4.z * scale_log2e, a4.w * scale_log2e,
-                                 b4.x * scale_log2e, b4.y * scale_log2e, b4.z * scale_log2e, b4.w * scale_log2e };
+            const float x[8] = { a4.x * qs, a4.y * qs, a4.z * qs, a4.w * qs, b4.x * qs, b4.y * qs, b4.z * qs, b4.w * qs };
+            if (!SCALED) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qmax = __builtin_fmaxf(qmax, __builtin_fabsf(x[i]));
+            }
             split8(x, qh[s], ql[s]);
         }
     }
@@ -244,7 +262,13 @@ void attention_d32_split_kernel(const float* __restrict__ q, const float* __rest
     const size_t g_off = (size_t)lkey * C + 4 * lc;
     const int wk0 = lkey * SROW + 4 * lc;
     const int wv0 = (4 * lc) * SROW + pv_slot(lkey);
-    auto stage = [&](int buf, const float4& kk4, const float4& vv4) {
+    auto stage = [&](int buf, float4 kk4, float4 vv4) {
+        if (SCALED) {
+            kk4.x *= sc.sk; kk4.y *= sc.sk; kk4.z *= sc.sk; kk4.w *= sc.sk;
+            vv4.x *= sc.sv; vv4.y *= sc.sv; vv4.z *= sc.sv; vv4.w *= sc.sv;
+        } else {
+            kmax = amax4(kmax, kk4); vmax = amax4(vmax, vv4);
+        }
         u32x2 H, L; unsigned hh, ll;
         split_pair(kk4.x, kk4.y, hh, ll); H[0] = hh; L[0] = ll;
         split_pair(kk4.z, kk4.w, hh, ll); H[1] = hh; L[1] = ll;
@@ -278,21 +302,24 @@ void attention_d32_split_kernel(const float* __restrict__ q, const float* __rest
         const int buf = t & 1;
         const h8* kr = reinterpret_cast<const h8*>(&sK[buf][a_off]);
         const h8 kh0 = kr[0], kh1 = kr[2], kl0 = kr[4], kl1 = kr[6];          // +0, +16, +32, +48 halfs
-        f32x16 sm, sc;
+        f32x16 sm, scx;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; sc[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; scx[r] = 0.f; }
         sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], sm, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], sc, 0, 0, 0);
+        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], scx, 0, 0, 0);
         sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], sm, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], sc, 0, 0, 0);
-        sc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], sc, 0, 0, 0);
+        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], scx, 0, 0, 0);
+        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], scx, 0, 0, 0);
+        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], scx, 0, 0, 0);
         const h8* vr = reinterpret_cast<const h8*>(&sV[buf][a_off]);
         const h8 vh0 = vr[0], vh1 = vr[2], vl0 = vr[4], vl1 = vr[6];
         // ---- online softmax, one query per lane
         float s[16];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = fmaf(sc[r], kLoInv, sm[r]);
+        for (int r = 0; r < 16; ++r) {
+            s[r] = fmaf(scx[r], kLoInv, sm[r]);
+            if (SCALED) s[r] = s[r] * sc.bq * sc.bk;
+        }
         float mt = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
 #pragma unroll
         for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
@@ -333,16 +360,51 @@ void attention_d32_split_kernel(const float* __restrict__ q, const float* __rest
         __syncthreads();
     }
 
+    if (!SCALED) {
+        // report (rare, divergent) -> barrier -> block-uniform verdict
+        if (qmax >= kSplitLimit) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, qmax));
+        if (kmax >= kSplitLimit) atomicMax(&sMax[1], __builtin_bit_cast(unsigned, kmax));
+        if (vmax >= kSplitLimit) atomicMax(&sMax[2], __builtin_bit_cast(unsigned, vmax));
+        __syncthreads();
+        if ((sMax[0] | sMax[1] | sMax[2]) != 0u) return true;
+    }
     const int qi = q0 + li;
     if (qi < nq) {
         const float inv = 1.0f / l_run;
         float* op = out + ((size_t)b * nq + qi) * C + h * D;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(op + 8 * g + 4 * hk) =
-                make_float4(fmaf(oc[4 * g], kLoInv, om[4 * g]) * inv, fmaf(oc[4 * g + 1], kLoInv, om[4 * g + 1]) * inv,
-                            fmaf(oc[4 * g + 2], kLoInv, om[4 * g + 2]) * inv, fmaf(oc[4 * g + 3], kLoInv, om[4 * g + 3]) * inv);
+        for (int g = 0; g < 4; ++g) {
+            float4 o4 = make_float4(fmaf(oc[4 * g], kLoInv, om[4 * g]) * inv, fmaf(oc[4 * g + 1], kLoInv, om[4 * g + 1]) * inv,
+                                    fmaf(oc[4 * g + 2], kLoInv, om[4 * g + 2]) * inv, fmaf(oc[4 * g + 3], kLoInv, om[4 * g + 3]) * inv);
+            if (SCALED) { o4.x *= sc.bv; o4.y *= sc.bv; o4.z *= sc.bv; o4.w *= sc.bv; }
+            *reinterpret_cast<float4*>(op + 8 * g + 4 * hk) = o4;
+        }
     }
+    return false;
+}
+
+// exponent e >= 0 with max * 2^-e in [2^13, 2^14) when the maximum (float bits) left the split range, else 0
+__device__ __forceinline__ int guard_exponent(unsigned maxbits)
+{
+    const int ex = (int)(maxbits >> 23) & 0xff;
+    if (maxbits == 0u || ex == 0xff) return 0;               // in range, or Inf / NaN (nothing to rescue: they propagate)
+    return ex - 127 - 13;
+}
+
+__global__ __launch_bounds__(AT, 2)
+void attention_d32_split_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sK[2][TK * SROW];      // [key][hi d 0..31 | lo d 0..31]
+    __shared__ __attribute__((aligned(16))) _Float16 sV[2][D * SROW];       // [d][hi slot 0..31 | lo slot 0..31]
+    __shared__ unsigned sMax[3];                                             // max |q*scale|, |k|, |v| bits, when >= 2^15
+    if (threadIdx.x < 3) sMax[threadIdx.x] = 0u;                             // ordered by the pass's first barrier
+    const attn_scales one = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    if (!attn_split_pass<false>(q, k, v, out, nq, nkv, heads, scale_log2e, sK, sV, sMax, one)) return;
+    const int eq = guard_exponent(sMax[0]), ek = guard_exponent(sMax[1]), ev = guard_exponent(sMax[2]);
+    auto p2 = [](int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); };            // |e| <= 114
+    const attn_scales sc = {p2(-eq), p2(-ek), p2(-ev), p2(eq), p2(ek), p2(ev)};
+    attn_split_pass<true>(q, k, v, out, nq, nkv, heads, scale_log2e, sK, sV, sMax, sc);
 }
 
 }  // namespace

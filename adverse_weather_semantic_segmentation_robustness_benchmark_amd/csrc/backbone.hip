@@ -329,6 +329,60 @@ void layernorm_rows_kernel(const float* __restrict__ x, int64_t n_rows, int C, c
 
 }  // namespace
 
+namespace {
+// ---- im2col for the strided / patch convolutions (ResNet layer2/3 first blocks, MiT patch embeddings and the
+// sequence-reduction convolutions): cols[m][(ky*kw + kx)*C + c] = x[b][oy*s - p + ky*d][ox*s - p + kx*d][c] (0 outside),
+// m = (b*Ho + oy)*Wo + ox, row length k_padded >= kh*kw*C (tail zero-filled).  The product with w[N][kh][kw][C] is then
+// one GEMM with the convolution's bias / BatchNorm shift / activation in its epilogue (awseg_gemm_split_bias_act or
+// awseg_gemm_bias_act): deterministic accumulation order, where MIOpen's pick for these shapes is a split-K igemm that
+// sums with atomics (run-to-run different results, tools/check_op_determinism.py).  One float4 per lane per item,
+// items ordered (m, tap, c/4) so a wave writes 1 KiB runs of a row.
+__global__ __launch_bounds__(kThreads)
+void im2col_nhwc_kernel(const float* __restrict__ x, int64_t rows, int H, int W, int C, int Ho, int Wo, int kh, int kw,
+                        int stride, int pad, int dil, int kpad, float* __restrict__ cols)
+{
+    const int q_row = kpad / 4;                       // float4 per output row
+    const int c4n = C / 4;
+    const int kq = kh * kw * c4n;                     // float4 that carry data
+    const int64_t total = rows * q_row;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int q = (int)(i % q_row);
+        const int64_t m = i / q_row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q < kq) {
+            const int tap = q / c4n, c4 = q - tap * c4n;
+            const int ky = tap / kw, kx = tap - ky * kw;
+            const int ox = (int)(m % Wo);
+            const int64_t t = m / Wo;
+            const int oy = (int)(t % Ho);
+            const int64_t b = t / Ho;
+            const int iy = oy * stride - pad + ky * dil, ix = ox * stride - pad + kx * dil;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W)
+                v = *reinterpret_cast<const float4*>(x + ((b * H + iy) * (int64_t)W + ix) * C + c4 * 4);
+        }
+        *reinterpret_cast<float4*>(cols + m * kpad + q * 4) = v;
+    }
+}
+}  // namespace
+
+AWSEG_API int awseg_im2col_nhwc(const float* x, int64_t batch, int height, int width, int channels, int kernel_h, int kernel_w,
+                                int stride, int pad, int dilation, int k_padded, float* cols, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!x || !cols || batch < 0 || height < 1 || width < 1 || channels < 4 || kernel_h < 1 || kernel_w < 1 || stride < 1 ||
+        pad < 0 || dilation < 1) return AWSEG_EINVAL;
+    if (channels % 4 || k_padded % 4 || k_padded < kernel_h * kernel_w * channels) return AWSEG_ERANGE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)cols & 15)) return AWSEG_EALIGN;
+    const int ho = (height + 2 * pad - dilation * (kernel_h - 1) - 1) / stride + 1;
+    const int wo = (width + 2 * pad - dilation * (kernel_w - 1) - 1) / stride + 1;
+    if (ho < 1 || wo < 1) return AWSEG_ERANGE;
+    const int64_t rows = batch * ho * wo;
+    hipLaunchKernelGGL(im2col_nhwc_kernel, dim3(awseg_grid_1d(rows * (k_padded / 4), kThreads)), dim3(kThreads), 0, awseg_s(stream),
+                       x, rows, height, width, channels, ho, wo, kernel_h, kernel_w, stride, pad, dilation, k_padded, cols);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
 AWSEG_API int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, int width, int channels, int dilation,
                                    const float* w9, const float* bias, int act, float* out, awseg_stream_t stream)
 {

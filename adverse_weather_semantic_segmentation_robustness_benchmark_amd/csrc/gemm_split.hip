@@ -19,7 +19,15 @@
 //   * persistent blocks (two per CU) walk the tiles XCD-aware (the turns of one XCD sweep the n-tiles of one m-tile
 //     band, whose x rows stay in that XCD's L2) and fetch the next tile's first K tile before their own epilogue, so
 //     the epilogue's stores and the next prologue's load latency overlap.
-// Inputs must be finite and below 65504 in magnitude.
+// Operand range.  f16 holds |v| < 65504 and the scaled low part needs |v| < 2^15, so:
+//   * weights are NORMALISED when they are split: awseg_gemm_split_weights finds max|w| on the device and stores
+//     w * 2^-ew (max in [2^13, 2^14)) together with 2^ew, which the GEMM folds into its epilogue — any float32 weight
+//     tensor keeps 22 significant bits, tiny or huge;
+//   * activations are split OPTIMISTICALLY (scale 1) while every block tracks max|x| of the A tiles it stages; a
+//     block that has seen |x| >= 2^15 throws its accumulators away and recomputes the tile with x * 2^-e (e from the
+//     observed maximum: exact, power of two), multiplying 2^e back in the epilogue.  LayerNorm / BatchNorm-scaled
+//     activations never take the second pass; a tensor at 1e5 or 1e30 costs twice the time and is still float32-grade
+//     (tests/test_gpu_kernels.py::test_gemm_split_large_operands).  Inf / NaN propagate as in a float32 GEMM.
 #include "awseg_common.h"
 
 namespace {
@@ -45,12 +53,40 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
-__global__ __launch_bounds__(SWT)
-void split_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_t* __restrict__ out)
+// power-of-two scale that brings a maximum magnitude with float bits `maxbits` into [2^13, 2^14): returns e with
+// scaled = v * 2^-e.  Zero / subnormal maxima (and Inf / NaN) leave the tensor unscaled.
+__device__ __forceinline__ int norm_exponent(unsigned maxbits)
 {
+    const int ex = (int)(maxbits >> 23) & 0xff;
+    if (ex == 0 || ex == 0xff) return 0;
+    return ex - 127 - 13;
+}
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }   // -126 <= e <= 127
+
+// trailer of a split-weight buffer (8 uint16 = 16 bytes behind the [2][N][K] halfs): {max|w| bits, 2^ew as float, 0, 0}
+__global__ __launch_bounds__(SWT)
+void weights_absmax_kernel(const float* __restrict__ w, int64_t n_elems, unsigned* __restrict__ trailer)
+{
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * SWT + threadIdx.x; i < n_elems; i += (int64_t)gridDim.x * SWT) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(trailer, __builtin_bit_cast(unsigned, m));
+}
+
+__global__ __launch_bounds__(SWT)
+void split_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_t* __restrict__ out, unsigned* __restrict__ trailer)
+{
+    const int e = norm_exponent(trailer[0]);
+    // |e| can exceed the exponent range of one float factor (max|w| = 1e-38 -> e = -139): apply it in two halves
+    const int e1 = e / 2, e2 = e - e1;
+    const float s1 = pow2f(-e1), s2 = pow2f(-e2);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        trailer[1] = (unsigned)e;                                   // the GEMM rebuilds 2^e from the integer (same two-factor form)
+    }
     const int64_t i = ((int64_t)blockIdx.x * SWT + threadIdx.x) * 2;
     if (i >= n_elems) return;
-    const float a = w[i], b = (i + 1 < n_elems) ? w[i + 1] : 0.f;
+    const float a = w[i] * s1 * s2, b = (i + 1 < n_elems) ? w[i + 1] * s1 * s2 : 0.f;
     unsigned hi, lo;
     split_pair(a, b, hi, lo);
     out[i] = (uint16_t)hi; out[n_elems + i] = (uint16_t)lo;
@@ -66,8 +102,11 @@ __device__ unsigned long long g_gemm_stamp[8];
 
 struct gemm_args {
     const float* x; const _Float16* wh; const _Float16* wl; const float* bias; const float* residual; float* out;
+    const unsigned* trailer;                                     // {max|w| bits, weight exponent ew} (awseg_gemm_split_weights)
     int64_t M; int N, K, act, ntm, ntm8, ntn;
 };
+
+constexpr float kSplitLimit = 32768.0f;                          // |x| below this splits without loss (hi < 65504, lo * 2048 < 65504)
 
 __device__ __forceinline__ constexpr int acc_row(int r, int hk) { return (r & 3) + 8 * (r >> 2) + 4 * hk; }
 
@@ -85,6 +124,7 @@ void gemm_split_kernel(gemm_args a)
     constexpr int NB = BN / 64;                                  // 16-byte chunks of w per thread per K tile (hi and lo)
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * GROW];
     __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * GROW];
+    __shared__ unsigned sMax[2];                                 // max|x| bits seen by the block in a pass (if >= 2^15), by pass parity
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = lane >> 5, li = lane & 31;
     const int wm = wave / WN, wn = wave % WN;                    // WM x WN waves, each (32 MT) rows x (32 NT) columns
@@ -122,6 +162,10 @@ void gemm_split_kernel(gemm_args a)
         }
     };
     float4 areg[NA]; u32x4 breg[NB];
+    float amax = 0.f;                                            // max|x| this thread staged in the current pass
+    bool scaled = false;                                         // second pass over a tile whose activations left the split range
+    float sx = 1.0f;                                             // activation scale of that pass (2^-e)
+    int xe = 0;
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -138,8 +182,12 @@ void gemm_split_kernel(gemm_args a)
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             u32x2 H, L; unsigned hh, ll;
-            split_pair(areg[i].x, areg[i].y, hh, ll); H[0] = hh; L[0] = ll;
-            split_pair(areg[i].z, areg[i].w, hh, ll); H[1] = hh; L[1] = ll;
+            float4 v = areg[i];
+            if (scaled) { v.x *= sx; v.y *= sx; v.z *= sx; v.w *= sx; }       // block-uniform branch
+            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));   // v_max3_f32 with |.| modifiers
+            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
+            split_pair(v.x, v.y, hh, ll); H[0] = hh; L[0] = ll;
+            split_pair(v.z, v.w, hh, ll); H[1] = hh; L[1] = ll;
             _Float16* d = &sA[buf][(ar + 64 * i) * GROW + 4 * ac];
             *reinterpret_cast<u32x2*>(d) = H;
             *reinterpret_cast<u32x2*>(d + 32) = L;
@@ -159,6 +207,9 @@ void gemm_split_kernel(gemm_args a)
     if (slot >= ntiles) return;                                  // block-uniform, before any barrier
     point(m0, n0);
     fetch(0);
+    if (tid < 2) sMax[tid] = 0u;                                 // ordered before its first use by the barrier behind stage(0)
+    int par = 0;                                                 // pass parity: which sMax word this pass reports into
+    const int we = (int)a.trailer[1];                            // weights were stored as w * 2^-we
 
     while (true) {
         // next live tile (its first K tile is fetched while this tile's last K tiles compute / its epilogue stores)
@@ -175,6 +226,7 @@ void gemm_split_kernel(gemm_args a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { am[i][j][r] = 0.f; ac2[i][j][r] = 0.f; }
 
+        amax = 0.f;
         stage(0);
         if (nkt > 1) fetch(GKT);
         else if (has_next) { point(nm0, nn0); fetch(0); }
@@ -200,6 +252,11 @@ void gemm_split_kernel(gemm_args a)
 #else
             if (t + 1 < nkt) stage(buf ^ 1);
 #endif
+            // range guard bookkeeping (two block-uniform branches per K tile).  First K tile: clear the OTHER parity's word
+            // — its readers (previous pass) are behind this pass's first barrier, its writers (next pass) behind this
+            // pass's last one.  Last K tile: everything this thread will stage in this pass has been staged; report.
+            if (t == 0 && tid == 0) sMax[par ^ 1] = 0u;
+            if (t == nkt - 1 && !scaled && amax >= kSplitLimit) atomicMax(&sMax[par], __builtin_bit_cast(unsigned, amax));
             if (t + 1 < nkt) {
                 if (t + 2 < nkt) fetch((t + 2) * GKT);
                 else if (has_next) { point(nm0, nn0); fetch(0); }
@@ -246,6 +303,29 @@ void gemm_split_kernel(gemm_args a)
         }
 #endif
 
+        // ---- range guard: some activation of this tile was too large for the optimistic split -> second pass, scaled
+        {
+            const unsigned mx = sMax[par];                       // written before the K loop's last barrier; block-uniform
+            par ^= 1;
+            if (mx != 0u && !scaled) {
+                const int ex = (int)(mx >> 23) & 0xff;
+                if (ex != 0xff) {                                // Inf / NaN: nothing to rescue, let them propagate
+                    xe = ex - 127 - 13;                          // max|x| * 2^-xe in [2^13, 2^14)
+                    sx = pow2f(-xe);                             // xe in [2, 114]: one factor is enough
+                    scaled = true;
+                    point(m0, n0);                               // the registers hold the NEXT tile's first K tile: fetch this one again
+                    fetch(0);
+                    continue;
+                }
+            }
+        }
+        // result scale: 2^(we + xe), applied as two factors (each a normal float; their product may legitimately overflow
+        // to Inf exactly where the float32 GEMM would)
+        const int oe = we + (scaled ? xe : 0);
+        const int oe1 = oe / 2, oe2 = oe - oe1;
+        const float os1 = pow2f(oe1 < -126 ? -126 : (oe1 > 127 ? 127 : oe1)), os2 = pow2f(oe2 < -126 ? -126 : (oe2 > 127 ? 127 : oe2));
+        const bool rescale = oe != 0;
+
         // ---- epilogue: lane = output column n, registers = rows m.  Raw-buffer accesses relative to the tile: one lane
         // offset per column group (out-of-range columns get an out-of-range VECTOR offset and are dropped) plus a scalar
         // row offset.  The hardware range check covers the vector offset only, so the one tile band with rows past M
@@ -285,7 +365,9 @@ void gemm_split_kernel(gemm_args a)
 #pragma unroll
                         for (int r8 = 0; r8 < 8; ++r8) {
                             const int r = 8 * half + r8;
-                            float vv = fmaf(ac2[i][j][r], kLoInv, am[i][j][r]) + bv + rv[r8];
+                            float vv = fmaf(ac2[i][j][r], kLoInv, am[i][j][r]);
+                            if (rescale) vv = vv * os1 * os2;                                  // block-uniform branch
+                            vv = vv + bv + rv[r8];
                             if (a.act == 1) vv = fmaxf(vv, 0.f);
                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, vo[r8], so[r8], 0);
                         }
@@ -295,6 +377,7 @@ void gemm_split_kernel(gemm_args a)
         }
         if (!has_next) break;
         slot = nslot; m0 = nm0; n0 = nn0;
+        scaled = false;
     }
 }
 
@@ -306,7 +389,14 @@ AWSEG_API int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w
     if (!w || !w_split || n < 0 || k < 0) return AWSEG_EINVAL;
     const int64_t ne = (int64_t)n * k;
     const int64_t blocks = (ne / 2 + SWT) / SWT;
-    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(SWT), 0, awseg_s(stream), w, ne, w_split);
+    unsigned* trailer = reinterpret_cast<unsigned*>(w_split + 2 * ne);      // 16 bytes behind the two f16 planes
+    if ((uintptr_t)trailer & 3) return AWSEG_EALIGN;
+    hipError_t e = hipMemsetAsync(trailer, 0, 16, awseg_s(stream));
+    if (e != hipSuccess) return (int)e;
+    const int64_t rb = (ne + SWT - 1) / SWT;
+    hipLaunchKernelGGL(weights_absmax_kernel, dim3((unsigned)(rb < 1024 ? rb : 1024)), dim3(SWT), 0, awseg_s(stream), w, ne, trailer);
+    AWSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(SWT), 0, awseg_s(stream), w, ne, w_split, trailer);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -320,6 +410,7 @@ AWSEG_API int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split,
     if (((uintptr_t)x & 15) || ((uintptr_t)w_split & 15)) return AWSEG_EALIGN;
     gemm_args a;
     a.x = x; a.wh = reinterpret_cast<const _Float16*>(w_split); a.wl = a.wh + (int64_t)n * k;
+    a.trailer = reinterpret_cast<const unsigned*>(w_split + 2 * (int64_t)n * k);
     a.bias = bias; a.residual = residual; a.out = out; a.M = m; a.N = n; a.K = k; a.act = act;
     static int cus = 0;                                          // CU count of the (single, per-process) device, read once
     if (cus == 0) {

@@ -965,19 +965,23 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
 
 // -------------------------------------------------------------------------------- A16
 __global__ __launch_bounds__(kThreads)
-void density_field_kernel(int64_t hw, uint64_t seed, const float* __restrict__ scale_off, float* __restrict__ density)
+void density_field_kernel(int64_t hw, uint64_t seed, const float* __restrict__ scale_off, const float* __restrict__ uniform,
+                          float* __restrict__ density)
 {
     const int64_t img = blockIdx.y;
     const float sc = scale_off[img * 2], of = scale_off[img * 2 + 1];
     float* dst = density + img * hw;
+    const float* usrc = uniform ? uniform + img * hw : nullptr;      // parity mode: the host's torch.rand draws
     const int64_t nquad = (hw + 3) / 4;
     for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
-        uint32_t r[4];
-        awseg_philox::gen(seed, (uint64_t)(img * nquad + q), 0x0DE5u, r);
+        uint32_t r[4] = {0u, 0u, 0u, 0u};
+        if (!usrc) awseg_philox::gen(seed, (uint64_t)(img * nquad + q), 0x0DE5u, r);
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             int64_t p = q * 4 + k;
-            if (p < hw) { float u = awseg_u01(r[k]); float v = u * sc; dst[p] = v + of; }   // torch.rand*a + b, trainer.py:503-509
+            // torch.rand(h, w) * a + b in float32, two separately rounded operations (trainer.py:503-509); the "else"
+            // branch of the reference has no "+ b": u * 0.1 + 0.0f is the same float (u >= 0)
+            if (p < hw) { float u = usrc ? usrc[p] : awseg_u01(r[k]); float v = u * sc; dst[p] = v + of; }
         }
     }
 }
@@ -1190,13 +1194,13 @@ AWSEG_API int awseg_snow_apply(const uint8_t* imgs, int height, int width, const
     return streak_common(true, imgs, height, width, jobs, n_jobs, flakes, out, norm_out, mean_host, std_host, awseg_s(stream));
 }
 
-AWSEG_API int awseg_fog_density_field(const float* scale_offset, int batch, int64_t hw, uint64_t seed, float* density,
-                                      awseg_stream_t stream)
+AWSEG_API int awseg_fog_density_field(const float* scale_offset, int batch, int64_t hw, uint64_t seed, const float* uniform,
+                                      float* density, awseg_stream_t stream)
 {
     if (!scale_offset || !density || batch < 1 || hw < 1) return AWSEG_EINVAL;
     if (batch > 65535) return AWSEG_ERANGE;
     dim3 grid(grid_for((hw + 3) / 4, batch), batch);
-    hipLaunchKernelGGL(density_field_kernel, grid, dim3(kThreads), 0, awseg_s(stream), hw, seed, scale_offset, density);
+    hipLaunchKernelGGL(density_field_kernel, grid, dim3(kThreads), 0, awseg_s(stream), hw, seed, scale_offset, uniform, density);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -56,6 +56,16 @@ def draw_rain(h: int, w: int, intensity=None, rs=np.random):
         intensity = rs.uniform(0.2, 0.8)
     n = int(100 + intensity * (500 - 100))
     drops = np.empty((n, 5), dtype=np.int32)
+    if rs is not np.random:
+        # per-frame stream (throughput mode): the same distributions drawn as arrays — no parity with the reference's
+        # call-by-call order is defined in this mode, and 5 Python RNG calls per drop are ~8 ms of host time per frame
+        x, y = rs.randint(0, w, n), rs.randint(0, h, n)
+        length, thick, angle = rs.randint(5, 20, n), rs.choice((1, 3), n), rs.uniform(-15, 15, n)
+        drops[:, 0], drops[:, 1] = x, y
+        drops[:, 2] = np.clip((x + length * np.sin(np.radians(angle))).astype(np.int64), 0, w - 1)   # int(): truncation toward zero
+        drops[:, 3] = np.clip((y + length * np.cos(np.radians(angle))).astype(np.int64), 0, h - 1)
+        drops[:, 4] = thick
+        return intensity, drops
     for i in range(n):
         x = rs.randint(0, w)
         y = rs.randint(0, h)
@@ -74,8 +84,11 @@ def draw_snow(h: int, w: int, intensity=None, rs=np.random):
         intensity = rs.uniform(0.2, 0.7)
     n = int(50 + intensity * (200 - 50))
     flakes = np.empty((n, 3), dtype=np.int32)
-    for i in range(n):
-        flakes[i] = (rs.randint(0, w), rs.randint(0, h), rs.choice((2, 8)))
+    if rs is not np.random:                                         # per-frame stream: array draws (see draw_rain)
+        flakes[:, 0], flakes[:, 1], flakes[:, 2] = rs.randint(0, w, n), rs.randint(0, h, n), rs.choice((2, 8), n)
+    else:
+        for i in range(n):
+            flakes[i] = (rs.randint(0, w), rs.randint(0, h), rs.choice((2, 8)))
     k = int(rs.choice((3, 7)))
     return intensity, flakes, (k + 1 if k % 2 == 0 else k)
 

@@ -290,6 +290,14 @@ class DeepLabV3Plus(nn.Module):
         from . import fused
         feats = fused.resnet_features(self.encoder, x)
         dec = self.decoder.forward_fused(*feats)
-        low = self.segmentation_head[0](dec).contiguous()                   # [B,C,H/4,W/4] NCHW (small)
+        head = self.segmentation_head[0]
+        if head.kernel_size == (1, 1):
+            # the classifier as a GEMM on the NHWC rows (deterministic accumulation order; MIOpen's 1x1 path is not promised to be)
+            dl = fused.nhwc_view(dec)
+            Bq, H4, W4, Cd = dl.shape
+            y2 = ops.gemm_bias_act(dl.reshape(Bq * H4 * W4, Cd), head.weight.view(head.out_channels, Cd), head.bias, 0, split=False)
+            low = y2.view(Bq, H4, W4, -1).permute(0, 3, 1, 2).contiguous()  # [B,C,H/4,W/4] NCHW (small)
+        else:
+            low = head(dec).contiguous()
         out = self.segmentation_head[1](low)                                # x4 bilinear, align_corners=True -> NCHW
         return (out, feats[-1]) if return_features else out

@@ -59,6 +59,8 @@ def cached(module: nn.Module, name: str, tensors, fn):
         return cache[1]
     val = fn()
     setattr(module, "_awseg_" + name, (key, val))
+    if name != "wsplit" and hasattr(module, "_awseg_wsplit"):
+        del module._awseg_wsplit                  # split-operand images are keyed on the tensor just replaced
     return val
 
 
@@ -103,6 +105,34 @@ def winograd_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     return cached(conv, "wino", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
 
 
+def _is_patch_gemm(conv: nn.Conv2d) -> bool:
+    """Strided / patch convolutions that run as im2col + ONE GEMM (deterministic summation order; MIOpen's default for
+    these shapes is a split-K kernel that accumulates with atomics): stride-2 3x3 (ResNet layer2/3 first blocks, MiT
+    patch embeddings 2-4) and kernel == stride (MiT sequence reduction).  The two 7x7 stems on 3 input channels stay on
+    MIOpen (C % 4 != 0; their solver is a plain implicit GEMM)."""
+    return (conv.groups == 1 and conv.in_channels % 4 == 0 and conv.stride[0] == conv.stride[1] and conv.stride[0] > 1
+            and conv.kernel_size[0] > 1 and conv.dilation == (1, 1) and conv.padding[0] == conv.padding[1])
+
+
+def patch_weights(conv: nn.Conv2d, scale: torch.Tensor = None) -> torch.Tensor:
+    """[N,C,kh,kw] (times an optional per-N scale) -> [N, round8(kh*kw*C)] in im2col column order (ky, kx, c)."""
+    w = conv.weight if scale is None else conv.weight * scale.view(-1, 1, 1, 1)
+    n = w.shape[0]
+    w2 = w.permute(0, 2, 3, 1).reshape(n, -1)
+    k = w2.shape[1]
+    kp = (k + 7) // 8 * 8
+    if kp != k:
+        w2 = torch.nn.functional.pad(w2, (0, kp - k))
+    return w2.contiguous()
+
+
+def conv_gemm_nhwc(x_nhwc: torch.Tensor, conv: nn.Conv2d, w2: torch.Tensor, bias: torch.Tensor, act: int, owner=None) -> torch.Tensor:
+    """conv(x) as im2col + GEMM on a contiguous [B,H,W,C] tensor -> [B,Ho,Wo,N]; w2 = patch_weights(conv[, scale])."""
+    cols, ho, wo = ops.im2col_nhwc(x_nhwc, conv.kernel_size[0], conv.kernel_size[1], conv.stride[0], conv.padding[0], 1, w2.shape[1])
+    y = ops.gemm_bias_act(cols, w2, bias, act, w_split=split_weights(owner if owner is not None else conv, w2, cols.shape[0]))
+    return y.view(x_nhwc.shape[0], ho, wo, w2.shape[0])
+
+
 def _is_pointwise(conv: nn.Conv2d) -> bool:
     # (dilation is irrelevant for a 1x1 kernel: smp's make_dilated sets it on every conv of the stage)
     return conv.kernel_size == (1, 1) and conv.stride in ((1, 1), (2, 2)) and conv.padding == (0, 0) and conv.groups == 1
@@ -135,6 +165,16 @@ def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, 
             y2 = torch.addmm(shift, x2, w2.t()) if residual is None else torch.addmm(nhwc_view(residual).reshape(B * H * W, Cout), x2, w2.t())
             ops.bias_act_nhwc_(y2, torch.zeros_like(shift) if residual is None else shift, None, act)
         return y2.view(B, H, W, Cout).permute(0, 3, 1, 2)
+    if _is_patch_gemm(conv) and residual is None and act in (N.ACT_NONE, N.ACT_RELU):
+        def build():
+            inv = torch.rsqrt(bn.running_var + bn.eps)
+            scale = bn.weight * inv
+            sh = bn.bias - bn.running_mean * scale
+            if conv.bias is not None:
+                sh = sh + conv.bias * scale
+            return patch_weights(conv, scale), sh.contiguous()
+        w2, sh = cached(conv, "patch", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+        return conv_gemm_nhwc(nhwc_view(x), conv, w2, sh, act).permute(0, 3, 1, 2)
     if _is_winograd(conv) and act in (N.ACT_NONE, N.ACT_RELU):
         # 3x3 stride-1 "same" convolution: Winograd F(2x2,3x3) on the fp32 matrix cores, epilogue fused
         u, shift = winograd_conv_bn(conv, bn)
@@ -221,9 +261,13 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
     tok = None
     for st in seg.stages:
         pe = st.patch_embeddings
-        w = cached(pe.proj, "wcl", [pe.proj.weight], lambda: pe.proj.weight.contiguous(memory_format=CL))
-        y = F.conv2d(t, w, pe.proj.bias, pe.proj.stride, pe.proj.padding)
-        tok = _ln(nhwc_view(y), pe.layer_norm)                               # [B,H,W,C]
+        if _is_patch_gemm(pe.proj) and pe.proj.bias is not None:
+            w2 = cached(pe.proj, "patch", [pe.proj.weight], lambda: patch_weights(pe.proj))
+            y = conv_gemm_nhwc(nhwc_view(t), pe.proj, w2, pe.proj.bias, N.ACT_NONE)              # [B,H,W,C]
+        else:
+            w = cached(pe.proj, "wcl", [pe.proj.weight], lambda: pe.proj.weight.contiguous(memory_format=CL))
+            y = nhwc_view(F.conv2d(t, w, pe.proj.bias, pe.proj.stride, pe.proj.padding))
+        tok = _ln(y, pe.layer_norm)                                          # [B,H,W,C]
         B, H, W, C = tok.shape
         for blk in st.blocks:
             a = blk.attention
@@ -231,10 +275,14 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
             q = F.linear(hcur, a.q_proj.weight, a.q_proj.bias)
             if a.sequence_reduction_ratio > 1:
                 sr = a.sequence_reduction
-                wsr = cached(sr.sequence_reduction, "wcl", [sr.sequence_reduction.weight],
-                             lambda: sr.sequence_reduction.weight.contiguous(memory_format=CL))
-                kv = F.conv2d(hcur.permute(0, 3, 1, 2), wsr, sr.sequence_reduction.bias, sr.sequence_reduction.stride)
-                kv = _ln(nhwc_view(kv), sr.layer_norm)
+                src = sr.sequence_reduction
+                if _is_patch_gemm(src) and src.bias is not None:
+                    w2 = cached(src, "patch", [src.weight], lambda: patch_weights(src))
+                    kv = conv_gemm_nhwc(hcur, src, w2, src.bias, N.ACT_NONE)
+                else:
+                    wsr = cached(src, "wcl", [src.weight], lambda: src.weight.contiguous(memory_format=CL))
+                    kv = nhwc_view(F.conv2d(hcur.permute(0, 3, 1, 2), wsr, src.bias, src.stride))
+                kv = _ln(kv, sr.layer_norm)
             else:
                 kv = hcur
             k = F.linear(kv, a.k_proj.weight, a.k_proj.bias)

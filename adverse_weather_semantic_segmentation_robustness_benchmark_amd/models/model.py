@@ -124,6 +124,11 @@ class DepthEstimationHead(nn.Module):
         h = self.depth_head
         y = fused.conv_bn_act(feats_cl, h[0], h[1], N.ACT_RELU)
         y = fused.conv_bn_act(y, h[4], h[5], N.ACT_RELU)
+        if h[7].kernel_size == (1, 1):
+            yl = fused.nhwc_view(y)
+            Bq, hh, ww, Cc = yl.shape
+            d = torch.addmm(h[7].bias, yl.reshape(Bq * hh * ww, Cc), h[7].weight.view(h[7].out_channels, Cc).t())
+            return torch.sigmoid(d).view(Bq, hh, ww, -1).permute(0, 3, 1, 2).contiguous()
         return torch.sigmoid(h[7](y))
 
 

@@ -296,12 +296,19 @@ def snow(imgs: torch.Tensor, jobs: np.ndarray, flakes: np.ndarray, out=None, nor
 _DENSITY_TABLE = {"fog": (0.5, 0.5), "rain": (0.3, 0.2), "snow": (0.3, 0.2)}   # trainer.py:501-509, else (0.1, 0)
 
 
-def fog_density_field(conditions: Sequence[str], h: int, w: int, device, seed: int) -> torch.Tensor:
-    """AdverseWeatherTrainer._estimate_fog_density (PKG/training/trainer.py:480-511) on device."""
+def fog_density_field(conditions: Sequence[str], h: int, w: int, device, seed: int,
+                      uniform: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """AdverseWeatherTrainer._estimate_fog_density (PKG/training/trainer.py:480-511) on device.  `uniform` float32
+    [B,h,w] (device): the host's torch.rand draws -> bit-identical to the reference (parity mode); None: in-kernel
+    Philox keyed by `seed` (throughput mode)."""
     so = np.array([_DENSITY_TABLE.get(str(c), (0.1, 0.0)) for c in conditions], dtype=np.float32)
     sod = torch.from_numpy(so).to(device, non_blocking=True)
     out = torch.empty(len(conditions), h, w, dtype=torch.float32, device=device)
-    N.call("awseg_fog_density_field", N.ptr(sod), len(conditions), h * w, seed & 0xFFFFFFFFFFFFFFFF, N.ptr(out),
+    if uniform is not None:
+        uniform = uniform.to(device=device, dtype=torch.float32).contiguous()
+        if tuple(uniform.shape) != (len(conditions), h, w):
+            raise ValueError(f"uniform field must be [{len(conditions)},{h},{w}], got {tuple(uniform.shape)}")
+    N.call("awseg_fog_density_field", N.ptr(sod), len(conditions), h * w, seed & 0xFFFFFFFFFFFFFFFF, N.ptr(uniform), N.ptr(out),
                                             N.stream())
     return out
 
@@ -485,12 +492,15 @@ def gemm_wants_split(m: int, n: int, k: int) -> bool:
 
 
 def gemm_split_weights(w: torch.Tensor) -> torch.Tensor:
-    """w float32 [N,K] -> int16 [2,N,K]: f16 bit patterns of the high parts and of the scaled low parts."""
+    """w float32 [N,K] -> int16 [2,N,K]: f16 bit patterns of the high parts and of the scaled low parts of
+    w * 2^-ew (ew normalises max|w| into [2^13, 2^14)).  The returned tensor is a view of a buffer that is 16 bytes
+    longer: the trailer holds {max|w| bits, ew} and is read by awseg_gemm_split_bias_act — pass the view on as it is
+    (a clone would drop the trailer)."""
     w = w.contiguous()
     n, k = w.shape
-    out = torch.empty(2, n, k, dtype=torch.int16, device=w.device)
-    N.call("awseg_gemm_split_weights", N.ptr(w), n, k, N.ptr(out), N.stream())
-    return out
+    buf = torch.empty(2 * n * k + 8, dtype=torch.int16, device=w.device)
+    N.call("awseg_gemm_split_weights", N.ptr(w), n, k, N.ptr(buf), N.stream())
+    return buf[:2 * n * k].view(2, n, k)
 
 
 def gemm_split_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
@@ -499,10 +509,25 @@ def gemm_split_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[t
     x = x.contiguous()
     m, k = x.shape
     n = w_split.shape[1]
+    if w_split.untyped_storage().nbytes() - w_split.storage_offset() * 2 < (2 * n * k + 8) * 2:
+        raise N.AwsegError("w_split lost its 16-byte trailer (weight exponent): pass the tensor gemm_split_weights returned, not a copy")
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=x.device)
     N.call("awseg_gemm_split_bias_act", N.ptr(x), N.ptr(w_split), N.ptr(bias), N.ptr(residual), act, N.ptr(out), m, n, k, N.stream())
     return out
+
+
+def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int, dilation: int = 1, k_padded: Optional[int] = None):
+    """x float32 [B,H,W,C] -> (cols [B*Ho*Wo, k_padded], Ho, Wo): column (ky*kw + kx)*C + c, zero padded (awseg.h)."""
+    x = x.contiguous()
+    b, h, w, c = x.shape
+    k = kh * kw * c
+    kp = k if k_padded is None else int(k_padded)
+    ho = (h + 2 * pad - dilation * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dilation * (kw - 1) - 1) // stride + 1
+    cols = torch.empty(b * ho * wo, kp, dtype=torch.float32, device=x.device)
+    N.call("awseg_im2col_nhwc", N.ptr(x), b, h, w, c, kh, kw, stride, pad, dilation, kp, N.ptr(cols), N.stream())
+    return cols, ho, wo
 
 
 def dwconv3x3_upcat(a: torch.Tensor, hi: torch.Tensor, w9: torch.Tensor) -> torch.Tensor:

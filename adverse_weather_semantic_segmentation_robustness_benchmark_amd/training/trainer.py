@@ -94,6 +94,8 @@ class AdverseWeatherTrainer:
         self.best_val_loss = float("inf")
         self.best_val_miou = 0.0
         rank = torch.distributed.get_rank() if parallel.is_dist() else 0
+        # "philox": field generated in the kernel (nothing per-pixel crosses PCIe); "torch": the reference's CPU draws, bit-exact
+        self.density_rng = str(config.get("density_rng", "philox"))
         self._density_seed = int(config.get("seed", 42)) + 7919 * rank      # ranks see different samples: different density noise too
         # data parallelism averages gradients only: the replicas must START identical (the backbones are random-init
         # offline), so rank 0's parameters and buffers are broadcast once
@@ -138,6 +140,11 @@ class AdverseWeatherTrainer:
         if len(conds) == 0:
             return None
         h, w = batch["image"].shape[2:]
+        if self.density_rng == "torch":
+            # parity mode: the reference's draws — torch.rand(h, w) per sample, in sample order, on torch's CPU generator
+            # (trainer.py:501-509) — uploaded; the kernel applies the same two float32 operations
+            u = torch.stack([torch.rand(h, w) for _ in conds])
+            return ops.fog_density_field([str(c) for c in conds], h, w, self.device, 0, uniform=u.to(self.device, non_blocking=True))
         self._density_seed = (self._density_seed * 6364136223846793005 + 1442695040888963407) & 0xFFFFFFFFFFFFFFFF
         return ops.fog_density_field([str(c) for c in conds], h, w, self.device, self._density_seed)
 

@@ -129,6 +129,10 @@ def algorithmic_work(name, B, H, W, C, info):
         return "hbm", (3 + 12) * px * n
     if name == "awseg_combine_argmax_confusion":
         return "hbm", (2 * C * 4 + 1) * px * B         # two member logit maps + labels in; counters only out
+    if name == "awseg_ensemble_eval_stats":
+        return "hbm", (2 * C * 4 + 1) * px * B         # the same two member logit maps + labels again; bins / histogram out
+    if name == "awseg_depth_upsample_combine":
+        return "hbm", (4 + 4 + 4) * px * B             # segformer depth in, upsampled deeplab depth + combined depth out
     if name == "awseg_aspp_depthwise3":
         h, w = H // 16, W // 16
         return "hbm", (2048 * 4 + 3 * 2048 * 4) * h * w * B
@@ -242,6 +246,7 @@ def parse_args(argv=None):
                     help="b0_r50: BASELINE configs[1] (float32 results); b5_r101: configs[4] (SegFormer-B5 + DeepLabV3+-R101, bf16 MFMA path)")
     ap.add_argument("--conv-search", type=int, default=int(os.environ.get("AWSEG_CONV_SEARCH", "0")),
                     help="1: let MIOpen time its solvers per convolution shape during warm-up (torch.backends.cudnn.benchmark)")
+    ap.add_argument("--deterministic-convs", action="store_true", help="torch.backends.cudnn.deterministic = True for the two 7x7 stems left on MIOpen (measured 6x slower)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (gloo, CPU): every rank reports its block of the global sample set, rank 0 prints the pooled "
                          "frame count — exercises the self-launch / sharding path where there is no GPU (tests/)")
@@ -315,6 +320,10 @@ def main():
     import numpy as np                     # noqa: F811
     import torch                           # noqa: F811
     torch.backends.cudnn.benchmark = bool(args.conv_search)
+    # (the strided / patch convolutions run as im2col + GEMM on this repo's kernels: MIOpen's default pick for them is a
+    # split-K igemm that accumulates with atomics, run-to-run different — tools/check_op_determinism.py.  Forcing
+    # torch.backends.cudnn.deterministic instead costs 6x: 381 ms/step, gpurun_out/r02_bench_b.json)
+    torch.backends.cudnn.deterministic = bool(args.deterministic_convs)
 
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd import _native, ops, parallel
     if args.fp32_mfma:
@@ -374,10 +383,13 @@ def main():
         info.update({"awseg_fog_fused": conds.count("fog"), "awseg_night_apply": conds.count("night"),
                      "awseg_rain_apply": conds.count("rain"), "awseg_snow_apply": conds.count("snow"),
                      "awseg_normalize": conds.count("clean"), "awseg_weather_batch": len(ids)})
-        sel = torch.tensor(local_idx, dtype=torch.int64, device=dev)
-        contiguous = local_idx == list(range(local_idx[0], local_idx[0] + len(local_idx)))
-        r = raw[local_idx[0]:local_idx[0] + len(local_idx)] if contiguous else raw.index_select(0, sel)
-        l = labels[local_idx[0]:local_idx[0] + len(local_idx)] if contiguous else labels.index_select(0, sel)
+        if local_idx == list(range(local_idx[0], local_idx[0] + len(local_idx))):
+            r, l = raw[local_idx[0]:local_idx[0] + len(local_idx)], labels[local_idx[0]:local_idx[0] + len(local_idx)]
+        else:
+            # a batch that wraps around the rank's block: gather it (index built on the host and copied without a
+            # stream synchronisation — torch.tensor(..., device=cuda) would wait for the GPU to drain, every step)
+            sel = torch.tensor(local_idx, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+            r, l = raw.index_select(0, sel), labels.index_select(0, sel)
         img = image[:len(ids)]
         tf.apply_batch(r, conds, norm_out=img, frame_ids=ids)
         eval_batch(model, st, img, l, conds, metrics, with_stats=with_stats)

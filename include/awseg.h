@@ -301,12 +301,17 @@ int awseg_snow_apply(const uint8_t* imgs, int height, int width,
  *  A16  AdverseWeatherTrainer._estimate_fog_density
  *       replaces PKG/training/trainer.py:494-511 (and its .to(device) at :321)
  * ------------------------------------------------------------------------- *
- * density[b] = U[0,1) * scale[b] + offset[b] generated on device (Philox; the
- * reference draws from torch's CPU generator, so parity is in distribution only).
- * scale_offset: device float32 [B,2] ({.5,.5} fog, {.3,.2} rain/snow, {.1,0} else).
+ * density[b] = u * scale[b] + offset[b] in float32 (two roundings, as torch evaluates
+ * `torch.rand(h, w) * a + b`).  scale_offset: device float32 [B,2] ({.5,.5} fog,
+ * {.3,.2} rain/snow, {.1,0} else).
+ *   uniform == NULL  throughput mode: u from in-kernel Philox keyed by (seed, pixel) —
+ *                    nothing per-pixel crosses PCIe; parity in distribution only;
+ *   uniform != NULL  parity mode: device float32 [B,hw] holding the host's draws (the
+ *                    reference calls torch.rand(h, w) once per sample, in sample order, on
+ *                    torch's CPU generator): the result is bit-identical to the reference's.
  */
 int awseg_fog_density_field(const float* scale_offset, int batch, int64_t hw, uint64_t seed,
-                            float* density, awseg_stream_t stream);
+                            const float* uniform, float* density, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A15  FogDensityAwareLoss  replaces PKG/models/model.py:577-587, 610, 638-642
@@ -440,10 +445,14 @@ int awseg_gemm_tune(const float* x, const float* w, const float* bias, int has_r
  * on the f16 matrix cores with SPLIT operands (x = f16(x) + f16((x - f16(x)) * 2048) / 2048: 22 significant bits;
  * x*w = xh*wh + (xh*wl + xl*wh)/2048 as three f16 MFMA products, float32 accumulation) — for the compute-bound 1x1
  * convolutions (ResNet layer3 / layer4, ASPP, decoder; PKG/models/model.py:349), where it runs at several times the
- * float32-input MFMA rate.  awseg_gemm_split_weights writes w_split = uint16 [2][N][K] (f16 bit patterns: high parts,
- * then scaled low parts) from w float32 [N][K], once per weight.  awseg_gemm_split_bias_act: x float32 [M][K],
- * bias float32 [N] or NULL, residual float32 [M][N] or NULL (may alias out), act 0 none / 1 ReLU, out float32 [M][N].
- * K % 8 == 0; x and w_split 16-byte aligned; operands finite and below 65504 in magnitude.  No workspace, no host
+ * float32-input MFMA rate.  awseg_gemm_split_weights writes w_split = uint16 [2][N][K] + 8 (f16 bit patterns of the
+ * high parts, then of the scaled low parts, of w * 2^-ew, where ew brings max|w| — found on the device — into
+ * [2^13, 2^14); the 8 trailing uint16 hold {max|w| bits, ew, 0, 0} as uint32) from w float32 [N][K], once per weight:
+ * the buffer must have room for 2*N*K + 8 uint16.  awseg_gemm_split_bias_act: x float32 [M][K], bias float32 [N] or
+ * NULL, residual float32 [M][N] or NULL (may alias out), act 0 none / 1 ReLU, out float32 [M][N].
+ * K % 8 == 0; x and w_split 16-byte aligned.  Operand range: any finite float32.  Activations are split optimistically;
+ * a block that meets |x| >= 2^15 in its A tiles recomputes that output tile with x * 2^-e (exact) and multiplies 2^e
+ * back in the epilogue — twice the time for that tile, same accuracy.  Inf / NaN propagate.  No workspace, no host
  * state. */
 int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w_split, awseg_stream_t stream);
 int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split, const float* bias, const float* residual, int act,
@@ -457,6 +466,18 @@ int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split, const flo
 int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_width, int a_channels, const float* hi, int hi_channels,
                                int64_t batch, int height, int width, const float* w9, float* out, awseg_stream_t stream);
 
+/* awseg_im2col_nhwc: patch matrix of a strided / patch convolution on a channel-last tensor, so that the convolution
+ * is ONE deterministic GEMM (awseg_gemm_split_bias_act / awseg_gemm_bias_act) with bias / folded BatchNorm / activation
+ * in its epilogue: x float32 [B,H,W,C] -> cols float32 [B*Ho*Wo, k_padded], cols[m][(ky*kw + kx)*C + c] =
+ * x[b][oy*stride - pad + ky*dilation][ox*stride - pad + kx*dilation][c] (zero outside the image and in the
+ * k_padded - kh*kw*C tail columns), Ho = (H + 2 pad - dilation (kh-1) - 1) / stride + 1.  C % 4 == 0, k_padded % 4 == 0.
+ * Used for the stride-2 3x3 convolutions of ResNet layer2/layer3 (smp encoder behind PKG/models/model.py:349), the MiT
+ * patch embeddings and sequence-reduction convolutions (transformers SegformerOverlapPatchEmbeddings /
+ * SegformerEfficientSelfAttention.sr inside PKG/models/model.py:193): MIOpen's default solver for those shapes is a
+ * split-K implicit GEMM that accumulates with atomics — its result changes from run to run. */
+int awseg_im2col_nhwc(const float* x, int64_t batch, int height, int width, int channels, int kernel_h, int kernel_w,
+                      int stride, int pad, int dilation, int k_padded, float* cols, awseg_stream_t stream);
+
 /* awseg_attention_d32: O = softmax(Q K^T * scale) V for head_dim 32 in exact float32 on the matrix cores — the
  * self-attention of the MiT encoder (transformers' SegformerEfficientSelfAttention inside the SegformerModel call at
  * PKG/models/model.py:193).  q float32 [batch, n_queries, heads*32], k / v float32 [batch, n_keys, heads*32]
@@ -468,8 +489,10 @@ int awseg_attention_d32(const float* q, const float* k, const float* v, float* o
 /* awseg_attention_d32_split: the same operator with both GEMMs on the f16 matrix cores and SPLIT float32 operands
  * (x = f16(x) + f16((x - f16(x)) * 2048) / 2048: 22 significant bits, three f16 products per float32 product, float32
  * accumulation) — 16x the MFMA rate per product, so 5.3x per float32-grade product.  Same arguments, layouts and error
- * codes as awseg_attention_d32; inputs must be finite and below 65504 in magnitude.  Its error against a float64
- * reference is of the same order as the float32 kernel's (tests/test_gpu_kernels.py). */
+ * codes as awseg_attention_d32.  Operand range: any finite float32 — a block that meets |q*scale|, |k| or |v| >= 2^15
+ * (outside the split range of f16) redoes its query tile with power-of-two scaled operands and scales the scores / the
+ * output back.  Its error against a float64 reference is of the same order as the float32 kernel's
+ * (tests/test_gpu_kernels.py). */
 int awseg_attention_d32_split(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                               int n_queries, int n_keys, float scale, awseg_stream_t stream);
 

@@ -37,6 +37,11 @@ def golden_model():
 
 
 @pytest.fixture(scope="session")
+def golden_trainer():
+    return np.load(GOLDEN / "trainer.npz")
+
+
+@pytest.fixture(scope="session")
 def oracle():
     from oracle import cpu_oracle
     cpu_oracle.build()

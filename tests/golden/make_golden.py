@@ -246,7 +246,65 @@ def gen_model(model):
     out["dhead_in"] = x.numpy()
     for kname, v in dh.state_dict().items():
         out["dhead_sd." + kname] = v.numpy()
+    # the same head at a Winograd-eligible size (in 64, hidden 128 -> 64): the shapes the HIP depth-head kernels take.
+    # Its parameters are not stored (0.6 MB of noise): they are re-drawn by `dhead64_params` from a seeded generator,
+    # here and in the test (tests/test_gpu_kernels.py imports this recipe by name, not the reference).
+    dh64 = model.DepthEstimationHead(in_channels=64, hidden_channels=128).eval()
+    dh64.load_state_dict(dhead64_params(dh64.state_dict()))
+    x64 = torch.randn(2, 64, 12, 20, generator=torch.Generator().manual_seed(64))
+    with torch.no_grad():
+        out["dhead64_out"] = dh64(x64).numpy()
+    out["dhead64_in"] = x64.numpy()
     np.savez_compressed(OUT / "model.npz", **out)
+
+
+def dhead64_params(template):
+    """Deterministic parameters for a DepthEstimationHead state_dict (same keys / shapes as `template`): conv weights
+    N(0, 2/fan_in), small biases, BatchNorm with non-trivial affine terms and running statistics."""
+    g = torch.Generator().manual_seed(640)
+    sd = {}
+    for k, v in template.items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros_like(v)
+        elif k.endswith("running_var"):
+            sd[k] = torch.rand(v.shape, generator=g) * 1.5 + 0.5
+        elif k.endswith("running_mean"):
+            sd[k] = torch.rand(v.shape, generator=g) - 0.5
+        elif v.dim() == 4:
+            sd[k] = torch.randn(v.shape, generator=g) * (2.0 / (v.shape[1] * v.shape[2] * v.shape[3])) ** 0.5
+        elif k.endswith("weight"):                                  # BatchNorm gamma
+            sd[k] = torch.rand(v.shape, generator=g) + 0.5
+        else:                                                       # conv / BatchNorm biases
+            sd[k] = (torch.rand(v.shape, generator=g) - 0.5) * 0.6
+    return sd
+
+
+def gen_trainer():
+    """AdverseWeatherTrainer._estimate_fog_density (trainer.py:480-511): it never reads `self`, so it is called
+    unbound.  trainer.py imports torch.utils.tensorboard (absent here): an inert module entry stands in for it, as for
+    cv2 / smp above.  The uniform field the reference drew is recovered by replaying torch's CPU generator."""
+    inert = {"torch.utils.tensorboard": ["SummaryWriter"], "torchvision.transforms": [],
+             "albumentations": ["Compose", "HorizontalFlip", "RandomBrightnessContrast", "Normalize"],
+             "albumentations.pytorch": ["ToTensorV2"]}
+    for name, attrs in inert.items():                              # absent packages the import chain names and never calls here
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, object)
+            sys.modules[name] = m
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    from adverse_weather_semantic_segmentation_robustness_benchmark.training import trainer as ref_trainer
+    out = {}
+    conds = ["fog", "clean", "rain", "night", "snow", "fog"]
+    h, w = 12, 20
+    batch = {"weather_condition": conds, "image": torch.zeros(len(conds), 3, h, w)}
+    torch.manual_seed(11)
+    out["density"] = ref_trainer.AdverseWeatherTrainer._estimate_fog_density(None, batch).numpy()
+    torch.manual_seed(11)
+    out["uniform"] = torch.stack([torch.rand(h, w) for _ in conds]).numpy()
+    out["conditions"] = np.array(conds)
+    assert ref_trainer.AdverseWeatherTrainer._estimate_fog_density(None, {"weather_condition": [], "image": batch["image"]}) is None
+    np.savez_compressed(OUT / "trainer.npz", **out)
 
 
 def gen_depth_estimate():
@@ -288,5 +346,6 @@ if __name__ == "__main__":
     gen_metrics(metrics)
     gen_model(model)
     gen_depth_estimate()
+    gen_trainer()
     for f in sorted(OUT.glob("*.npz")):
         print(f.name, f.stat().st_size)

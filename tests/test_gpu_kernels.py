@@ -242,6 +242,60 @@ def test_philox_modes_are_deterministic_and_plausible(ops):
     assert 0.2 <= f[1].min().item() and f[1].max().item() < 0.5 and f[2].max().item() < 0.1
 
 
+def test_fog_density_field_parity_mode_is_the_reference(ops, oracle, golden_trainer):
+    """A16 parity mode: fed the reference's torch.rand draws, the kernel returns the reference's field bit for bit
+    (fixture: the reference method itself, tests/golden/make_golden.py::gen_trainer); and the trainer's
+    density_rng="torch" mode replays torch's CPU generator in the reference's order."""
+    g = golden_trainer
+    conds = [str(c) for c in g["conditions"]]
+    b, h, w = g["uniform"].shape
+    got = ops.fog_density_field(conds, h, w, "cuda", 0, uniform=dev(g["uniform"]))
+    assert np.array_equal(got.cpu().numpy(), g["density"])
+    assert np.array_equal(oracle.trainer_fog_density(conds, g["uniform"]), g["density"])
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.training.trainer import AdverseWeatherTrainer
+    tr = AdverseWeatherTrainer.__new__(AdverseWeatherTrainer)          # the method reads only these attributes
+    tr.device, tr.density_rng, tr._density_seed = torch.device("cuda"), "torch", 0
+    torch.manual_seed(11)
+    d = tr._estimate_fog_density({"weather_condition": conds, "image": torch.zeros(b, 3, h, w)})
+    assert np.array_equal(d.cpu().numpy(), g["density"])
+    assert tr._estimate_fog_density({"weather_condition": [], "image": torch.zeros(1, 3, h, w)}) is None
+    # ragged pixel counts (hw % 4 != 0) and one sample
+    u = torch.rand(1, 5, 7)
+    f = ops.fog_density_field(["snow"], 5, 7, "cuda", 0, uniform=u.cuda())
+    assert np.array_equal(f.cpu().numpy(), oracle.trainer_fog_density(["snow"], u.numpy()))
+
+
+def test_depth_head_winograd_size_matches_reference_fixture(ops, golden_model):
+    """DepthEstimationHead (PKG/models/model.py:16-78) at the shapes the Winograd kernels take (in 64, hidden 128 -> 64):
+    output of the REFERENCE module on seeded parameters (re-drawn here by the generator's recipe) vs the fused eval
+    path (Winograd 3x3 + BN + ReLU, Winograd 3x3 + 1x1 + sigmoid) — 1e-4 abs (north_star), measured ~1e-6."""
+    import importlib.util
+    from pathlib import Path
+    spec = importlib.util.spec_from_file_location("make_golden_recipe", Path(__file__).parent / "golden" / "make_golden.py")
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)                                        # module level only defines functions (no reference import)
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import DepthEstimationHead
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models import fused
+    g = golden_model
+    head = DepthEstimationHead(in_channels=64, hidden_channels=128).eval()
+    head.load_state_dict(mg.dhead64_params(head.state_dict()))
+    head = head.cuda()
+    x = dev(g["dhead64_in"])
+    ref = g["dhead64_out"]
+    h = head.depth_head
+    assert fused._is_winograd(h[0]) and fused._is_winograd(h[4])
+    with torch.no_grad():
+        got = head.forward_fused(x.contiguous(memory_format=torch.channels_last))
+        # and the single-launch tail: Conv3x3 -> BN -> ReLU -> Conv1x1 -> Sigmoid on the hidden map
+        mid = fused.conv_bn_act(x.contiguous(memory_format=torch.channels_last), h[0], h[1], 1)
+        u, shift = fused.winograd_conv_bn(h[4], h[5])
+        tail = ops.conv3x3_winograd(fused.nhwc_view(mid), u, shift, w2=h[7].weight.view(-1), b2=h[7].bias).unsqueeze(1)
+    e1 = np.abs(got.cpu().numpy() - ref).max()
+    e2 = np.abs(tail.cpu().numpy() - ref).max()
+    print(f"depth head 64->128->64->1 vs reference fixture: fused path {e1:.2e}, single-launch tail {e2:.2e}")
+    assert e1 <= 1e-4 and e2 <= 1e-4
+
+
 # ------------------------------------------------------------------ loss
 def test_loss_golden(ops, golden_model):
     g = golden_model
@@ -745,9 +799,70 @@ def test_gemm_split_float32_grade(ops, shape, res_act):
     assert e_split < 4 * e_lib + 1e-6
 
 
+@pytest.mark.parametrize("shape", [(300, 256, 128), (38400, 256, 128), (4100, 320, 72)])
+@pytest.mark.parametrize("xscale,wscale", [(1e5, 0.05), (3e4, 1e-9), (1e30, 1e-28), (2.0, 1e6), (1e-30, 1e4)])
+def test_gemm_split_large_operands(ops, shape, xscale, wscale):
+    """operands outside the f16 range must not give silently wrong products.  Activations at 1e5 / 1e30
+    (a few rows only, or all of them), weights at 1e6 / 1e-9 / 1e-28: the split GEMM must stay float32-grade against
+    float64 — same gate as test_gemm_split_float32_grade, relative to the result's magnitude."""
+    M, Nn, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + Nn + K + 5)
+    x = torch.randn(M, K, device="cuda", generator=g)
+    x[::5] *= xscale                                            # every fifth row is large: tiles with and without a second pass
+    w = torch.randn(Nn, K, device="cuda", generator=g) * wscale
+    bias = torch.randn(Nn, device="cuda", generator=g)
+    res = torch.randn(M, Nn, device="cuda", generator=g)
+    ref = (x.double() @ w.double().t() + bias.double() + res.double()).clamp_min(0)
+    ws = ops.gemm_split_weights(w)
+    out = res.clone()
+    got = ops.gemm_split_bias_act(x, ws, bias, 1, residual=out, out=out)
+    lib = ops.gemm_bias_act(x, w, bias, 1, residual=res, split=False)
+    assert torch.isfinite(got).all()
+    # errors per ROW, relative to the row's magnitude (rows differ by xscale)
+    rowmag = ref.abs().amax(dim=1).clamp_min(1.0)
+    e_split = ((got.double() - ref).abs().amax(dim=1) / rowmag).max().item()
+    e_lib = ((lib.double() - ref).abs().amax(dim=1) / rowmag).max().item()
+    print(f"gemm {shape} x*{xscale:g} w*{wscale:g}: rel err hipBLASLt f32 {e_lib:.3e}, split {e_split:.3e}")
+    assert e_split < 1e-5
+    assert e_split < 4 * e_lib + 1e-6
+
+
+def test_gemm_split_propagates_inf_nan(ops):
+    x = torch.randn(256, 64, device="cuda"); w = torch.randn(128, 64, device="cuda")
+    x[3, 5] = float("inf"); x[77, 0] = float("nan")
+    got = ops.gemm_split_bias_act(x, ops.gemm_split_weights(w), None, 0)
+    assert not torch.isfinite(got[3]).any() and torch.isnan(got[77]).all()
+    ok = torch.ones(256, dtype=torch.bool, device="cuda"); ok[3] = ok[77] = False
+    ref = x[ok].double() @ w.double().t()
+    assert (got[ok].double() - ref).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("qs,ks,vs", [(1.0, 1.0, 1e5), (1e5, 1e-4, 1.0), (300.0, 300.0, 7e4), (1e5, 1e5, 1e5), (1e-3, 5e4, 1e20)])
+def test_attention_d32_split_large_operands(ops, qs, ks, vs):
+    """q / k / v outside the f16 range (|x| up to 1e5 and beyond): the split-operand kernel redoes the tile with
+    power-of-two scaled operands; error against float64 within a small multiple of the float32 kernel's."""
+    B, nh, nq, nkv = 2, 2, 300, 256
+    g = torch.Generator(device="cuda").manual_seed(123)
+    C = nh * 32
+    q = torch.randn(B, nq, C, device="cuda", generator=g) * qs
+    k = torch.randn(B, nkv, C, device="cuda", generator=g) * ks
+    v = torch.randn(B, nkv, C, device="cuda", generator=g) * vs
+    scale = 32 ** -0.5
+    qh, kh, vh = (t.double().view(B, -1, nh, 32).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(B, nq, C)
+    mag = ref.abs().max().item()
+    o32 = ops.attention_d32(q, k, v, nh, scale, split=False)
+    osp = ops.attention_d32(q, k, v, nh, scale, split=True)
+    assert torch.isfinite(osp).all()
+    e32 = (o32.double() - ref).abs().max().item() / mag
+    esp = (osp.double() - ref).abs().max().item() / mag
+    print(f"attention q*{qs:g} k*{ks:g} v*{vs:g}: rel err float32 kernel {e32:.3e}, split kernel {esp:.3e}")
+    assert esp < 4 * e32 + 2e-6
+
+
 def test_gemm_split_abi_checks(ops):
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd import _native as N
-    x = torch.zeros(8, 12, device="cuda"); ws = torch.zeros(2, 4, 12, dtype=torch.int16, device="cuda"); o = torch.zeros(8, 4, device="cuda")
+    x = torch.zeros(8, 12, device="cuda"); ws = torch.zeros(2 * 4 * 16 + 8, dtype=torch.int16, device="cuda"); o = torch.zeros(8, 4, device="cuda")
     rc = N.lib().awseg_gemm_split_bias_act(N.ptr(x), N.ptr(ws), None, None, 0, N.ptr(o), 8, 4, 12, N.stream())
     assert rc != 0                                              # K % 8 != 0
     rc = N.lib().awseg_gemm_split_bias_act(N.ptr(x), N.ptr(ws), None, None, 0, N.ptr(o), 0, 4, 16, N.stream())
@@ -786,3 +901,27 @@ def test_depth_upsample_combine_matches_torch(ops, shape):
     d2, d = ops.depth_upsample_combine(d1, lo, None)
     assert (d - (d1 + ref2) / 2).abs().max().item() < 1e-6
 
+
+
+@pytest.mark.parametrize("case", [(2, 17, 23, 8, 3, 3, 2, 1), (1, 32, 64, 32, 8, 8, 8, 0), (2, 16, 20, 160, 2, 2, 2, 0), (1, 9, 11, 4, 3, 3, 2, 1),
+                                  (2, 12, 16, 128, 3, 3, 2, 1)])
+def test_im2col_patch_gemm_is_the_convolution(ops, case):
+    """awseg_im2col_nhwc + one GEMM == F.conv2d for the strided / patch convolutions (ResNet stride-2 3x3, MiT patch
+    embeddings and sequence reductions): the patch matrix bit-exact against torch's unfold, the product within fp32
+    summation-order noise of the convolution; K padded to a multiple of 8 with zero columns."""
+    import torch.nn.functional as F
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models import fused
+    b, h, w, c, kh, kw, s, p = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    x = torch.randn(b, h, w, c, device="cuda", generator=g)
+    kp = (kh * kw * c + 7) // 8 * 8
+    cols, ho, wo = ops.im2col_nhwc(x, kh, kw, s, p, 1, kp)
+    un = F.unfold(x.permute(0, 3, 1, 2), (kh, kw), dilation=1, padding=p, stride=s)             # [B, C*kh*kw, L], (c, ky, kx) order
+    un = un.view(b, c, kh * kw, ho * wo).permute(0, 3, 2, 1).reshape(b * ho * wo, kh * kw * c)    # -> (ky, kx, c)
+    assert torch.equal(cols[:, :kh * kw * c], un) and (cols[:, kh * kw * c:] == 0).all()
+    conv = torch.nn.Conv2d(c, 24, (kh, kw), stride=s, padding=p).cuda()
+    w2 = fused.patch_weights(conv)
+    assert w2.shape == (24, kp)
+    y = fused.conv_gemm_nhwc(x, conv, w2, conv.bias, 0)
+    ref = conv(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert y.shape == ref.shape and (y - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())

@@ -161,3 +161,11 @@ def test_depth_estimate_ladder_and_gaussian(oracle, golden_depth):
         assert d.dtype == np.float64 and np.array_equal(d, g[f"depth{k}"])
         assert d.min() >= 0.0 and d.max() <= 1.0 + 1e-12
 
+
+
+def test_trainer_fog_density_field_matches_reference_draws(oracle, golden_trainer):
+    """A16 (PKG/training/trainer.py:480-511): the oracle's restatement on the reference's own torch.rand draws is
+    bit-identical to what the reference returned (fixture made by calling the reference method, make_golden.py)."""
+    g = golden_trainer
+    got = oracle.trainer_fog_density([str(c) for c in g["conditions"]], g["uniform"])
+    assert got.dtype == np.float32 and np.array_equal(got, g["density"])

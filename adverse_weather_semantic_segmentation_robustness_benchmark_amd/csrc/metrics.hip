@@ -258,10 +258,15 @@ void confusion_kernel(const void* __restrict__ pred, const void* __restrict__ la
 }
 
 // ---------------------------------------------------------------------------------------
-// ECE accumulators: per block LDS bins {count u32, correct u32, sum_conf f32-in-f64 partial}.
-// Block partials: [nblk][n_bins] x {uint32 cnt, uint32 correct, double sum_conf}.
+// ECE accumulators: per block LDS bins {count u32, correct u32, sum of confidences}.
+// The confidence sum is kept in FIXED POINT, units of 2^-30, in 64-bit integers: a float32 confidence in [2^-7, 1] is a
+// multiple of 2^-30, so conf * 2^30 is an exact integer and integer sums do not depend on the order of the atomics, the
+// block schedule or the number of ranks the counters are later all-reduced over (results identical at any
+// GPU count).  2^33 pixels fit.  Block partials: [nblk][n_bins] x {uint32 cnt, uint32 correct, uint64 sum_conf_q30}.
 // ---------------------------------------------------------------------------------------
-struct ece_cell { uint32_t cnt; uint32_t correct; double sum_conf; };
+struct ece_cell { uint32_t cnt; uint32_t correct; unsigned long long sum_conf; };
+constexpr float kConfQ = 1073741824.0f;                          // 2^30
+__device__ __forceinline__ unsigned long long conf_q30(float conf) { return (unsigned long long)(conf * kConfQ); }
 
 template <int LDT>
 __global__ __launch_bounds__(kThreads)
@@ -269,9 +274,9 @@ void ece_kernel(const float* __restrict__ logits, int C, int64_t hw, const void*
                 const float* __restrict__ edges, int n_bins, ece_cell* __restrict__ partial)
 {
     __shared__ uint32_t s_cnt[64], s_cor[64];
-    __shared__ double s_sum[64];
+    __shared__ unsigned long long s_sum[64];
     __shared__ float s_edges[65];
-    for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0.0; }
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0ull; }
     for (int i = threadIdx.x; i <= n_bins; i += kThreads) s_edges[i] = edges[i];
     __syncthreads();
     const int64_t img = blockIdx.y;
@@ -290,7 +295,7 @@ void ece_kernel(const float* __restrict__ logits, int C, int64_t hw, const void*
             if (conf > s_edges[k] && conf <= s_edges[k + 1]) {
                 atomicAdd(&s_cnt[k], 1u);
                 if (bi == t) atomicAdd(&s_cor[k], 1u);
-                atomicAdd(&s_sum[k], (double)conf);
+                atomicAdd(&s_sum[k], conf_q30(conf));
                 break;
             }
     }
@@ -299,8 +304,8 @@ void ece_kernel(const float* __restrict__ logits, int C, int64_t hw, const void*
     for (int i = threadIdx.x; i < n_bins; i += kThreads) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = s_sum[i]; }
 }
 
-// bins out: per slot, n_bins x {int64 count, double sum_conf, int64 sum_correct}
-struct ece_out { long long cnt; double sum_conf; long long correct; };
+// bins out: per slot, n_bins x {int64 count, int64 sum_conf in units of 2^-30, int64 sum_correct}
+struct ece_out { long long cnt; long long sum_conf; long long correct; };
 
 __global__ void ece_fold_kernel(const ece_cell* __restrict__ partial, int blocks_per_image, int n_bins,
                                 const int32_t* __restrict__ cond, int n_slots, ece_out* __restrict__ bins)
@@ -309,19 +314,19 @@ __global__ void ece_fold_kernel(const ece_cell* __restrict__ partial, int blocks
     const int k = threadIdx.x;
     if (k >= n_bins) return;
     const ece_cell* src = partial + (int64_t)img * blocks_per_image * n_bins;
-    unsigned long long cnt = 0, cor = 0; double sum = 0.0;
+    unsigned long long cnt = 0, cor = 0, sum = 0;
     for (int b = 0; b < blocks_per_image; ++b) { cnt += src[b * n_bins + k].cnt; cor += src[b * n_bins + k].correct; sum += src[b * n_bins + k].sum_conf; }
     int slot = -1;
     if (cond) { int c = cond[img]; if (c >= 0 && c + 1 < n_slots) slot = c + 1; }
     if (cnt) {
         atomicAdd((unsigned long long*)&bins[k].cnt, cnt);
         atomicAdd((unsigned long long*)&bins[k].correct, cor);
-        atomicAdd(&bins[k].sum_conf, sum);
+        atomicAdd((unsigned long long*)&bins[k].sum_conf, sum);
         if (slot > 0) {
             ece_out* b = bins + (int64_t)slot * n_bins;
             atomicAdd((unsigned long long*)&b[k].cnt, cnt);
             atomicAdd((unsigned long long*)&b[k].correct, cor);
-            atomicAdd(&b[k].sum_conf, sum);
+            atomicAdd((unsigned long long*)&b[k].sum_conf, sum);
         }
     }
 }
@@ -347,14 +352,14 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
 {
     constexpr int C = 19;
     __shared__ uint32_t s_cnt[64], s_cor[64];
-    __shared__ float s_sum[64];
+    __shared__ unsigned long long s_sum[64];
     __shared__ float s_edges[65];
     // Score histogram of this block in LDS (2 x n_hist uint32, n_hist <= kHistMax): pixels of one frame
     // have similar scores, so counting straight into global memory is same-address atomic traffic
     // (measured 45 ms per batch); the block flushes only its non-zero bins at the end.
     extern __shared__ uint32_t s_hist[];
     for (int i = threadIdx.x; i < 2 * n_hist; i += kThreads) s_hist[i] = 0u;
-    for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0.f; }
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0ull; }
     for (int i = threadIdx.x; i <= n_bins; i += kThreads) s_edges[i] = edges[i];
     __syncthreads();
     const int64_t img = blockIdx.y;
@@ -405,7 +410,7 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
                 if (conf > s_edges[b] && conf <= s_edges[b + 1]) {
                     atomicAdd(&s_cnt[b], 1u);
                     if (rarg == (int)t) atomicAdd(&s_cor[b], 1u);
-                    atomicAdd(&s_sum[b], conf);
+                    atomicAdd(&s_sum[b], conf_q30(conf));
                     break;
                 }
             // disagreement (mutual information) and the error flag of the mean-probability prediction
@@ -427,7 +432,7 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
     }
     __syncthreads();
     ece_cell* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_bins;
-    for (int i = threadIdx.x; i < n_bins; i += kThreads) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = (double)s_sum[i]; }
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = s_sum[i]; }
     for (int i = threadIdx.x; i < 2 * n_hist; i += kThreads) {
         const uint32_t v = s_hist[i];
         if (v) atomicAdd(&hist[i], (unsigned long long)v);

@@ -1,0 +1,542 @@
+// wino_split.hip — the operator of wino.hip (3x3 stride-1 "same" convolution as Winograd F(2x2,3x3), NHWC, fused
+// epilogues; PKG/models/model.py:42-52, :219-221 and the ResNet bottleneck 3x3s behind :349) with its 16 GEMMs on the
+// f16 matrix cores and SPLIT float32 operands.  wino.hip is bound by the fp32-input MFMA itself (64 cycles per
+// 32x32x2 product tile: 63 % of a 157 TFLOP/s instruction); v_mfma_f32_32x32x16_f16 retires 16x the
+// multiply-adds per cycle, and a float32-grade product is three f16 products:
+//     V = Vh + Vl,  Vh = f16(V),  Vl = f16(V - Vh)      (22 significant bits while |V| >= 2^-3; absolute 2^-25 below)
+//     V * U = Vh*Uh + Vh*Ul + Vl*Uh                      (+ Vl*Ul, below float32 rounding noise, dropped)
+// ONE accumulator per position (256 registers per wave leave no room for a separate correction tile): the low parts are
+// used unscaled, which is exact as long as they are normal f16 numbers, so
+//   * U = G g G^T is NORMALISED on the host side (device ops, no synchronisation): stored as U * 2^-eu with max|U| in
+//     [2^13, 2^14), 2^eu in a trailer — tiny or huge filters keep 22 bits;
+//   * activations are taken as they are (BatchNorm/ReLU outputs are O(1)) while every thread tracks max|x| of the
+//     patches it transforms; a block whose maximum is >= 2^13 (4 max|x| could leave the f16 range in V = B^T x B) or
+//     < 2^-4 (low parts would go subnormal) runs its tile again with x * 2^sx, sx from the observed maximum, and the
+//     epilogue multiplies 2^(eu - sx) back.  Same guard as gemm_split.hip / attn.hip.
+//
+// Block = 8x8 tiles (16x16 outputs) x 64 output channels, 4 waves, input channels in chunks of 16 (one K step of the
+// MFMA).  Wave (nt, ph) owns ALL 64 tiles x 32 couts x 8 of the 16 positions (V rows 2ph, 2ph+1): 2 m-tiles x 8
+// positions = 256 accumulator registers.  With this split every U fragment is loaded by exactly ONE wave of the block,
+// straight from L2 into registers (64 KB per chunk per CU; sharing U through LDS would need 64 KB of LDS per chunk, a
+// second wave pair loading the same fragments 128 KB of L2 traffic), and a wave's U fragment of a position feeds two
+// m-tiles.  The partial inverse transforms of the two position halves meet through LDS once, in the epilogue.
+//   * raw 18x18-pixel patch of a chunk: LDS-DMA, three chunks ahead, ring of three 21 KB slots;
+//   * V (f16 high | low parts, [position][tile][16 hi | 16 lo], 16-byte chunks XOR-swizzled by (tile >> 2) & 3:
+//     conflict-free ds_read_b128 A fragments) is SINGLE-buffered in 64 KB and refilled in halves behind the MFMAs that
+//     consumed them: a chunk is two slots — slot A: MFMAs on V rows {0, 2} while rows {1, 3} of the same chunk are
+//     written and the next chunk's patch is read and row-transformed; slot B: MFMAs on rows {1, 3} while rows {0, 2}
+//     of the next chunk are written — one barrier per slot;
+//   * transform item of a thread = (tile, 4 channels): ds_read_b64 of the patch, packed f32 adds, split, ds_write_b64.
+#include "awseg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+constexpr int WT = 256;                    // threads per block
+constexpr int TB = 8;                      // 8 x 8 tiles per block
+constexpr int NTILE = TB * TB;             // 64
+constexpr int KC = 16;                     // input channels per chunk = one K step of v_mfma_f32_32x32x16_f16
+constexpr int NB = 64;                     // output channels per block
+constexpr int PW = 2 * TB + 2;             // 18 x 18 input pixels feed the block's tiles
+constexpr int QS = PW * PW + 1;            // 16-byte slots per channel quad of the patch (one pad slot: quad stride = 20 banks mod 64)
+constexpr int P_INSTR = (4 * QS + 63) / 64;   // 21 wave-wide LDS-DMA instructions per chunk
+constexpr int P_BYTES = P_INSTR * 1024;    // 21504
+constexpr int P_RING = 3;
+constexpr int V_POS = NTILE * 64;          // bytes of one position: 64 tiles x (16 hi + 16 lo halfs)
+constexpr int V_BYTES = 16 * V_POS;        // 65536
+constexpr int LDS_BYTES = V_BYTES + P_RING * P_BYTES + 64;
+
+struct ws_args {
+    const float* x; const uint16_t* U; const float* shift; const float* residual; const float* w2; const float* b2;
+    float* out;
+    int H, W, Cin, Cout, dil, act, nbx, nby, ngroups, batch;
+    int64_t u_halfs;                       // halfs of U in front of the trailer {2^eu as float}
+};
+
+__device__ __forceinline__ float act_apply(float v, int act) { return (act == AWSEG_ACT_RELU) ? (v > 0.f ? v : 0.f) : v; }
+
+// LDS-DMA of 16 bytes per lane through a buffer descriptor (see wino.hip: inline asm on purpose, hardware range check
+// supplies the zero padding)
+__device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "m0");
+}
+__device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+__device__ __forceinline__ uint32_t lds_addr(const void* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
+{
+    v2f d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+// (a, b) -> packed f16 high parts and packed f16 low parts (a - f16(a), b - f16(b): exact in float32, then rounded to f16)
+__device__ __forceinline__ void split_pair(v2f v, unsigned& hi, unsigned& lo)
+{
+    const auto hp = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
+    const h2 hh = __builtin_bit_cast(h2, hp);
+    hi = __builtin_bit_cast(unsigned, hp);
+    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x - (float)hh.x, v.y - (float)hh.y));
+}
+
+#ifdef AWSEG_WS_STAMP
+// tools/probe_wino_stamps.hip: s_memtime stamps of block 0, wave 0: [slot A work, barrier A, slot B work, barrier B,
+// chunks, prologue, epilogue, whole block]
+__device__ unsigned long long g_ws_stamp[8];
+#define WS_T(var) const unsigned long long var = __builtin_readcyclecounter()
+#else
+#define WS_T(var)
+#endif
+
+struct awseg_false { static constexpr bool value = false; };
+struct awseg_true { static constexpr bool value = true; };
+
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }   // -126 <= e <= 127
+
+template <int MODE>   // 0 FULL (NHWC map out), 1 HEAD1 (fused 1x1 + sigmoid, Cout == 64)
+__global__ __launch_bounds__(WT, 1)
+void wino_split_kernel(ws_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sV = smem;
+    unsigned char* sP = smem + V_BYTES;
+    unsigned* sMax = reinterpret_cast<unsigned*>(smem + V_BYTES + P_RING * P_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    // 1-D grid, XCD-aware (wino.hip): spatial tile t -> XCD t % 8, its cout groups back to back there
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int ng = jj % a.ngroups, t = (jj / a.ngroups) * 8 + xcd;
+    const int gx = a.nbx * a.dil, gy = a.nby * a.dil;
+    if (t >= gx * gy * a.batch) return;
+    const int b = t / (gx * gy), txy = t - b * (gx * gy), tyy = txy / gx, txx = txy - tyy * gx;
+    const int bx = txx % a.nbx, rx = txx / a.nbx;
+    const int by = tyy % a.nby, ry = tyy / a.nby;
+    const int Hs = (a.H - ry + a.dil - 1) / a.dil, Ws = (a.W - rx + a.dil - 1) / a.dil;   // sub-grid extent of this residue
+    if (by * 2 * TB >= Hs || bx * 2 * TB >= Ws) return;
+    const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
+    const int n0 = ng * NB;
+    const int nchunks = a.Cin / KC;
+
+    // ---- raw patch DMA: slot q = quad * QS + py * PW + px (16 bytes = 4 channels of one pixel); slots >= 4 * QS and the
+    // pad slot of each quad fetch out of range (zeros)
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+    uint32_t pvoff[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = (wave + 4 * j) * 64 + lane;
+        const int h = q / QS, r = q - h * QS;
+        const int py = r / PW, px = r - py * PW;
+        const int sy = by * 2 * TB - 1 + py, sx = bx * 2 * TB - 1 + px;
+        const int y = ry + a.dil * sy, x = rx + a.dil * sx;
+        const bool ok = h < 4 && r < PW * PW && sy >= 0 && sx >= 0 && y < a.H && x < a.W;
+        pvoff[j] = ok ? (uint32_t)(((y * a.W + x) * a.Cin + h * 4) * 4) : 0x80000000u;
+    }
+    const int n_pinstr = wave == 0 ? 6 : 5;                         // 21 instructions over 4 waves
+    const uint32_t p_lds = __builtin_amdgcn_readfirstlane(lds_addr(sP) + wave * 1024);
+    auto glds_patch = [&](int chunk, int slot) {
+        const uint32_t soff = (uint32_t)((chunk < nchunks ? chunk : nchunks - 1) * KC * 4);
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j < n_pinstr) bufdma16(x_rsrc, pvoff[j], soff, p_lds + (uint32_t)(slot * P_BYTES + j * 4096));
+    };
+
+    // ---- transform role: tile xtile, channel quad xq (4 channels = two packed pairs)
+    const int xtile = tid >> 2, xq = tid & 3;
+    const int xty = xtile >> 3, xtx = xtile & 7;
+    const int prd = (xq * QS + 2 * xty * PW + 2 * xtx) * 16;        // patch byte offset of the tile's pixel (0,0), this quad
+    const int xsw = (xtile >> 2) & 3;
+    const int vw_hi = xtile * 64 + (((xq >> 1) ^ xsw) * 16) + (xq & 1) * 8;          // hi chunk = quad >> 1 (channels 0-7 | 8-15)
+    const int vw_lo = xtile * 64 + (((2 + (xq >> 1)) ^ xsw) * 16) + (xq & 1) * 8;
+
+    // ---- MFMA role: wave (nt, ph): couts n0 + 32 nt .., positions 8 ph .. 8 ph + 7, both m-tiles
+    const int nt = wave & 1, ph = wave >> 1;
+    int a_hi[2], a_lo[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int tile = m * 32 + li, sw = (tile >> 2) & 3;
+        a_hi[m] = tile * 64 + ((hk ^ sw) * 16);
+        a_lo[m] = tile * 64 + (((2 + hk) ^ sw) * 16);
+    }
+    // U: [chunk][position][cout block of 32][hi h0 | hi h1 | lo h0 | lo h1][32 couts][8 halfs]: 2 KB per (chunk, p, cb)
+    const int ncb = a.Cout / 32, cb = (n0 >> 5) + nt;
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, (int)(a.u_halfs * 2), 0x00020000);
+    const uint32_t ulane = (uint32_t)(hk * 512 + li * 16);
+    const uint32_t u_p = (uint32_t)ncb * 2048u, u_c = 16u * u_p;
+    const uint32_t u_w = (uint32_t)(__builtin_amdgcn_readfirstlane(8 * ph) * (int)u_p + __builtin_amdgcn_readfirstlane(cb) * 2048);
+    const float uscale = *reinterpret_cast<const float*>(a.U + a.u_halfs);              // 2^eu
+
+    WS_T(blk0);
+    f32x16 acc[8][2];
+    float amax = 0.f;
+    float xs = 1.0f;                                                 // activation scale of a second pass (2^sx)
+    int sx = 0;
+    if (tid == 0) sMax[0] = 0u;
+
+    // One pass over the input channels.  SC::value: activations are multiplied by xs (second pass of the range guard);
+    // the first pass tracks max|x| instead.
+    auto run = [&](auto SC) {
+        constexpr bool SCALED = decltype(SC)::value;
+        v2f tA[16], tB[16];                                          // B^T d of the item's two channel pairs, alive across a slot boundary
+        // ---- transform pieces ----------------------------------------------------------------------------------------
+        auto patch_rows = [&](int slot, int e, v2f (&tt)[16]) {
+            const unsigned char* pp = sP + slot * P_BYTES + prd + e * 8;
+            v2f r[16];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) r[i * 4 + j] = *reinterpret_cast<const v2f*>(pp + (i * PW + j) * 16);
+            if (!SCALED) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(r[i].x)), __builtin_fabsf(r[i].y));
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) r[i] = r[i] * v2f{xs, xs};
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                tt[0 * 4 + j] = pk_sub(r[0 * 4 + j], r[2 * 4 + j]);
+                tt[1 * 4 + j] = pk_add(r[1 * 4 + j], r[2 * 4 + j]);
+                tt[2 * 4 + j] = pk_sub(r[2 * 4 + j], r[1 * 4 + j]);
+                tt[3 * 4 + j] = pk_sub(r[1 * 4 + j], r[3 * 4 + j]);
+            }
+        };
+        // row i of (t B) -> positions 4i .. 4i+3, split, stored as {hi pair A, hi pair B} and {lo pair A, lo pair B}
+        auto cols_store = [&](int i) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v2f va, vb;
+                if (j == 0) { va = pk_sub(tA[i * 4 + 0], tA[i * 4 + 2]); vb = pk_sub(tB[i * 4 + 0], tB[i * 4 + 2]); }
+                else if (j == 1) { va = pk_add(tA[i * 4 + 1], tA[i * 4 + 2]); vb = pk_add(tB[i * 4 + 1], tB[i * 4 + 2]); }
+                else if (j == 2) { va = pk_sub(tA[i * 4 + 2], tA[i * 4 + 1]); vb = pk_sub(tB[i * 4 + 2], tB[i * 4 + 1]); }
+                else { va = pk_sub(tA[i * 4 + 1], tA[i * 4 + 3]); vb = pk_sub(tB[i * 4 + 1], tB[i * 4 + 3]); }
+                u32x2 H, L; unsigned h, l;
+                split_pair(va, h, l); H[0] = h; L[0] = l;
+                split_pair(vb, h, l); H[1] = h; L[1] = l;
+                *reinterpret_cast<u32x2*>(sV + (i * 4 + j) * V_POS + vw_hi) = H;
+                *reinterpret_cast<u32x2*>(sV + (i * 4 + j) * V_POS + vw_lo) = L;
+            }
+        };
+        // ---- MFMA pieces -----------------------------------------------------------------------------------------------
+        auto u_load = [&](int c, int lp, h8& uh, h8& ul) {
+            const uint32_t so = (uint32_t)c * u_c + u_w + (uint32_t)lp * u_p;
+            uh = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane, so, 0));
+            ul = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane + 1024u, so, 0));
+        };
+        auto a_load = [&](int lp, h8 (&vh)[2], h8 (&vl)[2]) {
+            const unsigned char* vp = sV + (8 * ph + lp) * V_POS;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                vh[m] = *reinterpret_cast<const h8*>(vp + a_hi[m]);
+                vl[m] = *reinterpret_cast<const h8*>(vp + a_lo[m]);
+            }
+        };
+        auto mfma6 = [&](int lp, const h8 (&vh)[2], const h8 (&vl)[2], const h8& uh, const h8& ul) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x16 z = acc[lp][m];
+                if (MODE == 1) {                                     // couts on the accumulator rows (in-register sum over couts)
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vh[m], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh[m], z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vl[m], z, 0, 0, 0);
+                } else {
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[m], uh, z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[m], ul, z, 0, 0, 0);
+                    z = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[m], uh, z, 0, 0, 0);
+                }
+                acc[lp][m] = z;
+            }
+        };
+        // instruction-mix recipe for one position group: each of the 6 MFMAs is followed by a share of the group's
+        // companion work (mask 0x008 MFMA, 0x002 VALU, 0x020 VMEM read, 0x100 DS read, 0x200 DS write)
+#define WS_MIX(NVALU, NDSR, NDSW)                                                                \
+        _Pragma("unroll") for (int mm = 0; mm < 6; ++mm) {                                       \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                   \
+            if (mm < 2) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                       \
+            if (NDSR) __builtin_amdgcn_sched_group_barrier(0x100, NDSR, 0);                      \
+            if (NVALU) __builtin_amdgcn_sched_group_barrier(0x002, NVALU, 0);                    \
+            if (NDSW) __builtin_amdgcn_sched_group_barrier(0x200, NDSW, 0);                      \
+        }
+
+        // ---- prologue ----------------------------------------------------------------------------------------------------
+#pragma unroll
+        for (int lp = 0; lp < 8; ++lp)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[lp][m][r] = 0.f;
+        glds_patch(0, 0);
+        glds_patch(1, 1);
+        glds_patch(2, 2);
+        // U fragments are fetched TWO positions ahead of their MFMAs (ring of three register pairs): they come from L2 /
+        // the Infinity Cache (U does not fit one XCD's L2 for the wide layers), 500-900 cycles away
+        h8 ua_h, ua_l, ub_h, ub_l, uc_h, uc_l;
+        u_load(0, 0, ua_h, ua_l);
+        u_load(0, 1, ub_h, ub_l);
+        vm_wait_all();
+        __syncthreads();                                             // (also orders sMax[0] = 0 / the previous pass's V reads)
+        patch_rows(0, 0, tA);
+        patch_rows(0, 1, tB);
+        cols_store(0);
+        cols_store(2);
+        __syncthreads();
+
+        // ---- main loop: two slots per chunk ------------------------------------------------------------------------------
+        // positions 0..7 of chunk c use U registers a b c a b c a b; the loads issued during them fetch positions 2..7 of
+        // chunk c and 0, 1 of chunk c+1 into c a b c a b | c a ... -> the ring phase advances by 8 mod 3 = 2 per chunk, so
+        // the loop body is unrolled three times (phases 0, 2, 1)
+#define WS_CHUNK(c, U0h, U0l, U1h, U1l, U2h, U2l)                                                                 \
+        {                                                                                                        \
+            h8 vh0[2], vl0[2], vh1[2], vl1[2];                                                                   \
+            const int cn = (c) + 1 < nchunks ? (c) + 1 : (c);                                                    \
+            /* slot A: MFMAs on V rows {0, 2} of chunk c | rows {1, 3} of chunk c written, pair A of patch c+1 */ \
+            WS_T(st0);                                                                                           \
+            vm_wait_all();                                           /* the DMA issued a chunk ago (long landed) */ \
+            glds_patch((c) + 3, (c) % 3);                                                                        \
+            a_load(0, vh0, vl0);                                                                                 \
+            u_load(c, 2, U2h, U2l); a_load(1, vh1, vl1);                                                         \
+            cols_store(1);                                                                                       \
+            mfma6(0, vh0, vl0, U0h, U0l);                                                                        \
+            WS_MIX(11, 1, 2)                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            u_load(c, 3, U0h, U0l); a_load(2, vh0, vl0);                                                         \
+            cols_store(3);                                                                                       \
+            mfma6(1, vh1, vl1, U1h, U1l);                                                                        \
+            WS_MIX(11, 1, 2)                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            u_load(c, 4, U1h, U1l); a_load(3, vh1, vl1);                                                         \
+            mfma6(2, vh0, vl0, U2h, U2l);                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            u_load(c, 5, U2h, U2l);                                                                              \
+            patch_rows(((c) + 1) % 3, 0, tA);                                                                    \
+            mfma6(3, vh1, vl1, U0h, U0l);                                                                        \
+            WS_MIX(8, 3, 0)                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            WS_T(st1);                                                                                           \
+            __syncthreads();                                                                                     \
+            WS_T(st2);                                                                                           \
+            /* slot B: MFMAs on rows {1, 3} of chunk c | pair B of patch c+1, rows {0, 2} of chunk c+1 written */ \
+            a_load(4, vh0, vl0);                                                                                 \
+            u_load(c, 6, U0h, U0l); a_load(5, vh1, vl1);                                                         \
+            patch_rows(((c) + 1) % 3, 1, tB);                                                                    \
+            mfma6(4, vh0, vl0, U1h, U1l);                                                                        \
+            WS_MIX(8, 3, 0)                                                                                      \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            u_load(c, 7, U1h, U1l); a_load(6, vh0, vl0);                                                         \
+            cols_store(0);                                                                                       \
+            mfma6(5, vh1, vl1, U2h, U2l);                                                                        \
+            WS_MIX(11, 1, 2)                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            u_load(cn, 0, U2h, U2l); a_load(7, vh1, vl1);                                                        \
+            cols_store(2);                                                                                       \
+            mfma6(6, vh0, vl0, U0h, U0l);                                                                        \
+            WS_MIX(11, 1, 2)                                                                                     \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            u_load(cn, 1, U0h, U0l);                                                                             \
+            mfma6(7, vh1, vl1, U1h, U1l);                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                   \
+            WS_T(st3);                                                                                           \
+            __syncthreads();                                                                                     \
+            WS_T(st4);                                                                                           \
+            WS_ACC(st0, st1, st2, st3, st4)                                                                      \
+        }
+#ifdef AWSEG_WS_STAMP
+        unsigned long long sa = 0, ba = 0, sb = 0, bb = 0, nn = 0;
+#define WS_ACC(t0, t1, t2, t3, t4) { sa += t1 - t0; ba += t2 - t1; sb += t3 - t2; bb += t4 - t3; nn += 1; }
+#else
+#define WS_ACC(t0, t1, t2, t3, t4)
+#endif
+        WS_T(loop0);
+        int c = 0;
+        for (; c + 3 <= nchunks; c += 3) {
+            WS_CHUNK(c, ua_h, ua_l, ub_h, ub_l, uc_h, uc_l)
+            WS_CHUNK(c + 1, uc_h, uc_l, ua_h, ua_l, ub_h, ub_l)
+            WS_CHUNK(c + 2, ub_h, ub_l, uc_h, uc_l, ua_h, ua_l)
+        }
+        if (c < nchunks) {
+            WS_CHUNK(c, ua_h, ua_l, ub_h, ub_l, uc_h, uc_l)
+            if (c + 1 < nchunks) WS_CHUNK(c + 1, uc_h, uc_l, ua_h, ua_l, ub_h, ub_l)
+        }
+        vm_wait_all();
+#ifdef AWSEG_WS_STAMP
+        if (blockIdx.x == 0 && tid == 0) {
+            g_ws_stamp[0] += sa; g_ws_stamp[1] += ba; g_ws_stamp[2] += sb; g_ws_stamp[3] += bb; g_ws_stamp[4] += nn;
+            g_ws_stamp[5] += loop0 - blk0;
+        }
+#endif
+#undef WS_CHUNK
+#undef WS_ACC
+#undef WS_MIX
+    };
+
+    run(awseg_false{});
+    {
+        // ---- range guard: one more pass with scaled activations? --------------------------------------------------------
+        if (amax > 0.f) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, amax));
+        __syncthreads();
+        const unsigned mx = sMax[0];
+        const int ex = (int)(mx >> 23) & 0xff;
+        const float mf = __builtin_bit_cast(float, mx);
+        if (!(mx == 0u || ex == 0xff || (mf < 8192.0f && mf >= 0.0625f))) {     // out of range (and not all zero / Inf / NaN)
+            sx = 11 - (ex - 127);                                    // max|x| * 2^sx in [2^11, 2^12): 4 max|x| < 2^14
+            sx = sx > 126 ? 126 : sx;
+            xs = pow2f(sx);
+            run(awseg_true{});
+        }
+    }
+
+    // ---- output transform.  Wave (nt, ph) holds M rows 2ph, 2ph+1 (positions 8ph + 4 i' + j); Y = A^T M A is linear in M:
+    // each half computes its partial 2x2 and the halves meet through LDS — m-tile ph is finished by wave ph.
+    //   tmp[0][j] = M0j + M1j + M2j, tmp[1][j] = M1j - M2j - M3j;  Y[a][0] = tmp[a][0] + tmp[a][1] + tmp[a][2],
+    //   Y[a][1] = tmp[a][1] - tmp[a][2] - tmp[a][3]
+    float* xch = reinterpret_cast<float*>(sV);                        // [nt][dest ph][4 outputs][16 regs][64 lanes]
+    auto partial = [&](int m, f32x16 (&yp)[4]) {
+        f32x16 t0[4], t1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (ph == 0) { t0[j] = acc[j][m] + acc[4 + j][m]; t1[j] = acc[4 + j][m]; }
+            else { t0[j] = acc[j][m]; t1[j] = -acc[j][m] - acc[4 + j][m]; }
+        }
+        yp[0] = t0[0] + t0[1] + t0[2]; yp[1] = t0[1] - t0[2] - t0[3];
+        yp[2] = t1[0] + t1[1] + t1[2]; yp[3] = t1[1] - t1[2] - t1[3];
+    };
+    f32x16 y[4];
+    {
+        // the m-tile the partner finishes goes to LDS first (frees its accumulators), then this wave's own
+        float* dst = xch + ((nt * 2 + (1 - ph)) * 4) * 16 * 64 + lane;
+        if (ph == 0) partial(1, y); else partial(0, y);
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dst[(o * 16 + r) * 64] = y[o][r];
+        if (ph == 0) partial(0, y); else partial(1, y);
+    }
+    __syncthreads();
+    const float ysc = uscale * pow2f(-sx);                            // 2^(eu - sx)
+    {
+        const float* src = xch + ((nt * 2 + ph) * 4) * 16 * 64 + lane;
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) y[o][r] = (y[o][r] + src[(o * 16 + r) * 64]) * ysc;
+    }
+    const int mt = ph;                                               // this wave's m-tile in the epilogue
+
+    if (MODE == 0) {
+        // rows = tiles of m-tile mt (tile row 4 mt + (r >> 2), tile column 4 hk + (r & 3)), columns = couts (see wino.hip)
+        const int n = n0 + nt * 32 + li;
+        const float sh = a.shift[n];
+        const size_t img = (size_t)a.H * a.W * a.Cout;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img), 0, (int)(img * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual ? a.residual + (size_t)b * img : a.out), 0, (int)(img * 4), 0x00020000);
+        const bool has_res = a.residual != nullptr;
+        const int mt_u = __builtin_amdgcn_readfirstlane(mt);
+        const uint32_t kOob = 0x80000000u;
+        uint32_t vsel[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + bb);
+                const int xl = a.dil * 8 * hk;
+                vsel[c][bb] = (xs0 + xl < a.W) ? (uint32_t)((xl * a.Cout + n) * 4) : kOob;
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ty = mt_u * 4 + (r >> 2), c = r & 3;
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + aa);
+                if (yy >= a.H) continue;                             // wave-uniform
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + bb);
+                    const uint32_t soff = (uint32_t)((yy * a.W + xs0) * a.Cout * 4);
+                    float v = y[aa * 2 + bb][r] + sh;
+                    if (has_res) v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vsel[c][bb], soff, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, act_apply(v, a.act)), o_rsrc, vsel[c][bb], soff, 0);
+                }
+            }
+        }
+    } else {
+        // rows = couts n0 + 32 nt + (r & 3) + 8 (r >> 2) + 4 hk, columns = tiles of m-tile mt (tile = 32 mt + li)
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = n0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
+            const float sh = a.shift[co], w = a.w2[co];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) z[o] += fmaxf(y[o][r] + sh, 0.f) * w;
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o) z[o] += __shfl_xor(z[o], 32, 64);   // the other half-wave holds rows + 4 of the same tile
+        __syncthreads();                                             // every wave has read its exchange data
+        float* red = reinterpret_cast<float*>(sV);                   // [nt][tile][4]
+        if (hk == 0) *reinterpret_cast<float4*>(red + (nt * NTILE + mt * 32 + li) * 4) = make_float4(z[0], z[1], z[2], z[3]);
+        __syncthreads();
+        const int tile = tid >> 2, q = tid & 3;
+        const int uy = by * 2 * TB + 2 * (tile >> 3) + (q >> 1), ux = bx * 2 * TB + 2 * (tile & 7) + (q & 1);
+        const int yy = ry + a.dil * uy, xx = rx + a.dil * ux;
+        if (yy < a.H && xx < a.W) {
+            const float zz = red[tile * 4 + q] + red[(NTILE + tile) * 4 + q] + a.b2[0];
+            a.out[((int64_t)b * a.H + yy) * a.W + xx] = 1.0f / (1.0f + expf(-zz));
+        }
+    }
+#ifdef AWSEG_WS_STAMP
+    { WS_T(blk1); if (blockIdx.x == 0 && tid == 0) g_ws_stamp[7] += blk1 - blk0; }
+#endif
+}
+
+template <int MODE>
+int launch_ws(const ws_args& a, hipStream_t s)
+{
+    auto kern = wino_split_kernel<MODE>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
+    const int64_t tiles = (int64_t)a.nbx * a.dil * a.nby * a.dil * a.batch;
+    const int64_t nblocks = ((tiles + 7) / 8) * a.ngroups * 8;
+    if (nblocks >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WT), LDS_BYTES, s, a);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+AWSEG_API int64_t awseg_winograd_split_weight_halfs(int cin, int cout)
+{
+    if (cin < KC || cin % KC || cout < NB || cout % NB) return -1;
+    return (int64_t)16 * cin * cout * 2;                             // 16 positions x (hi + lo)
+}
+
+AWSEG_API int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
+                                                const uint16_t* u_split, const float* shift, const float* residual, int act,
+                                                const float* w2, const float* b2, float* out, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!x || !u_split || !shift || !out || batch < 0 || height < 1 || width < 1 || dilation < 1) return AWSEG_EINVAL;
+    if (cin < KC || (cin % KC) || cout < NB || (cout % NB)) return AWSEG_ERANGE;
+    if ((w2 == nullptr) != (b2 == nullptr)) return AWSEG_EINVAL;
+    if (w2 && (cout != NB || residual)) return AWSEG_ERANGE;
+    if (act != AWSEG_ACT_NONE && act != AWSEG_ACT_RELU) return AWSEG_ERANGE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)u_split & 15)) return AWSEG_EALIGN;
+    if ((int64_t)height * width * cin >= (int64_t)1 << 29 || (int64_t)height * width * cout >= (int64_t)1 << 29 ||
+        (int64_t)32 * cin * cout * 2 >= (int64_t)1 << 31) return AWSEG_ERANGE;       // 32-bit byte offsets
+    ws_args a;
+    a.x = x; a.U = u_split; a.shift = shift; a.residual = residual; a.w2 = w2; a.b2 = b2; a.out = out;
+    a.H = height; a.W = width; a.Cin = cin; a.Cout = cout; a.dil = dilation; a.act = act;
+    const int hs = (height + dilation - 1) / dilation, ws = (width + dilation - 1) / dilation;
+    a.nbx = (ws + 2 * TB - 1) / (2 * TB); a.nby = (hs + 2 * TB - 1) / (2 * TB); a.ngroups = cout / NB; a.batch = batch;
+    a.u_halfs = (int64_t)16 * cin * cout * 2;
+    return w2 ? launch_ws<1>(a, awseg_s(stream)) : launch_ws<0>(a, awseg_s(stream));
+}

@@ -70,16 +70,12 @@ class EvalState:
         self.auroc.view(-1).index_add_(0, idx, valid.to(torch.int64))
 
     def all_reduce(self):
+        """ONE SUM all-reduce of every counter — all int64 (confusion, ECE bins with fixed-point confidence sums, AUROC
+        histogram): integer sums are order-independent, so the results are bit-identical at any rank count."""
         ts = [self.acc.counts, self.acc.oob, self.ece]
         if self.auroc is not None:
             ts.append(self.auroc)
-        # ECE bins hold a float64 field inside an int64-typed buffer: reduce them as float64/int64 views
-        if parallel.is_dist():
-            raw = self.ece.view(-1, 3)
-            cnt, conf, cor = raw[:, 0].contiguous(), raw[:, 1].contiguous().view(torch.float64), raw[:, 2].contiguous()
-            others = [self.acc.counts, self.acc.oob, cnt, cor] + ([self.auroc] if self.auroc is not None else [])
-            parallel.all_reduce_sum_(others + [conf])
-            raw[:, 0], raw[:, 1], raw[:, 2] = cnt, conf.view(torch.int64), cor
+        parallel.all_reduce_sum_(ts)
 
     def auroc_value(self) -> float:
         neg, pos = self.auroc[0].double(), self.auroc[1].double()

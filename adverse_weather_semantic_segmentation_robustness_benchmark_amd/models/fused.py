@@ -105,6 +105,29 @@ def winograd_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     return cached(conv, "wino", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
 
 
+def winograd_split_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
+    """(split-operand image of U = G (w * bn_scale) G^T, shift) for the f16-MFMA Winograd kernel; cached like winograd_conv_bn."""
+    def build():
+        inv = torch.rsqrt(bn.running_var + bn.eps)
+        scale = bn.weight * inv
+        shift = bn.bias - bn.running_mean * scale
+        if conv.bias is not None:
+            shift = shift + conv.bias * scale
+        return ops.winograd_split_weights(conv.weight, scale), shift.contiguous()
+    return cached(conv, "wino_split", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+
+
+def conv3x3_winograd_bn(x_nhwc: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int = 0, residual: torch.Tensor = None,
+                        w2: torch.Tensor = None, b2: torch.Tensor = None) -> torch.Tensor:
+    """act(bn(conv3x3(x)) [+ residual]) (or the fused 1x1 + sigmoid head) on a contiguous NHWC tensor: the split-operand
+    f16-MFMA Winograd kernel, or the float32-input MFMA one (ops.WINO_SPLIT)."""
+    if ops.WINO_SPLIT:
+        us, shift = winograd_split_conv_bn(conv, bn)
+        return ops.conv3x3_winograd_split(x_nhwc, us, conv.out_channels, shift, act=act, dilation=conv.dilation[0], residual=residual, w2=w2, b2=b2)
+    u, shift = winograd_conv_bn(conv, bn)
+    return ops.conv3x3_winograd(x_nhwc, u, shift, act=act, dilation=conv.dilation[0], residual=residual, w2=w2, b2=b2)
+
+
 def _is_patch_gemm(conv: nn.Conv2d) -> bool:
     """Strided / patch convolutions that run as im2col + ONE GEMM (deterministic summation order; MIOpen's default for
     these shapes is a split-K kernel that accumulates with atomics): stride-2 3x3 (ResNet layer2/3 first blocks, MiT
@@ -177,9 +200,7 @@ def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, 
         return conv_gemm_nhwc(nhwc_view(x), conv, w2, sh, act).permute(0, 3, 1, 2)
     if _is_winograd(conv) and act in (N.ACT_NONE, N.ACT_RELU):
         # 3x3 stride-1 "same" convolution: Winograd F(2x2,3x3) on the fp32 matrix cores, epilogue fused
-        u, shift = winograd_conv_bn(conv, bn)
-        y = ops.conv3x3_winograd(nhwc_view(x), u, shift, act=act, dilation=conv.dilation[0],
-                                 residual=None if residual is None else nhwc_view(residual))
+        y = conv3x3_winograd_bn(nhwc_view(x), conv, bn, act, None if residual is None else nhwc_view(residual))
         return y.permute(0, 3, 1, 2)
     y = F.conv2d(x, w, None, conv.stride, conv.padding, conv.dilation, conv.groups)
     if not y.is_contiguous(memory_format=CL):

@@ -112,8 +112,7 @@ class DepthEstimationHead(nn.Module):
         mid = upconv3x3_bn_relu(feats, h[0], h[1], height, width)            # [B,hidden,H,W], channels_last memory
         if fused._is_winograd(h[4]) and h[4].out_channels == 64 and h[7].kernel_size == (1, 1):
             # Conv3x3 -> BN -> ReLU -> Conv1x1 -> Sigmoid in one Winograd/MFMA launch (no 64-channel map in HBM)
-            u, shift = fused.winograd_conv_bn(h[4], h[5])
-            d = ops.conv3x3_winograd(fused.nhwc_view(mid), u, shift, w2=h[7].weight.view(-1), b2=h[7].bias)
+            d = fused.conv3x3_winograd_bn(fused.nhwc_view(mid), h[4], h[5], w2=h[7].weight.view(-1), b2=h[7].bias)
             return d.unsqueeze(1)
         y = fused.conv_bn_act(mid, h[4], h[5], N.ACT_RELU)
         return torch.sigmoid(h[7](y)).contiguous()

@@ -136,8 +136,15 @@ def ensemble_eval_stats(seg1: torch.Tensor, seg2: torch.Tensor, mode: int, weigh
            N.ptr(auroc_hist), auroc_hist.shape[1], float(lo), float(hi), N.ptr(ws), N.stream())
 
 
+ECE_CONF_UNIT = 2.0 ** -30     # the device keeps the confidence sums in fixed point (int64, units of 2^-30): exact, order-independent
+
+
 def ece_bins_to_numpy(bins: torch.Tensor) -> np.ndarray:
-    return bins.cpu().numpy().view(np.uint8).reshape(bins.shape[0], bins.shape[1], 24).view(ECE_BIN_DTYPE)[..., 0]
+    """device bins int64 [slots, n_bins, {count, sum_conf_q30, sum_correct}] -> structured array with float64 sum_conf."""
+    raw = bins.cpu().numpy()
+    out = np.zeros(raw.shape[:2], dtype=ECE_BIN_DTYPE)
+    out["count"], out["sum_conf"], out["sum_correct"] = raw[..., 0], raw[..., 1].astype(np.float64) * ECE_CONF_UNIT, raw[..., 2]
+    return out
 
 
 # ----------------------------------------------------------------------------- A7
@@ -442,7 +449,51 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, shift: torch.Tensor, act:
 
 
 # 3x3 convolutions: 1 = Winograd on split-operand f16 MFMA (csrc/wino_split.hip), 0 = Winograd on float32-input MFMA
-WINO_SPLIT = os.environ.get("AWSEG_WINO_SPLIT", "0") != "0"     # default flips to 1 once wino_split.hip is in
+WINO_SPLIT = os.environ.get("AWSEG_WINO_SPLIT", "1") != "0"
+
+def winograd_split_weights(weight: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """[Cout,Cin,3,3] filters (times an optional per-Cout scale) -> the split-operand image of U = G g G^T that
+    awseg_conv3x3_winograd_split_nhwc reads (include/awseg.h): f16 high and low parts of U * 2^-eu in the B-fragment
+    order [Cin/16][16][Cout/32][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15][32][8], then 2^eu as one float32.  eu brings
+    max|U| into [2^13, 2^14); it is computed on the device (no host synchronisation).  int16 tensor, 16-byte aligned."""
+    g = weight.double()
+    if scale is not None:
+        g = g * scale.double().view(-1, 1, 1, 1)
+    cout, cin = weight.shape[0], weight.shape[1]
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=weight.device)
+    u = torch.einsum("ik,ockl,jl->ijco", G, g, G).reshape(16, cin, cout)                   # [p][ci][co], float64
+    mx = u.abs().max()
+    e = torch.where(mx > 0, torch.floor(torch.log2(mx.clamp_min(1e-300))) - 13.0, torch.zeros_like(mx))
+    us = u * torch.exp2(-e)
+    hi = us.to(torch.float16)
+    lo = (us - hi.double()).to(torch.float16)
+    nch, ncb = cin // 16, cout // 32
+
+    def frag(t):                                                                          # -> [nch][16][ncb][h][32][8]
+        return t.view(16, nch, 2, 8, ncb, 32).permute(1, 0, 4, 2, 5, 3)
+    img = torch.stack([frag(hi), frag(lo)], dim=3).reshape(-1).contiguous()               # [nch][16][ncb][hi/lo][h][32][8]
+    n = img.numel()
+    buf = torch.zeros(n + 8, dtype=torch.int16, device=weight.device)
+    buf[:n] = img.view(torch.int16)
+    buf[n:n + 2] = torch.exp2(e).to(torch.float32).reshape(1).view(torch.int16)
+    return buf
+
+
+def conv3x3_winograd_split(x: torch.Tensor, u_split: torch.Tensor, cout: int, shift: torch.Tensor, act: int = 0, dilation: int = 1,
+                           residual: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
+                           b2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3_winograd on the split-operand f16-MFMA kernel: x float32 [B,H,W,Cin] NHWC, u_split = winograd_split_weights(...)."""
+    x = x.contiguous()
+    b, h, w, cin = x.shape
+    need = N.lib().awseg_winograd_split_weight_halfs(cin, cout)
+    if need < 0 or u_split.numel() != need + 8:
+        raise N.AwsegError(f"u_split does not match Cin {cin}, Cout {cout} (expected {need} + 8 int16)")
+    out = torch.empty((b, h, w) if w2 is not None else (b, h, w, cout), dtype=torch.float32, device=x.device)
+    N.call("awseg_conv3x3_winograd_split_nhwc", N.ptr(x), b, h, w, cin, cout, dilation, N.ptr(u_split), N.ptr(shift.contiguous()),
+           N.ptr(None if residual is None else residual.contiguous()), act, N.ptr(None if w2 is None else w2.contiguous()),
+           N.ptr(None if b2 is None else b2.contiguous()), N.ptr(out), N.stream())
+    return out
+
 
 GEMM_WORKSPACE_BYTES = 32 << 20
 GEMM_TUNE = os.environ.get("AWSEG_GEMM_TUNE", "0") != "0"      # opt-in: time hipBLASLt's candidates once per new problem shape

@@ -466,6 +466,19 @@ int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split, const flo
 int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_width, int a_channels, const float* hi, int hi_channels,
                                int64_t batch, int height, int width, const float* w9, float* out, awseg_stream_t stream);
 
+/* awseg_conv3x3_winograd_split_nhwc: the operator of awseg_conv3x3_winograd_nhwc (same arguments, layouts, epilogues
+ * and error codes) with its 16 position GEMMs on the f16 matrix cores and SPLIT float32 operands (V = f16(V) + f16(V -
+ * f16(V)), three f16 products per float32-grade product, float32 accumulation): 16x the multiply-adds per cycle of the
+ * float32-input MFMA that bounds the other kernel.  u_split: uint16 [Cin/16][16 positions][Cout/32][hi k 0-7 | hi k 8-15 |
+ * lo k 0-7 | lo k 8-15][32 couts][8] f16 bit patterns of U * 2^-eu (U = G (w * bn_scale) G^T, max|U * 2^-eu| in
+ * [2^13, 2^14)), followed by 2^eu as one float32 (a 16-byte trailer): awseg_winograd_split_weight_halfs(cin, cout) uint16
+ * in front of the trailer.  Cin % 16 == 0, Cout % 64 == 0.  Operand range: any finite float32 activations — a block whose
+ * patch maximum is >= 2^13 or < 2^-4 redoes its tile with power-of-two scaled activations. */
+int64_t awseg_winograd_split_weight_halfs(int cin, int cout);
+int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
+                                      const uint16_t* u_split, const float* shift, const float* residual, int act,
+                                      const float* w2, const float* b2, float* out, awseg_stream_t stream);
+
 /* awseg_im2col_nhwc: patch matrix of a strided / patch convolution on a channel-last tensor, so that the convolution
  * is ONE deterministic GEMM (awseg_gemm_split_bias_act / awseg_gemm_bias_act) with bias / folded BatchNorm / activation
  * in its epilogue: x float32 [B,H,W,C] -> cols float32 [B*Ho*Wo, k_padded], cols[m][(ky*kw + kx)*C + c] =
@@ -524,7 +537,8 @@ int awseg_layernorm_rows(const float* x, int64_t n_rows, int channels, const flo
  * For every pixel with label != 255: conf = max softmax prob, bin k with
  * edges[k] < conf <= edges[k+1] (edges: device float32[n_bins+1] =
  * torch.linspace(0,1,n_bins+1), n_bins <= 64); bins[slot][k] accumulates
- * {int64 count, float64 sum_conf, int64 sum_correct} (24 bytes per bin).
+ * {int64 count, int64 sum_conf in units of 2^-30 (fixed point: exact and independent of summation order), int64
+ * sum_correct} (24 bytes per bin).
  * Slots as in awseg_combine_argmax_confusion.  workspace as awseg_metrics_workspace.
  */
 int awseg_ece_accumulate(const float* logits, int64_t batch, int num_classes, int64_t hw,

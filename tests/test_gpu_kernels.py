@@ -463,6 +463,58 @@ def test_conv3x3_winograd_matches_direct(ops, shape):
         assert got.shape == (B, H, W) and (got.double() - want).abs().max().item() < 1e-5
 
 
+@pytest.mark.parametrize("shape", [(2, 20, 36, 32, 64, 1), (1, 16, 16, 16, 64, 1), (2, 37, 29, 64, 128, 1), (1, 24, 40, 48, 64, 2),
+                                   (1, 33, 47, 32, 128, 2), (1, 50, 34, 16, 64, 3), (1, 40, 72, 256, 256, 1), (2, 16, 32, 2048, 256, 1)])
+@pytest.mark.parametrize("xscale,wscale", [(1.0, 1.0), (3e4, 1e-3), (1e-6, 50.0)])
+def test_conv3x3_winograd_split_float32_grade(ops, shape, xscale, wscale):
+    """Winograd F(2x2,3x3) on split-operand f16 MFMA against a float64 direct convolution, next to the float32-MFMA
+    Winograd kernel on the same inputs: bias, ReLU, residual, dilation, ragged edges, the fused 1x1 + sigmoid head; and
+    activations / filters far outside the f16 range (the in-kernel range guard redoes those tiles scaled).  1e-4 abs on
+    O(1) outputs (north_star), and never worse than a small multiple of the float32 kernel's error."""
+    B, H, W, Cin, Cout, d = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + 17)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g) * xscale
+    x[:, ::3, 1::4] *= 1e-3                                        # small activations next to O(1) ones
+    wt = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (3.0 * Cin ** 0.5) * wscale
+    scale = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    shift = torch.randn(Cout, device="cuda", generator=g)
+    res = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+    u32 = ops.winograd_weights(wt, scale)
+    us = ops.winograd_split_weights(wt, scale)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), (wt * scale.view(-1, 1, 1, 1)).double(), None, 1, d, d)
+    ref = ref.permute(0, 2, 3, 1) + shift.double()
+    mag = max(1.0, ref.abs().max().item())
+    got = ops.conv3x3_winograd_split(x, us, Cout, shift, act=0, dilation=d)
+    f32 = ops.conv3x3_winograd(x, u32, shift, act=0, dilation=d)
+    e_s, e_f = (got.double() - ref).abs().max().item() / mag, (f32.double() - ref).abs().max().item() / mag
+    print(f"winograd {shape} x*{xscale:g} w*{wscale:g}: rel err float32 kernel {e_f:.3e}, split kernel {e_s:.3e}")
+    assert e_s < 1e-4 and e_s < 4 * e_f + 2e-6
+    got = ops.conv3x3_winograd_split(x, us, Cout, shift, act=1, dilation=d, residual=res)
+    assert (got.double() - (ref + res.double()).clamp_min(0)).abs().max().item() / mag < 1e-4
+    if Cout == 64:
+        w2 = torch.randn(64, device="cuda", generator=g) * 0.2 / mag
+        b2 = torch.randn(1, device="cuda", generator=g)
+        got = ops.conv3x3_winograd_split(x, us, Cout, shift, dilation=d, w2=w2, b2=b2)
+        want = torch.sigmoid((ref.clamp_min(0) * w2.double()).sum(-1) + b2.double())
+        assert got.shape == (B, H, W) and (got.double() - want).abs().max().item() < 2e-5
+
+
+def test_conv3x3_winograd_split_abi_checks(ops, native):
+    N = native
+    sh = torch.zeros(64, device="cuda")
+    us = ops.winograd_split_weights(torch.zeros(64, 16, 3, 3, device="cuda"))
+    x = torch.zeros(1, 8, 8, 16, device="cuda")
+    assert us.numel() == N.lib().awseg_winograd_split_weight_halfs(16, 64) + 8
+    assert N.lib().awseg_winograd_split_weight_halfs(8, 64) < 0 and N.lib().awseg_winograd_split_weight_halfs(16, 32) < 0
+    with pytest.raises(N.AwsegError):
+        ops.conv3x3_winograd_split(torch.zeros(1, 8, 8, 32, device="cuda"), us, 64, sh)                                  # weights of another shape
+    with pytest.raises(N.AwsegError):
+        ops.conv3x3_winograd_split(x, us, 64, sh, w2=torch.zeros(64, device="cuda"))                                     # w2 without b2
+    assert ops.conv3x3_winograd_split(x[:0], us, 64, sh).shape == (0, 8, 8, 64)
+    out = ops.conv3x3_winograd_split(x, us, 64, sh)                                                                       # all-zero input and filters
+    assert (out == 0).all()
+
+
 def test_conv3x3_winograd_abi_checks(ops, native):
     N = native
     x = torch.zeros(1, 8, 8, 16, device="cuda"); u = torch.zeros(2, 16, 2, 64, 4, device="cuda"); sh = torch.zeros(64, device="cuda")

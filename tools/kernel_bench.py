@@ -134,6 +134,9 @@ def main():
         b2w = torch.zeros(1, device=dev) if head else None
         fl = 2.0 * 16 * cin * cout * b * ((hh + 1) // 2) * ((ww + 1) // 2)
         cases[name] = (lambda: ops.conv3x3_winograd(xw, u, shw, act=1, dilation=dil, w2=w2w, b2=b2w), "mfma", fl)
+        us = ops.winograd_split_weights(torch.randn(cout, cin, 3, 3, device=dev) * 0.05)
+        cases[name + " [split f16x3, issued flops]"] = (lambda: ops.conv3x3_winograd_split(xw, us, cout, shw, act=1, dilation=dil, w2=w2w, b2=b2w),
+                                                         "mfma_f16", 3 * fl)
     wino_case("winograd 128->64 +1x1+sigmoid @full (segformer depth)", B, H, W, 128, 64, 1, True)
     wino_case("winograd 64->64 @1/4 (resnet l1)", B, H // 4, W // 4, 64, 64, 1, False)
     wino_case("winograd 256->256 @1/16 (resnet l3)", B, H // 16, W // 16, 256, 256, 1, False)

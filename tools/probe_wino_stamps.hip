@@ -1,0 +1,47 @@
+// Cycle stamps of the split-operand Winograd kernel: where do a wave's cycles per 16-channel chunk go?
+// Build and run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -DAWSEG_WS_STAMP -Iinclude \
+//         -Iadverse_weather_semantic_segmentation_robustness_benchmark_amd/csrc tools/probe_wino_stamps.hip -o /tmp/probe_ws && /tmp/probe_ws
+#include "wino_split.hip"
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+static void run(int B, int H, int W, int cin, int cout, int dil, bool head)
+{
+    float *x, *o, *sh, *w2, *b2; uint16_t* u;
+    const size_t nx = (size_t)B * H * W * cin, no = (size_t)B * H * W * (head ? 1 : cout);
+    const int64_t uh = awseg_winograd_split_weight_halfs(cin, cout);
+    hipMalloc(&x, nx * 4); hipMalloc(&o, no * 4); hipMalloc(&sh, cout * 4); hipMalloc(&w2, 64 * 4); hipMalloc(&b2, 4); hipMalloc(&u, uh * 2 + 16);
+    std::vector<float> hx(nx);
+    for (size_t i = 0; i < nx; ++i) hx[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
+    hipMemcpy(x, hx.data(), nx * 4, hipMemcpyHostToDevice);
+    std::vector<uint16_t> hu(uh + 8, 0x3c00);                       // every U half = 1.0 (timing only)
+    const float one = 1.0f; memcpy(&hu[uh], &one, 4);
+    hipMemcpy(u, hu.data(), hu.size() * 2, hipMemcpyHostToDevice);
+    hipMemset(sh, 0, cout * 4); hipMemset(w2, 0, 256); hipMemset(b2, 0, 4);
+    for (int rep = 0; rep < 3; ++rep) awseg_conv3x3_winograd_split_nhwc(x, B, H, W, cin, cout, dil, u, sh, nullptr, 1, head ? w2 : nullptr, head ? b2 : nullptr, o, nullptr);
+    hipDeviceSynchronize();
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamp), z, sizeof z);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0, nullptr);
+    int rc = awseg_conv3x3_winograd_split_nhwc(x, B, H, W, cin, cout, dil, u, sh, nullptr, 1, head ? w2 : nullptr, head ? b2 : nullptr, o, nullptr);
+    hipEventRecord(e1, nullptr); hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    hipMemcpyFromSymbol(r, HIP_SYMBOL(g_ws_stamp), sizeof r);
+    const double n = (double)r[4];
+    printf("%d x %dx%d  %d->%d d%d head=%d: rc %d, %.3f ms (stamped build); block 0 wave 0: %llu chunks\n", B, H, W, cin, cout, dil, (int)head, rc, ms, r[4]);
+    printf("  per chunk (s_memtime ticks): slot A work %.0f | barrier A %.0f | slot B work %.0f | barrier B %.0f | total %.0f;  prologue %llu, whole block %llu\n",
+           r[0] / n, r[1] / n, r[2] / n, r[3] / n, (r[0] + r[1] + r[2] + r[3]) / n, r[5], r[7]);
+    hipFree(x); hipFree(o); hipFree(sh); hipFree(w2); hipFree(b2); hipFree(u);
+}
+
+int main()
+{
+    run(8, 64, 128, 2048, 256, 1, false);
+    run(8, 64, 128, 512, 512, 2, false);
+    run(8, 256, 512, 64, 64, 1, false);
+    run(2, 1024, 2048, 128, 64, 1, true);
+    return 0;
+}

@@ -44,8 +44,8 @@ constexpr int NTILE = TB * TB;             // 64
 constexpr int KC = 16;                     // input channels per chunk = one K step of v_mfma_f32_32x32x16_f16
 constexpr int NB = 64;                     // output channels per block
 constexpr int PW = 2 * TB + 2;             // 18 x 18 input pixels feed the block's tiles
-constexpr int QS = PW * PW + 1;            // 16-byte slots per channel quad of the patch (one pad slot: quad stride = 20 banks mod 64)
-constexpr int P_INSTR = (4 * QS + 63) / 64;   // 21 wave-wide LDS-DMA instructions per chunk
+constexpr int NPIX = PW * PW;              // 324 pixels, 64 bytes (16 channels) each: 4 consecutive DMA lanes fetch one pixel's 64 contiguous bytes
+constexpr int P_INSTR = (4 * NPIX + 63) / 64; // 21 wave-wide LDS-DMA instructions per chunk
 constexpr int P_BYTES = P_INSTR * 1024;    // 21504
 constexpr int P_RING = 3;
 constexpr int V_POS = NTILE * 64;          // bytes of one position: 64 tiles x (16 hi + 16 lo halfs)
@@ -68,11 +68,14 @@ __device__ __forceinline__ void bufdma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t v
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "m0");
 }
 __device__ __forceinline__ void vm_wait_all() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+// everything but the six youngest vector-memory operations (the U fragments of the next three positions, fetched last)
+__device__ __forceinline__ void vm_wait_keep6() { asm volatile("s_waitcnt vmcnt(6)" : : : "memory"); }
 __device__ __forceinline__ uint32_t lds_addr(const void* p)
 {
     return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
 }
 
+#ifdef AWSEG_WS_ASM_PK
 __device__ __forceinline__ v2f pk_add(v2f a, v2f b) { v2f d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
 __device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
 {
@@ -80,20 +83,30 @@ __device__ __forceinline__ v2f pk_sub(v2f a, v2f b)
     asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
     return d;
 }
+#else
+// plain vector arithmetic: the scheduler can classify these (sched_group_barrier) and, next to f16 MFMAs, whether hipcc
+// keeps them packed matters less than where they are placed
+__device__ __forceinline__ v2f pk_add(v2f a, v2f b) { return a + b; }
+__device__ __forceinline__ v2f pk_sub(v2f a, v2f b) { return a - b; }
+#endif
 
 // (a, b) -> packed f16 high parts and packed f16 low parts (a - f16(a), b - f16(b): exact in float32, then rounded to f16)
+// Three instructions: v_cvt_pkrtz_f16_f32, then one mixed-precision FMA per value — v_fma_mixlo/mixhi_f16 computes
+// x * 1.0 + (-hi) with the f16 source widened and the sum taken in float32 (exact: hi is x's leading bits), rounds it to f16
+// and writes one half of the destination.  (The plain form costs six: two v_cvt_f32_f16, two subtracts, a second pack.)
 __device__ __forceinline__ void split_pair(v2f v, unsigned& hi, unsigned& lo)
 {
-    const auto hp = __builtin_amdgcn_cvt_pkrtz(v.x, v.y);
-    const h2 hh = __builtin_bit_cast(h2, hp);
-    hi = __builtin_bit_cast(unsigned, hp);
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x - (float)hh.x, v.y - (float)hh.y));
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(v.x, v.y));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo) : "v"(v.x), "v"(v.y), "v"(hi));
 }
 
 #ifdef AWSEG_WS_STAMP
 // tools/probe_wino_stamps.hip: s_memtime stamps of block 0, wave 0: [slot A work, barrier A, slot B work, barrier B,
 // chunks, prologue, epilogue, whole block]
 __device__ unsigned long long g_ws_stamp[8];
+__device__ unsigned long long g_ws_stamp2[8];                      // slot A in detail: [wait, DMA issue, group 0, group 1, group 2]
 #define WS_T(var) const unsigned long long var = __builtin_readcyclecounter()
 #else
 #define WS_T(var)
@@ -128,18 +141,22 @@ void wino_split_kernel(ws_args a)
     const int n0 = ng * NB;
     const int nchunks = a.Cin / KC;
 
-    // ---- raw patch DMA: slot q = quad * QS + py * PW + px (16 bytes = 4 channels of one pixel); slots >= 4 * QS and the
-    // pad slot of each quad fetch out of range (zeros)
+    // ---- raw patch DMA, pixel-major: slot = 4 * g + quad (16 bytes = 4 channels), pixel group g = py * 18 + pos with the
+    // even columns of a patch row first (pos = px / 2 for even px, 9 + px / 2 for odd px): the four lanes of a group
+    // read 64 contiguous bytes of global memory (one request instead of four), and the eight tiles of a tile row — two
+    // pixels apart — sit in consecutive 64-byte records, which halves the bank conflicts of the transform's reads.
+    // Slots >= 4 * 324 fetch out of range (zeros).
     const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
     uint32_t pvoff[6];
 #pragma unroll
     for (int j = 0; j < 6; ++j) {
         const int q = (wave + 4 * j) * 64 + lane;
-        const int h = q / QS, r = q - h * QS;
-        const int py = r / PW, px = r - py * PW;
+        const int g = q >> 2, h = q & 3;
+        const int py = g / PW, pos = g - py * PW;
+        const int px = pos < PW / 2 ? 2 * pos : 2 * (pos - PW / 2) + 1;
         const int sy = by * 2 * TB - 1 + py, sx = bx * 2 * TB - 1 + px;
         const int y = ry + a.dil * sy, x = rx + a.dil * sx;
-        const bool ok = h < 4 && r < PW * PW && sy >= 0 && sx >= 0 && y < a.H && x < a.W;
+        const bool ok = g < NPIX && sy >= 0 && sx >= 0 && y < a.H && x < a.W;
         pvoff[j] = ok ? (uint32_t)(((y * a.W + x) * a.Cin + h * 4) * 4) : 0x80000000u;
     }
     const int n_pinstr = wave == 0 ? 6 : 5;                         // 21 instructions over 4 waves
@@ -154,7 +171,7 @@ void wino_split_kernel(ws_args a)
     // ---- transform role: tile xtile, channel quad xq (4 channels = two packed pairs)
     const int xtile = tid >> 2, xq = tid & 3;
     const int xty = xtile >> 3, xtx = xtile & 7;
-    const int prd = (xq * QS + 2 * xty * PW + 2 * xtx) * 16;        // patch byte offset of the tile's pixel (0,0), this quad
+    const int prd = (2 * xty * PW + xtx) * 64 + xq * 16;            // patch byte offset of the tile's pixel (0,0), this quad
     const int xsw = (xtile >> 2) & 3;
     const int vw_hi = xtile * 64 + (((xq >> 1) ^ xsw) * 16) + (xq & 1) * 8;          // hi chunk = quad >> 1 (channels 0-7 | 8-15)
     const int vw_lo = xtile * 64 + (((2 + (xq >> 1)) ^ xsw) * 16) + (xq & 1) * 8;
@@ -195,7 +212,7 @@ void wino_split_kernel(ws_args a)
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) r[i * 4 + j] = *reinterpret_cast<const v2f*>(pp + (i * PW + j) * 16);
+                for (int j = 0; j < 4; ++j) r[i * 4 + j] = *reinterpret_cast<const v2f*>(pp + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
             if (!SCALED) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(r[i].x)), __builtin_fabsf(r[i].y));
@@ -278,11 +295,13 @@ void wino_split_kernel(ws_args a)
         glds_patch(0, 0);
         glds_patch(1, 1);
         glds_patch(2, 2);
-        // U fragments are fetched TWO positions ahead of their MFMAs (ring of three register pairs): they come from L2 /
-        // the Infinity Cache (U does not fit one XCD's L2 for the wide layers), 500-900 cycles away
-        h8 ua_h, ua_l, ub_h, ub_l, uc_h, uc_l;
-        u_load(0, 0, ua_h, ua_l);
-        u_load(0, 1, ub_h, ub_l);
+        // U fragments are fetched THREE positions ahead of their MFMAs into a ring of four register pairs (8 positions per
+        // chunk: the ring phase is the same in every chunk).  The kernel is bound by what a CU can pull from L2 (U: 64 KB
+        // per chunk, patch: 21 KB; measured 12-14 B/clk/CU with two positions in flight): bytes in flight are what raises it.
+        h8 u0h, u0l, u1h, u1l, u2h, u2l, u3h, u3l;
+        u_load(0, 0, u0h, u0l);
+        u_load(0, 1, u1h, u1l);
+        u_load(0, 2, u2h, u2l);
         vm_wait_all();
         __syncthreads();                                             // (also orders sMax[0] = 0 / the previous pass's V reads)
         patch_rows(0, 0, tA);
@@ -292,90 +311,92 @@ void wino_split_kernel(ws_args a)
         __syncthreads();
 
         // ---- main loop: two slots per chunk ------------------------------------------------------------------------------
-        // positions 0..7 of chunk c use U registers a b c a b c a b; the loads issued during them fetch positions 2..7 of
-        // chunk c and 0, 1 of chunk c+1 into c a b c a b | c a ... -> the ring phase advances by 8 mod 3 = 2 per chunk, so
-        // the loop body is unrolled three times (phases 0, 2, 1)
-#define WS_CHUNK(c, U0h, U0l, U1h, U1l, U2h, U2l)                                                                 \
-        {                                                                                                        \
-            h8 vh0[2], vl0[2], vh1[2], vl1[2];                                                                   \
-            const int cn = (c) + 1 < nchunks ? (c) + 1 : (c);                                                    \
-            /* slot A: MFMAs on V rows {0, 2} of chunk c | rows {1, 3} of chunk c written, pair A of patch c+1 */ \
-            WS_T(st0);                                                                                           \
-            vm_wait_all();                                           /* the DMA issued a chunk ago (long landed) */ \
-            glds_patch((c) + 3, (c) % 3);                                                                        \
-            a_load(0, vh0, vl0);                                                                                 \
-            u_load(c, 2, U2h, U2l); a_load(1, vh1, vl1);                                                         \
-            cols_store(1);                                                                                       \
-            mfma6(0, vh0, vl0, U0h, U0l);                                                                        \
-            WS_MIX(11, 1, 2)                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            u_load(c, 3, U0h, U0l); a_load(2, vh0, vl0);                                                         \
-            cols_store(3);                                                                                       \
-            mfma6(1, vh1, vl1, U1h, U1l);                                                                        \
-            WS_MIX(11, 1, 2)                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            u_load(c, 4, U1h, U1l); a_load(3, vh1, vl1);                                                         \
-            mfma6(2, vh0, vl0, U2h, U2l);                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            u_load(c, 5, U2h, U2l);                                                                              \
-            patch_rows(((c) + 1) % 3, 0, tA);                                                                    \
-            mfma6(3, vh1, vl1, U0h, U0l);                                                                        \
-            WS_MIX(8, 3, 0)                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            WS_T(st1);                                                                                           \
-            __syncthreads();                                                                                     \
-            WS_T(st2);                                                                                           \
-            /* slot B: MFMAs on rows {1, 3} of chunk c | pair B of patch c+1, rows {0, 2} of chunk c+1 written */ \
-            a_load(4, vh0, vl0);                                                                                 \
-            u_load(c, 6, U0h, U0l); a_load(5, vh1, vl1);                                                         \
-            patch_rows(((c) + 1) % 3, 1, tB);                                                                    \
-            mfma6(4, vh0, vl0, U1h, U1l);                                                                        \
-            WS_MIX(8, 3, 0)                                                                                      \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            u_load(c, 7, U1h, U1l); a_load(6, vh0, vl0);                                                         \
-            cols_store(0);                                                                                       \
-            mfma6(5, vh1, vl1, U2h, U2l);                                                                        \
-            WS_MIX(11, 1, 2)                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            u_load(cn, 0, U2h, U2l); a_load(7, vh1, vl1);                                                        \
-            cols_store(2);                                                                                       \
-            mfma6(6, vh0, vl0, U0h, U0l);                                                                        \
-            WS_MIX(11, 1, 2)                                                                                     \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            u_load(cn, 1, U0h, U0l);                                                                             \
-            mfma6(7, vh1, vl1, U1h, U1l);                                                                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                   \
-            WS_T(st3);                                                                                           \
-            __syncthreads();                                                                                     \
-            WS_T(st4);                                                                                           \
-            WS_ACC(st0, st1, st2, st3, st4)                                                                      \
-        }
 #ifdef AWSEG_WS_STAMP
+        unsigned long long fa[5] = {0, 0, 0, 0, 0};
+#define WS_ACC2(t0, t1, t2, t3, t4, t5) { fa[0] += t1 - t0; fa[1] += t2 - t1; fa[2] += t3 - t2; fa[3] += t4 - t3; fa[4] += t5 - t4; }
         unsigned long long sa = 0, ba = 0, sb = 0, bb = 0, nn = 0;
 #define WS_ACC(t0, t1, t2, t3, t4) { sa += t1 - t0; ba += t2 - t1; sb += t3 - t2; bb += t4 - t3; nn += 1; }
 #else
+#define WS_ACC2(t0, t1, t2, t3, t4, t5)
 #define WS_ACC(t0, t1, t2, t3, t4)
 #endif
         WS_T(loop0);
-        int c = 0;
-        for (; c + 3 <= nchunks; c += 3) {
-            WS_CHUNK(c, ua_h, ua_l, ub_h, ub_l, uc_h, uc_l)
-            WS_CHUNK(c + 1, uc_h, uc_l, ua_h, ua_l, ub_h, ub_l)
-            WS_CHUNK(c + 2, ub_h, ub_l, uc_h, uc_l, ua_h, ua_l)
-        }
-        if (c < nchunks) {
-            WS_CHUNK(c, ua_h, ua_l, ub_h, ub_l, uc_h, uc_l)
-            if (c + 1 < nchunks) WS_CHUNK(c + 1, uc_h, uc_l, ua_h, ua_l, ub_h, ub_l)
+        for (int c = 0; c < nchunks; ++c) {
+            h8 vh0[2], vl0[2], vh1[2], vl1[2];
+            const int cn = c + 1 < nchunks ? c + 1 : c;              // chunk of the U prefetches behind position 4 (clamped)
+            // slot A: MFMAs on V rows {0, 2} of chunk c | rows {1, 3} of chunk c written, pair A of patch c+1 read and row-transformed
+            WS_T(st0);
+            vm_wait_keep6();                                         // the DMA issued a chunk ago (long landed)
+            WS_T(sa1);
+            glds_patch(c + 3, c % 3);                                // that ring slot held patch c (read a slot ago, behind a barrier)
+            WS_T(sa2);
+            a_load(0, vh0, vl0);
+            u_load(c, 3, u3h, u3l); a_load(1, vh1, vl1);
+            __builtin_amdgcn_sched_barrier(0);
+            cols_store(1);
+            mfma6(0, vh0, vl0, u0h, u0l);
+            WS_MIX(6, 0, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            WS_T(sa3);
+            u_load(c, 4, u0h, u0l); a_load(2, vh0, vl0);
+            __builtin_amdgcn_sched_barrier(0);
+            cols_store(3);
+            mfma6(1, vh1, vl1, u1h, u1l);
+            WS_MIX(6, 0, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            WS_T(sa4);
+            u_load(c, 5, u1h, u1l); a_load(3, vh1, vl1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma6(2, vh0, vl0, u2h, u2l);
+            __builtin_amdgcn_sched_barrier(0);
+            WS_T(sa5);
+            WS_ACC2(st0, sa1, sa2, sa3, sa4, sa5)
+            u_load(c, 6, u2h, u2l);
+            patch_rows((c + 1) % 3, 0, tA);
+            mfma6(3, vh1, vl1, u3h, u3l);
+            WS_MIX(6, 3, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            WS_T(st1);
+            __syncthreads();
+            WS_T(st2);
+            // slot B: MFMAs on rows {1, 3} of chunk c | pair B of patch c+1, rows {0, 2} of chunk c+1 written
+            a_load(4, vh0, vl0);
+            u_load(c, 7, u3h, u3l); a_load(5, vh1, vl1);
+            __builtin_amdgcn_sched_barrier(0);
+            patch_rows((c + 1) % 3, 1, tB);
+            mfma6(4, vh0, vl0, u0h, u0l);
+            WS_MIX(6, 3, 0)
+            __builtin_amdgcn_sched_barrier(0);
+            u_load(cn, 0, u0h, u0l); a_load(6, vh0, vl0);
+            __builtin_amdgcn_sched_barrier(0);
+            cols_store(0);
+            mfma6(5, vh1, vl1, u1h, u1l);
+            WS_MIX(6, 0, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            u_load(cn, 1, u1h, u1l); a_load(7, vh1, vl1);
+            __builtin_amdgcn_sched_barrier(0);
+            cols_store(2);
+            mfma6(6, vh0, vl0, u2h, u2l);
+            WS_MIX(6, 0, 2)
+            __builtin_amdgcn_sched_barrier(0);
+            u_load(cn, 2, u2h, u2l);
+            mfma6(7, vh1, vl1, u3h, u3l);
+            __builtin_amdgcn_sched_barrier(0);
+            WS_T(st3);
+            __syncthreads();
+            WS_T(st4);
+            WS_ACC(st0, st1, st2, st3, st4)
         }
         vm_wait_all();
 #ifdef AWSEG_WS_STAMP
         if (blockIdx.x == 0 && tid == 0) {
             g_ws_stamp[0] += sa; g_ws_stamp[1] += ba; g_ws_stamp[2] += sb; g_ws_stamp[3] += bb; g_ws_stamp[4] += nn;
             g_ws_stamp[5] += loop0 - blk0;
+            for (int i = 0; i < 5; ++i) g_ws_stamp2[i] += fa[i];
         }
 #endif
-#undef WS_CHUNK
 #undef WS_ACC
+#undef WS_ACC2
 #undef WS_MIX
     };
 
@@ -400,15 +421,21 @@ void wino_split_kernel(ws_args a)
     //   tmp[0][j] = M0j + M1j + M2j, tmp[1][j] = M1j - M2j - M3j;  Y[a][0] = tmp[a][0] + tmp[a][1] + tmp[a][2],
     //   Y[a][1] = tmp[a][1] - tmp[a][2] - tmp[a][3]
     float* xch = reinterpret_cast<float*>(sV);                        // [nt][dest ph][4 outputs][16 regs][64 lanes]
+    // (register by register: the whole-tile form keeps eight 16-register temporaries alive and spills — scratch loads in the
+    // epilogue cost the big depth-head launch, 8 chunks per block, a fifth of its time)
     auto partial = [&](int m, f32x16 (&yp)[4]) {
-        f32x16 t0[4], t1[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (ph == 0) { t0[j] = acc[j][m] + acc[4 + j][m]; t1[j] = acc[4 + j][m]; }
-            else { t0[j] = acc[j][m]; t1[j] = -acc[j][m] - acc[4 + j][m]; }
+        for (int r = 0; r < 16; ++r) {
+            float t0[4], t1[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float lo = acc[j][m][r], hi = acc[4 + j][m][r];
+                if (ph == 0) { t0[j] = lo + hi; t1[j] = hi; }
+                else { t0[j] = lo; t1[j] = -lo - hi; }
+            }
+            yp[0][r] = t0[0] + t0[1] + t0[2]; yp[1][r] = t0[1] - t0[2] - t0[3];
+            yp[2][r] = t1[0] + t1[1] + t1[2]; yp[3][r] = t1[1] - t1[2] - t1[3];
         }
-        yp[0] = t0[0] + t0[1] + t0[2]; yp[1] = t0[1] - t0[2] - t0[3];
-        yp[2] = t1[0] + t1[1] + t1[2]; yp[3] = t1[1] - t1[2] - t1[3];
     };
     f32x16 y[4];
     {

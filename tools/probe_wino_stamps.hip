@@ -24,16 +24,20 @@ static void run(int B, int H, int W, int cin, int cout, int dil, bool head)
     hipDeviceSynchronize();
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, r[8];
     hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamp), z, sizeof z);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_ws_stamp2), z, sizeof z);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, nullptr);
     int rc = awseg_conv3x3_winograd_split_nhwc(x, B, H, W, cin, cout, dil, u, sh, nullptr, 1, head ? w2 : nullptr, head ? b2 : nullptr, o, nullptr);
     hipEventRecord(e1, nullptr); hipDeviceSynchronize();
     float ms = 0; hipEventElapsedTime(&ms, e0, e1);
     hipMemcpyFromSymbol(r, HIP_SYMBOL(g_ws_stamp), sizeof r);
+    unsigned long long r2[8];
+    hipMemcpyFromSymbol(r2, HIP_SYMBOL(g_ws_stamp2), sizeof r2);
     const double n = (double)r[4];
     printf("%d x %dx%d  %d->%d d%d head=%d: rc %d, %.3f ms (stamped build); block 0 wave 0: %llu chunks\n", B, H, W, cin, cout, dil, (int)head, rc, ms, r[4]);
     printf("  per chunk (s_memtime ticks): slot A work %.0f | barrier A %.0f | slot B work %.0f | barrier B %.0f | total %.0f;  prologue %llu, whole block %llu\n",
            r[0] / n, r[1] / n, r[2] / n, r[3] / n, (r[0] + r[1] + r[2] + r[3]) / n, r[5], r[7]);
+    printf("  slot A in detail: vmcnt wait %.0f | DMA issue %.0f | position group 0 %.0f | group 1 %.0f | group 2 %.0f\n", r2[0] / n, r2[1] / n, r2[2] / n, r2[3] / n, r2[4] / n);
     hipFree(x); hipFree(o); hipFree(sh); hipFree(w2); hipFree(b2); hipFree(u);
 }
 

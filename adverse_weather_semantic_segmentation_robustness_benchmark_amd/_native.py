@@ -48,6 +48,10 @@ SIGNATURES = {
     "awseg_gemm_tune": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i64, c_i, c_i, c_p, C.c_size_t, c_p]),
     "awseg_gemm_split_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "awseg_gemm_split_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
+    "awseg_gemm_bf16_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    "awseg_gemm_bf16_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
+    "awseg_conv3x3_winograd_bf16_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "awseg_attention_d32_bf16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "awseg_dwconv3x3_upcat_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_winograd_split_weight_halfs": (c_i64, [c_i, c_i]),
     "awseg_conv3x3_winograd_split_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),

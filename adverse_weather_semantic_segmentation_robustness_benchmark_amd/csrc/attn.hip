@@ -224,8 +224,26 @@ __device__ __forceinline__ float amax4(float m, const float4& t)
     return __builtin_fmaxf(__builtin_fmaxf(m, __builtin_fabsf(t.z)), __builtin_fabsf(t.w));
 }
 
-// returns true (block-uniform) when the optimistic pass met an out-of-range operand and stored nothing
-template <bool SCALED>
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
+}
+__device__ __forceinline__ h8 pack8_bf16(const float* x)
+{
+    u32x4 H;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) H[i] = pack_bf16(x[2 * i], x[2 * i + 1]);
+    return __builtin_bit_cast(h8, H);
+}
+#define MFMA_BF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, A), __builtin_bit_cast(bf8, B), C, 0, 0, 0)
+
+// returns true (block-uniform) when the optimistic pass met an out-of-range operand and stored nothing.
+// BF16: ONE bf16 MFMA per product tile (q, k, v and the probabilities rounded to bf16, float32 accumulation and softmax):
+// BASELINE config 5's bf16 MFMA path; no range guard (bf16 has float32's exponent range).
+template <bool SCALED, bool BF16 = false>
 __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                                 float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e,
                                                 _Float16 (*sK)[TK * SROW], _Float16 (*sV)[D * SROW], unsigned* sMax, const attn_scales sc)
@@ -250,6 +268,7 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
             const float4 a4 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * hk);
             const float4 b4 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * hk + 4);
             const float x[8] = { a4.x * qs, a4.y * qs, a4.z * qs, a4.w * qs, b4.x * qs, b4.y * qs, b4.z * qs, b4.w * qs };
+            if (BF16) { qh[s] = pack8_bf16(x); continue; }
             if (!SCALED) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) qmax = __builtin_fmaxf(qmax, __builtin_fabsf(x[i]));
@@ -263,6 +282,16 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
     const int wk0 = lkey * SROW + 4 * lc;
     const int wv0 = (4 * lc) * SROW + pv_slot(lkey);
     auto stage = [&](int buf, float4 kk4, float4 vv4) {
+        if (BF16) {
+            u32x2 H;
+            H[0] = pack_bf16(kk4.x, kk4.y); H[1] = pack_bf16(kk4.z, kk4.w);
+            *reinterpret_cast<u32x2*>(&sK[buf][wk0]) = H;
+            const unsigned v01 = pack_bf16(vv4.x, vv4.y), v23 = pack_bf16(vv4.z, vv4.w);
+            unsigned short* svb = reinterpret_cast<unsigned short*>(&sV[buf][wv0]);
+            svb[0] = (unsigned short)v01; svb[SROW] = (unsigned short)(v01 >> 16);
+            svb[2 * SROW] = (unsigned short)v23; svb[3 * SROW] = (unsigned short)(v23 >> 16);
+            return;
+        }
         if (SCALED) {
             kk4.x *= sc.sk; kk4.y *= sc.sk; kk4.z *= sc.sk; kk4.w *= sc.sk;
             vv4.x *= sc.sv; vv4.y *= sc.sv; vv4.z *= sc.sv; vv4.w *= sc.sv;
@@ -305,12 +334,17 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
         f32x16 sm, scx;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { sm[r] = 0.f; scx[r] = 0.f; }
-        sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], sm, 0, 0, 0);
-        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], scx, 0, 0, 0);
-        sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], sm, 0, 0, 0);
-        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], scx, 0, 0, 0);
-        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], scx, 0, 0, 0);
-        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], scx, 0, 0, 0);
+        if (BF16) {
+            sm = MFMA_BF(kh0, qh[0], sm);
+            sm = MFMA_BF(kh1, qh[1], sm);
+        } else {
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], sm, 0, 0, 0);
+            scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], scx, 0, 0, 0);
+            sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], sm, 0, 0, 0);
+            scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], scx, 0, 0, 0);
+            scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], scx, 0, 0, 0);
+            scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], scx, 0, 0, 0);
+        }
         const h8* vr = reinterpret_cast<const h8*>(&sV[buf][a_off]);
         const h8 vh0 = vr[0], vh1 = vr[2], vl0 = vr[4], vl1 = vr[6];
         // ---- online softmax, one query per lane
@@ -341,6 +375,19 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
         // The probabilities are pre-scaled to (0, 2^15], so their low parts need no scaling: p - f16(p) is a normal f16
         // for p >= 2^-3 and below that a subnormal worth < 2^-40 of the row maximum (the f16 matrix cores keep
         // subnormals) -> V_hi P_lo goes to the main accumulator, only V_lo' P_hi to the scaled correction.
+        if (BF16) {
+            om = MFMA_BF(vh0, pack8_bf16(p), om);
+            om = MFMA_BF(vh1, pack8_bf16(p + 8), om);
+            if (t + 1 < ntiles) {
+                stage(buf ^ 1, kreg, vreg);
+                if (t + 2 < ntiles) {
+                    kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * C + g_off);
+                    vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * C + g_off);
+                }
+            }
+            __syncthreads();
+            continue;
+        }
         h8 ph0, pl0, ph1, pl1;
         split8_unscaled(p, ph0, pl0);
         split8_unscaled(p + 8, ph1, pl1);
@@ -360,7 +407,7 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
         __syncthreads();
     }
 
-    if (!SCALED) {
+    if (!SCALED && !BF16) {
         // report (rare, divergent) -> barrier -> block-uniform verdict
         if (qmax >= kSplitLimit) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, qmax));
         if (kmax >= kSplitLimit) atomicMax(&sMax[1], __builtin_bit_cast(unsigned, kmax));
@@ -407,6 +454,17 @@ void attention_d32_split_kernel(const float* __restrict__ q, const float* __rest
     attn_split_pass<true>(q, k, v, out, nq, nkv, heads, scale_log2e, sK, sV, sMax, sc);
 }
 
+__global__ __launch_bounds__(AT, 2)
+void attention_d32_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
+                               float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sK[2][TK * SROW];
+    __shared__ __attribute__((aligned(16))) _Float16 sV[2][D * SROW];
+    __shared__ unsigned sMax[3];
+    const attn_scales one = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+    attn_split_pass<false, true>(q, k, v, out, nq, nkv, heads, scale_log2e, sK, sV, sMax, one);
+}
+
 }  // namespace
 
 namespace {
@@ -437,4 +495,10 @@ AWSEG_API int awseg_attention_d32_split(const float* q, const float* k, const fl
                                         int n_queries, int n_keys, float scale, awseg_stream_t stream)
 {
     return launch_attention(attention_d32_split_kernel, q, k, v, out, batch, heads, n_queries, n_keys, scale, stream);
+}
+
+AWSEG_API int awseg_attention_d32_bf16(const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                                       int n_queries, int n_keys, float scale, awseg_stream_t stream)
+{
+    return launch_attention(attention_d32_bf16_kernel, q, k, v, out, batch, heads, n_queries, n_keys, scale, stream);
 }

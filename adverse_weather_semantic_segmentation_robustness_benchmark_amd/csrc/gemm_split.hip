@@ -114,7 +114,21 @@ __device__ __forceinline__ constexpr int acc_row(int r, int hk) { return (r & 3)
 //   <1, 2, 4, 2>: 128 x 128, 64 accumulator registers per lane, four waves per SIMD, two blocks per CU
 //   <2, 2, 2, 4>: 128 x 256, 128 accumulator registers, two waves per SIMD, one block per CU: 25 % fewer operand bytes
 //                 fetched per multiply-add (the measured limit) for the shapes with N >= 256
-template <int MT, int NT, int WM, int WN, bool KTAIL>
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+
+// float32 pair -> packed bf16 (round to nearest even: v_cvt_pk_bf16_f32)
+__device__ __forceinline__ unsigned pack_bf16(float a, float b)
+{
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f2{a, b}, bf2));
+}
+
+// BF16 = true: the same kernel with ONE v_mfma_f32_32x32x16_bf16 per product tile (BASELINE config 5: the bf16 MFMA
+// path): activations are rounded to bf16 when they are staged, weights come as one bf16 plane (awseg_gemm_bf16_weights
+// writes it where the split form keeps its high parts), float32 accumulation and epilogue.  bf16 has float32's exponent
+// range: no range guard, no second pass.
+template <int MT, int NT, int WM, int WN, bool KTAIL, bool BF16>
 __global__ __launch_bounds__(GT, (MT * NT <= 2 ? 4 : 2))
 void gemm_split_kernel(gemm_args a)
 {
@@ -122,6 +136,7 @@ void gemm_split_kernel(gemm_args a)
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int NA = BM / 64;                                  // float4 of x per thread per K tile
     constexpr int NB = BN / 64;                                  // 16-byte chunks of w per thread per K tile (hi and lo)
+    constexpr int NBL = BF16 ? NB / 2 : NB;                      // ... of which the bf16 form loads the first plane only
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * GROW];
     __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * GROW];
     __shared__ unsigned sMax[2];                                 // max|x| bits seen by the block in a pass (if >= 2^15), by pass parity
@@ -174,6 +189,7 @@ void gemm_split_kernel(gemm_args a)
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
+            if (BF16 && (i & 1)) continue;                       // no low plane
             if (KTAIL && k0 + 8 * (tid & 3) >= K) breg[i] = u32x4{0u, 0u, 0u, 0u};
             else breg[i] = *reinterpret_cast<const u32x4*>(((i & 1) == 0 ? whb : wlb) + boff[i >> 1] + k0);
         }
@@ -183,17 +199,25 @@ void gemm_split_kernel(gemm_args a)
         for (int i = 0; i < NA; ++i) {
             u32x2 H, L; unsigned hh, ll;
             float4 v = areg[i];
+            _Float16* d = &sA[buf][(ar + 64 * i) * GROW + 4 * ac];
+            if (BF16) {
+                H[0] = pack_bf16(v.x, v.y); H[1] = pack_bf16(v.z, v.w);
+                *reinterpret_cast<u32x2*>(d) = H;
+                continue;
+            }
             if (scaled) { v.x *= sx; v.y *= sx; v.z *= sx; v.w *= sx; }       // block-uniform branch
             amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));   // v_max3_f32 with |.| modifiers
             amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
             split_pair(v.x, v.y, hh, ll); H[0] = hh; L[0] = ll;
             split_pair(v.z, v.w, hh, ll); H[1] = hh; L[1] = ll;
-            _Float16* d = &sA[buf][(ar + 64 * i) * GROW + 4 * ac];
             *reinterpret_cast<u32x2*>(d) = H;
             *reinterpret_cast<u32x2*>(d + 32) = L;
         }
 #pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<u32x4*>(&sB[buf][bdst0 + (i >> 1) * 128 * GROW + 32 * (i & 1)]) = breg[i];
+        for (int i = 0; i < NB; ++i) {
+            if (BF16 && (i & 1)) continue;
+            *reinterpret_cast<u32x4*>(&sB[buf][bdst0 + (i >> 1) * 128 * GROW + 32 * (i & 1)]) = breg[i];
+        }
     };
 
     const int nkt = (K + GKT - 1) / GKT;
@@ -256,7 +280,7 @@ void gemm_split_kernel(gemm_args a)
             // — its readers (previous pass) are behind this pass's first barrier, its writers (next pass) behind this
             // pass's last one.  Last K tile: everything this thread will stage in this pass has been staged; report.
             if (t == 0 && tid == 0) sMax[par ^ 1] = 0u;
-            if (t == nkt - 1 && !scaled && amax >= kSplitLimit) atomicMax(&sMax[par], __builtin_bit_cast(unsigned, amax));
+            if (!BF16 && t == nkt - 1 && !scaled && amax >= kSplitLimit) atomicMax(&sMax[par], __builtin_bit_cast(unsigned, amax));
             if (t + 1 < nkt) {
                 if (t + 2 < nkt) fetch((t + 2) * GKT);
                 else if (has_next) { point(nm0, nn0); fetch(0); }
@@ -271,17 +295,23 @@ void gemm_split_kernel(gemm_args a)
 #pragma unroll
                 for (int i = 0; i < MT; ++i) {
                     const _Float16* pa = &sA[buf][fa + i * 32 * GROW + 16 * ks];
-                    Ah[i] = *reinterpret_cast<const h8*>(pa); Al[i] = *reinterpret_cast<const h8*>(pa + 32);
+                    Ah[i] = *reinterpret_cast<const h8*>(pa);
+                    if (!BF16) Al[i] = *reinterpret_cast<const h8*>(pa + 32);
                 }
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     const _Float16* pb = &sB[buf][fb + j * 32 * GROW + 16 * ks];
-                    Bh[j] = *reinterpret_cast<const h8*>(pb); Bl[j] = *reinterpret_cast<const h8*>(pb + 32);
+                    Bh[j] = *reinterpret_cast<const h8*>(pb);
+                    if (!BF16) Bl[j] = *reinterpret_cast<const h8*>(pb + 32);
                 }
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
 #pragma unroll
                     for (int j = 0; j < NT; ++j) {
+                        if (BF16) {
+                            am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, Ah[i]), __builtin_bit_cast(bf8, Bh[j]), am[i][j], 0, 0, 0);
+                            continue;
+                        }
                         am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bh[j], am[i][j], 0, 0, 0);
                         ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bl[j], ac2[i][j], 0, 0, 0);
                         ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i], Bh[j], ac2[i][j], 0, 0, 0);
@@ -305,7 +335,7 @@ void gemm_split_kernel(gemm_args a)
 
         // ---- range guard: some activation of this tile was too large for the optimistic split -> second pass, scaled
         {
-            const unsigned mx = sMax[par];                       // written before the K loop's last barrier; block-uniform
+            const unsigned mx = BF16 ? 0u : sMax[par];           // written before the K loop's last barrier; block-uniform
             par ^= 1;
             if (mx != 0u && !scaled) {
                 const int ex = (int)(mx >> 23) & 0xff;
@@ -401,8 +431,9 @@ AWSEG_API int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w
     return 0;
 }
 
-AWSEG_API int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split, const float* bias, const float* residual,
-                                        int act, float* out, int64_t m, int n, int k, awseg_stream_t stream)
+namespace {
+int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float* bias, const float* residual,
+                int act, float* out, int64_t m, int n, int k, awseg_stream_t stream)
 {
     if (m == 0 || n == 0) return 0;
     if (!x || !w_split || !out || m < 0 || n < 0 || k < 8 || act < 0 || act > 1) return AWSEG_EINVAL;
@@ -433,13 +464,54 @@ AWSEG_API int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split,
     if (blocks < 8) blocks = 8;
     if (blocks > slots) blocks = slots;                          // slots is a multiple of 8
     const dim3 grid((unsigned)blocks), block(GT);
-    if (wide) {
-        if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, 4, true>), grid, block, 0, awseg_s(stream), a);
-        else hipLaunchKernelGGL((gemm_split_kernel<2, 2, 2, 4, false>), grid, block, 0, awseg_s(stream), a);
-    } else {
-        if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<1, 2, 4, 2, true>), grid, block, 0, awseg_s(stream), a);
-        else hipLaunchKernelGGL((gemm_split_kernel<1, 2, 4, 2, false>), grid, block, 0, awseg_s(stream), a);
-    }
+#define GEMM_GO(MT_, NT_, WM_, WN_)                                                                                    \
+    do {                                                                                                              \
+        if (bf16) {                                                                                                   \
+            if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<MT_, NT_, WM_, WN_, true, true>), grid, block, 0, awseg_s(stream), a);   \
+            else hipLaunchKernelGGL((gemm_split_kernel<MT_, NT_, WM_, WN_, false, true>), grid, block, 0, awseg_s(stream), a);         \
+        } else {                                                                                                      \
+            if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<MT_, NT_, WM_, WN_, true, false>), grid, block, 0, awseg_s(stream), a);  \
+            else hipLaunchKernelGGL((gemm_split_kernel<MT_, NT_, WM_, WN_, false, false>), grid, block, 0, awseg_s(stream), a);        \
+        }                                                                                                             \
+    } while (0)
+    if (wide) GEMM_GO(2, 2, 2, 4); else GEMM_GO(1, 2, 4, 2);
+#undef GEMM_GO
     AWSEG_LAUNCH_CHECK();
     return 0;
+}
+
+__global__ __launch_bounds__(SWT)
+void bf16_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_t* __restrict__ out, unsigned* __restrict__ trailer)
+{
+    if (blockIdx.x == 0 && threadIdx.x == 0) { trailer[0] = 0u; trailer[1] = 0u; trailer[2] = 0u; trailer[3] = 0u; }   // exponent 0
+    const int64_t i = ((int64_t)blockIdx.x * SWT + threadIdx.x) * 2;
+    if (i >= n_elems) return;
+    const unsigned p = pack_bf16(w[i], (i + 1 < n_elems) ? w[i + 1] : 0.f);
+    out[i] = (uint16_t)p;
+    if (i + 1 < n_elems) out[i + 1] = (uint16_t)(p >> 16);
+}
+}  // namespace
+
+AWSEG_API int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split, const float* bias, const float* residual,
+                                        int act, float* out, int64_t m, int n, int k, awseg_stream_t stream)
+{
+    return gemm_launch(false, x, w_split, bias, residual, act, out, m, n, k, stream);
+}
+
+AWSEG_API int awseg_gemm_bf16_weights(const float* w, int n, int k, uint16_t* w_bf16, awseg_stream_t stream)
+{
+    if (n == 0 || k == 0) return 0;
+    if (!w || !w_bf16 || n < 0 || k < 0) return AWSEG_EINVAL;
+    const int64_t ne = (int64_t)n * k;
+    unsigned* trailer = reinterpret_cast<unsigned*>(w_bf16 + 2 * ne);
+    if ((uintptr_t)trailer & 3) return AWSEG_EALIGN;
+    hipLaunchKernelGGL(bf16_weights_kernel, dim3((unsigned)((ne / 2 + SWT) / SWT)), dim3(SWT), 0, awseg_s(stream), w, ne, w_bf16, trailer);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_gemm_bf16_bias_act(const float* x, const uint16_t* w_bf16, const float* bias, const float* residual,
+                                       int act, float* out, int64_t m, int n, int k, awseg_stream_t stream)
+{
+    return gemm_launch(true, x, w_bf16, bias, residual, act, out, m, n, k, stream);
 }

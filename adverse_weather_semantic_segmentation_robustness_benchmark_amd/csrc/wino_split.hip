@@ -117,7 +117,19 @@ struct awseg_true { static constexpr bool value = true; };
 
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }   // -126 <= e <= 127
 
-template <int MODE>   // 0 FULL (NHWC map out), 1 HEAD1 (fused 1x1 + sigmoid, Cout == 64)
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned pack_bf16(v2f v)
+{
+    typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf2));
+}
+
+// MODE: 0 FULL (NHWC map out), 1 HEAD1 (fused 1x1 + sigmoid, Cout == 64).
+// BF16: the same kernel with ONE v_mfma_f32_32x32x16_bf16 per product tile (BASELINE config 5, the bf16 MFMA path): V is
+// rounded to bf16 after the float32 input transform, U comes as bf16 in the "high part" slots of the same image (the low
+// slots are neither stored nor fetched: half the U traffic), float32 accumulation, transforms and epilogue.  bf16 has
+// float32's exponent range: no range guard.
+template <int MODE, bool BF16>
 __global__ __launch_bounds__(WT, 1)
 void wino_split_kernel(ws_args a)
 {
@@ -213,7 +225,8 @@ void wino_split_kernel(ws_args a)
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) r[i * 4 + j] = *reinterpret_cast<const v2f*>(pp + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
-            if (!SCALED) {
+            if (BF16) {
+            } else if (!SCALED) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(r[i].x)), __builtin_fabsf(r[i].y));
             } else {
@@ -238,6 +251,11 @@ void wino_split_kernel(ws_args a)
                 else if (j == 2) { va = pk_sub(tA[i * 4 + 2], tA[i * 4 + 1]); vb = pk_sub(tB[i * 4 + 2], tB[i * 4 + 1]); }
                 else { va = pk_sub(tA[i * 4 + 1], tA[i * 4 + 3]); vb = pk_sub(tB[i * 4 + 1], tB[i * 4 + 3]); }
                 u32x2 H, L; unsigned h, l;
+                if (BF16) {
+                    H[0] = pack_bf16(va); H[1] = pack_bf16(vb);
+                    *reinterpret_cast<u32x2*>(sV + (i * 4 + j) * V_POS + vw_hi) = H;
+                    continue;
+                }
                 split_pair(va, h, l); H[0] = h; L[0] = l;
                 split_pair(vb, h, l); H[1] = h; L[1] = l;
                 *reinterpret_cast<u32x2*>(sV + (i * 4 + j) * V_POS + vw_hi) = H;
@@ -248,21 +266,24 @@ void wino_split_kernel(ws_args a)
         auto u_load = [&](int c, int lp, h8& uh, h8& ul) {
             const uint32_t so = (uint32_t)c * u_c + u_w + (uint32_t)lp * u_p;
             uh = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane, so, 0));
-            ul = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane + 1024u, so, 0));
+            if (!BF16) ul = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane + 1024u, so, 0));
         };
         auto a_load = [&](int lp, h8 (&vh)[2], h8 (&vl)[2]) {
             const unsigned char* vp = sV + (8 * ph + lp) * V_POS;
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 vh[m] = *reinterpret_cast<const h8*>(vp + a_hi[m]);
-                vl[m] = *reinterpret_cast<const h8*>(vp + a_lo[m]);
+                if (!BF16) vl[m] = *reinterpret_cast<const h8*>(vp + a_lo[m]);
             }
         };
         auto mfma6 = [&](int lp, const h8 (&vh)[2], const h8 (&vl)[2], const h8& uh, const h8& ul) {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 f32x16 z = acc[lp][m];
-                if (MODE == 1) {                                     // couts on the accumulator rows (in-register sum over couts)
+                if (BF16) {
+                    if (MODE == 1) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, uh), __builtin_bit_cast(bf8, vh[m]), z, 0, 0, 0);
+                    else z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, vh[m]), __builtin_bit_cast(bf8, uh), z, 0, 0, 0);
+                } else if (MODE == 1) {                              // couts on the accumulator rows (in-register sum over couts)
                     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vh[m], z, 0, 0, 0);
                     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul, vh[m], z, 0, 0, 0);
                     z = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh, vl[m], z, 0, 0, 0);
@@ -401,7 +422,7 @@ void wino_split_kernel(ws_args a)
     };
 
     run(awseg_false{});
-    {
+    if (!BF16) {
         // ---- range guard: one more pass with scaled activations? --------------------------------------------------------
         if (amax > 0.f) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, amax));
         __syncthreads();
@@ -524,10 +545,10 @@ void wino_split_kernel(ws_args a)
 #endif
 }
 
-template <int MODE>
+template <int MODE, bool BF16>
 int launch_ws(const ws_args& a, hipStream_t s)
 {
-    auto kern = wino_split_kernel<MODE>;
+    auto kern = wino_split_kernel<MODE, BF16>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     if (e != hipSuccess) return (int)e;
     const int64_t tiles = (int64_t)a.nbx * a.dil * a.nby * a.dil * a.batch;
@@ -546,9 +567,10 @@ AWSEG_API int64_t awseg_winograd_split_weight_halfs(int cin, int cout)
     return (int64_t)16 * cin * cout * 2;                             // 16 positions x (hi + lo)
 }
 
-AWSEG_API int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
-                                                const uint16_t* u_split, const float* shift, const float* residual, int act,
-                                                const float* w2, const float* b2, float* out, awseg_stream_t stream)
+namespace {
+int ws_entry(bool bf16, const float* x, int batch, int height, int width, int cin, int cout, int dilation,
+             const uint16_t* u_split, const float* shift, const float* residual, int act,
+             const float* w2, const float* b2, float* out, awseg_stream_t stream)
 {
     if (batch == 0) return 0;
     if (!x || !u_split || !shift || !out || batch < 0 || height < 1 || width < 1 || dilation < 1) return AWSEG_EINVAL;
@@ -565,5 +587,21 @@ AWSEG_API int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int h
     const int hs = (height + dilation - 1) / dilation, ws = (width + dilation - 1) / dilation;
     a.nbx = (ws + 2 * TB - 1) / (2 * TB); a.nby = (hs + 2 * TB - 1) / (2 * TB); a.ngroups = cout / NB; a.batch = batch;
     a.u_halfs = (int64_t)16 * cin * cout * 2;
-    return w2 ? launch_ws<1>(a, awseg_s(stream)) : launch_ws<0>(a, awseg_s(stream));
+    if (bf16) return w2 ? launch_ws<1, true>(a, awseg_s(stream)) : launch_ws<0, true>(a, awseg_s(stream));
+    return w2 ? launch_ws<1, false>(a, awseg_s(stream)) : launch_ws<0, false>(a, awseg_s(stream));
+}
+}  // namespace
+
+AWSEG_API int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
+                                                const uint16_t* u_split, const float* shift, const float* residual, int act,
+                                                const float* w2, const float* b2, float* out, awseg_stream_t stream)
+{
+    return ws_entry(false, x, batch, height, width, cin, cout, dilation, u_split, shift, residual, act, w2, b2, out, stream);
+}
+
+AWSEG_API int awseg_conv3x3_winograd_bf16_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
+                                               const uint16_t* u_bf16, const float* shift, const float* residual, int act,
+                                               const float* w2, const float* b2, float* out, awseg_stream_t stream)
+{
+    return ws_entry(true, x, batch, height, width, cin, cout, dilation, u_bf16, shift, residual, act, w2, b2, out, stream);
 }

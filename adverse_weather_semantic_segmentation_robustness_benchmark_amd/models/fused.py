@@ -47,8 +47,9 @@ def folded_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):
     conv._awseg_fold = (key, w, shift.contiguous())
     # everything derived from the folded weights dies with them: the split-operand image is keyed on the folded tensor's
     # (address, version), and a re-folded tensor can land on the same address with the same version
-    if hasattr(conv, "_awseg_wsplit"):
-        del conv._awseg_wsplit
+    for dep in ("_awseg_wsplit", "_awseg_wbf16"):
+        if hasattr(conv, dep):
+            delattr(conv, dep)
     return w, shift.contiguous()
 
 
@@ -59,13 +60,22 @@ def cached(module: nn.Module, name: str, tensors, fn):
         return cache[1]
     val = fn()
     setattr(module, "_awseg_" + name, (key, val))
-    if name != "wsplit" and hasattr(module, "_awseg_wsplit"):
-        del module._awseg_wsplit                  # split-operand images are keyed on the tensor just replaced
+    if name not in ("wsplit", "wbf16"):
+        for dep in ("_awseg_wsplit", "_awseg_wbf16"):
+            if hasattr(module, dep):
+                delattr(module, dep)              # operand images are keyed on the tensor just replaced
     return val
 
 
 def split_weights(owner: nn.Module, w2: torch.Tensor, m: int):
-    """gemm_split_weights(w2) cached on `owner` (None when the problem stays on the library GEMM)."""
+    """The GEMM's prepared weight image cached on `owner`: gemm_bf16_weights(w2) in bf16 mode, gemm_split_weights(w2) for
+    the split-operand kernel, None when the problem stays on the library GEMM."""
+    if ops.gemm_wants_bf16(m, w2.shape[0], w2.shape[1]):
+        def build():
+            wb = ops.gemm_bf16_weights(w2)
+            wb._awseg_bf16 = True
+            return wb
+        return cached(owner, "wbf16", (w2,), build)
     if not ops.gemm_wants_split(m, w2.shape[0], w2.shape[1]):
         return None
     return cached(owner, "wsplit", (w2,), lambda: ops.gemm_split_weights(w2))
@@ -121,6 +131,16 @@ def conv3x3_winograd_bn(x_nhwc: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2
                         w2: torch.Tensor = None, b2: torch.Tensor = None) -> torch.Tensor:
     """act(bn(conv3x3(x)) [+ residual]) (or the fused 1x1 + sigmoid head) on a contiguous NHWC tensor: the split-operand
     f16-MFMA Winograd kernel, or the float32-input MFMA one (ops.WINO_SPLIT)."""
+    if ops.PRECISION == "bf16":
+        def build():
+            inv = torch.rsqrt(bn.running_var + bn.eps)
+            scale = bn.weight * inv
+            shift = bn.bias - bn.running_mean * scale
+            if conv.bias is not None:
+                shift = shift + conv.bias * scale
+            return ops.winograd_bf16_weights(conv.weight, scale), shift.contiguous()
+        ub, shift = cached(conv, "wino_bf16", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+        return ops.conv3x3_winograd_bf16(x_nhwc, ub, conv.out_channels, shift, act=act, dilation=conv.dilation[0], residual=residual, w2=w2, b2=b2)
     if ops.WINO_SPLIT:
         us, shift = winograd_split_conv_bn(conv, bn)
         return ops.conv3x3_winograd_split(x_nhwc, us, conv.out_channels, shift, act=act, dilation=conv.dilation[0], residual=residual, w2=w2, b2=b2)
@@ -262,6 +282,16 @@ def _ln(t, ln: nn.LayerNorm):
     return F.layer_norm(t, (c,), ln.weight, ln.bias, ln.eps)
 
 
+def _linear(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
+    """lin(x) on the last dimension: torch's float32 GEMM, or — in bf16 mode — this repo's GEMM kernel on bf16 MFMA."""
+    k = x.shape[-1]
+    m = x.numel() // k
+    if lin.bias is not None and x.is_contiguous() and ops.gemm_wants_bf16(m, lin.out_features, k):
+        y = ops.gemm_bias_act(x.view(m, k), lin.weight, lin.bias, N.ACT_NONE, w_split=split_weights(lin, lin.weight, m))
+        return y.view(*x.shape[:-1], lin.out_features)
+    return F.linear(x, lin.weight, lin.bias)
+
+
 def _linear_residual(x2: torch.Tensor, lin: nn.Linear, tok: torch.Tensor) -> torch.Tensor:
     """tok + lin(x2) for NHWC tokens [B,H,W,C], written over tok (which the caller owns and drops)."""
     if lin.bias is None or not tok.is_contiguous():
@@ -293,7 +323,7 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
         for blk in st.blocks:
             a = blk.attention
             hcur = _ln(tok, blk.layernorm_before)
-            q = F.linear(hcur, a.q_proj.weight, a.q_proj.bias)
+            q = _linear(hcur, a.q_proj)
             if a.sequence_reduction_ratio > 1:
                 sr = a.sequence_reduction
                 src = sr.sequence_reduction
@@ -306,21 +336,25 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
                 kv = _ln(kv, sr.layer_norm)
             else:
                 kv = hcur
-            k = F.linear(kv, a.k_proj.weight, a.k_proj.bias)
-            v = F.linear(kv, a.v_proj.weight, a.v_proj.bias)
+            k = _linear(kv, a.k_proj)
+            v = _linear(kv, a.v_proj)
             nh, d = a.num_attention_heads, a.head_dim
             nkv = kv.shape[1] * kv.shape[2]
             if d == 32 and nkv % 32 == 0:
                 # exact-fp32 flash attention on the matrix cores, token-major in and out (no head transposes)
                 o = ops.attention_d32(q.view(B, H * W, C), k.reshape(B, nkv, C), v.reshape(B, nkv, C), nh, a.scaling).view(B * H * W, C)
             else:
-                o = F.scaled_dot_product_attention(q.view(B, H * W, nh, d).transpose(1, 2), k.reshape(B, -1, nh, d).transpose(1, 2),
-                                                   v.reshape(B, -1, nh, d).transpose(1, 2), scale=a.scaling)
+                # other head widths (MiT-B1..B5: 64): torch's fused attention; in bf16 mode on bf16 operands (bf16 MFMA path)
+                qq, kk, vv = (t_.view(B, -1, nh, d).transpose(1, 2) for t_ in (q.view(B, H * W, C), k.reshape(B, -1, C), v.reshape(B, -1, C)))
+                if ops.PRECISION == "bf16":
+                    o = F.scaled_dot_product_attention(qq.bfloat16(), kk.bfloat16(), vv.bfloat16(), scale=a.scaling).float()
+                else:
+                    o = F.scaled_dot_product_attention(qq, kk, vv, scale=a.scaling)
                 o = o.transpose(1, 2).reshape(B * H * W, C)
             # tok + o_proj(o): the residual is the GEMM's beta*C operand, accumulated over tok's buffer
             tok = _linear_residual(o, a.o_proj, tok)
             m = blk.mlp
-            hcur = F.linear(_ln(tok, blk.layernorm_after), m.fc1.weight, m.fc1.bias)
+            hcur = _linear(_ln(tok, blk.layernorm_after), m.fc1)
             if getattr(seg.config, "hidden_act", "gelu") == "gelu":
                 hcur = ops.dwconv3x3_nhwc(hcur, dw_taps(m.dwconv.dwconv), m.dwconv.dwconv.bias, N.ACT_GELU)   # dwconv + GELU fused
             else:

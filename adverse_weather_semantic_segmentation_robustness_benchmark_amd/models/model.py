@@ -165,8 +165,9 @@ class SegFormerModel(nn.Module):
     """PKG/models/model.py:81-223."""
 
     def __init__(self, model_name: str = "nvidia/segformer-b0-finetuned-ade-512-512", num_classes: int = 19,
-                 include_depth: bool = True, pretrained: bool = True) -> None:
+                 include_depth: bool = True, pretrained: bool = True, *, compute_dtype: Optional[str] = None) -> None:
         super().__init__()
+        self.compute_dtype = compute_dtype          # None / "f32": float32-grade; "bf16": bf16 MFMA contractions (eval path)
         self.num_classes = num_classes
         self.include_depth = include_depth
         self.segformer = _build_mit(model_name, pretrained)
@@ -202,7 +203,7 @@ class SegFormerModel(nn.Module):
         if _use_hip(self, x):
             if not x.is_cuda:
                 raise N.AwsegError("eval-mode forward runs HIP kernels: it needs CUDA (HIP) tensors; no CPU fallback exists")
-            with torch.no_grad():
+            with torch.no_grad(), ops.precision(self.compute_dtype):
                 return self._forward_hip(fused.mit_features_nhwc(self.segformer, x), H, W)
         feats = self.encode(x)
         up = F.interpolate(feats, size=(H, W), mode="bilinear", align_corners=False)     # model.py:211
@@ -228,8 +229,9 @@ class DeepLabV3PlusModel(nn.Module):
     :286-336 is out of scope)."""
 
     def __init__(self, backbone: str = "resnet50", num_classes: int = 19, include_depth: bool = True,
-                 pretrained: bool = True, output_stride: int = 16) -> None:
+                 pretrained: bool = True, output_stride: int = 16, *, compute_dtype: Optional[str] = None) -> None:
         super().__init__()
+        self.compute_dtype = compute_dtype
         self.num_classes = num_classes
         self.include_depth = include_depth
         if pretrained:
@@ -243,7 +245,8 @@ class DeepLabV3PlusModel(nn.Module):
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         if _use_hip(self, x):
-            return self._forward_hip(x)
+            with ops.precision(self.compute_dtype):
+                return self._forward_hip(x)
         seg = self.model(x)
         results = {"segmentation": seg}
         if self.include_depth:
@@ -279,16 +282,18 @@ class EnsembleModel(nn.Module):
 
     def __init__(self, num_classes: int = 19, include_depth: bool = True, ensemble_strategy: str = "weighted_average",
                  temperature_scaling: bool = True, *, segformer_name: Optional[str] = None,
-                 deeplab_backbone: str = "resnet50", pretrained: bool = True) -> None:
+                 deeplab_backbone: str = "resnet50", pretrained: bool = True, compute_dtype: Optional[str] = None) -> None:
         super().__init__()
+        self.compute_dtype = compute_dtype
         self.num_classes = num_classes
         self.include_depth = include_depth
         self.ensemble_strategy = ensemble_strategy
         self.temperature_scaling = temperature_scaling
         kw = {} if segformer_name is None else {"model_name": segformer_name}
-        self.segformer = SegFormerModel(num_classes=num_classes, include_depth=include_depth, pretrained=pretrained, **kw)
+        self.segformer = SegFormerModel(num_classes=num_classes, include_depth=include_depth, pretrained=pretrained,
+                                        compute_dtype=compute_dtype, **kw)
         self.deeplabv3plus = DeepLabV3PlusModel(backbone=deeplab_backbone, num_classes=num_classes,
-                                                include_depth=include_depth, pretrained=pretrained)
+                                                include_depth=include_depth, pretrained=pretrained, compute_dtype=compute_dtype)
         self.ensemble_weights = nn.Parameter(torch.ones(2) / 2)
         if self.temperature_scaling:
             self.temperature = nn.Parameter(torch.ones(1))

@@ -451,7 +451,7 @@ def conv3x3_winograd(x: torch.Tensor, u: torch.Tensor, shift: torch.Tensor, act:
 # 3x3 convolutions: 1 = Winograd on split-operand f16 MFMA (csrc/wino_split.hip), 0 = Winograd on float32-input MFMA
 WINO_SPLIT = os.environ.get("AWSEG_WINO_SPLIT", "1") != "0"
 
-def winograd_split_weights(weight: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+def winograd_split_weights(weight: torch.Tensor, scale: Optional[torch.Tensor] = None, bf16: bool = False) -> torch.Tensor:
     """[Cout,Cin,3,3] filters (times an optional per-Cout scale) -> the split-operand image of U = G g G^T that
     awseg_conv3x3_winograd_split_nhwc reads (include/awseg.h): f16 high and low parts of U * 2^-eu in the B-fragment
     order [Cin/16][16][Cout/32][hi k0-7 | hi k8-15 | lo k0-7 | lo k8-15][32][8], then 2^eu as one float32.  eu brings
@@ -465,8 +465,13 @@ def winograd_split_weights(weight: torch.Tensor, scale: Optional[torch.Tensor] =
     mx = u.abs().max()
     e = torch.where(mx > 0, torch.floor(torch.log2(mx.clamp_min(1e-300))) - 13.0, torch.zeros_like(mx))
     us = u * torch.exp2(-e)
-    hi = us.to(torch.float16)
-    lo = (us - hi.double()).to(torch.float16)
+    if bf16:
+        hi = us.to(torch.bfloat16).view(torch.int16)
+        lo = torch.zeros_like(hi)
+    else:
+        hi = us.to(torch.float16)
+        lo = (us - hi.double()).to(torch.float16).view(torch.int16)
+        hi = hi.view(torch.int16)
     nch, ncb = cin // 16, cout // 32
 
     def frag(t):                                                                          # -> [nch][16][ncb][h][32][8]
@@ -474,7 +479,7 @@ def winograd_split_weights(weight: torch.Tensor, scale: Optional[torch.Tensor] =
     img = torch.stack([frag(hi), frag(lo)], dim=3).reshape(-1).contiguous()               # [nch][16][ncb][hi/lo][h][32][8]
     n = img.numel()
     buf = torch.zeros(n + 8, dtype=torch.int16, device=weight.device)
-    buf[:n] = img.view(torch.int16)
+    buf[:n] = img
     buf[n:n + 2] = torch.exp2(e).to(torch.float32).reshape(1).view(torch.int16)
     return buf
 
@@ -512,6 +517,9 @@ def gemm_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int
     m, k = x.shape
     n = w.shape[0]
     bias = bias.contiguous()
+    if split is None and gemm_wants_bf16(m, n, k):
+        wb = w_split if (w_split is not None and getattr(w_split, "_awseg_bf16", False)) else gemm_bf16_weights(w)
+        return gemm_bf16_bias_act(x, wb, bias, act, residual=residual, out=out)
     if gemm_wants_split(m, n, k) if split is None else split:
         return gemm_split_bias_act(x, w_split if w_split is not None else gemm_split_weights(w), bias, act, residual=residual, out=out)
     ws = N.workspace.get(x.device, GEMM_WORKSPACE_BYTES, tag="gemm")
@@ -605,8 +613,77 @@ def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
     b, nq, c = q.shape
     out = torch.empty_like(q)
-    sym = "awseg_attention_d32_split" if (ATTENTION_SPLIT if split is None else split) else "awseg_attention_d32"
+    if split is None and PRECISION == "bf16":
+        sym = "awseg_attention_d32_bf16"
+    else:
+        sym = "awseg_attention_d32_split" if (ATTENTION_SPLIT if split is None else split) else "awseg_attention_d32"
     N.call(sym, N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), b, heads, nq, k.shape[1], float(scale), N.stream())
+    return out
+
+
+# Compute precision of the dense contractions (1x1 convolutions / Linear layers, 3x3 Winograd convolutions, attention):
+# "f32" = float32-grade results (split-operand f16 MFMA or float32-input MFMA, see set_split), "bf16" = one bf16 MFMA per
+# product tile with float32 accumulation (BASELINE config 5).  Models switch it for the duration of their forward.
+PRECISION = "f32"
+
+
+class precision:
+    """Context manager: `with ops.precision("bf16"): model(x)`."""
+
+    def __init__(self, dtype: Optional[str]):
+        self.dtype = {None: None, "f32": "f32", "fp32": "f32", "float32": "f32", "bf16": "bf16", "bfloat16": "bf16"}[dtype]
+
+    def __enter__(self):
+        global PRECISION
+        self.prev = PRECISION
+        if self.dtype is not None:
+            PRECISION = self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global PRECISION
+        PRECISION = self.prev
+        return False
+
+
+def gemm_wants_bf16(m: int, n: int, k: int) -> bool:
+    return PRECISION == "bf16" and m >= 128 and n >= 32 and k >= 16 and k % 8 == 0
+
+
+def gemm_bf16_weights(w: torch.Tensor) -> torch.Tensor:
+    """w float32 [N,K] -> int16 view [2,N,K] of a buffer with a 16-byte trailer (plane 0 = bf16(w), plane 1 unused)."""
+    w = w.contiguous()
+    n, k = w.shape
+    buf = torch.zeros(2 * n * k + 8, dtype=torch.int16, device=w.device)
+    N.call("awseg_gemm_bf16_weights", N.ptr(w), n, k, N.ptr(buf), N.stream())
+    return buf[:2 * n * k].view(2, n, k)
+
+
+def gemm_bf16_bias_act(x: torch.Tensor, w_bf16: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
+                       residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = x.contiguous()
+    m, k = x.shape
+    n = w_bf16.shape[1]
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    N.call("awseg_gemm_bf16_bias_act", N.ptr(x), N.ptr(w_bf16), N.ptr(bias), N.ptr(residual), act, N.ptr(out), m, n, k, N.stream())
+    return out
+
+
+def winograd_bf16_weights(weight: torch.Tensor, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The image winograd_split_weights builds, with bf16(U * 2^-eu) in the high slots and zeros in the (unread) low slots."""
+    return winograd_split_weights(weight, scale, bf16=True)
+
+
+def conv3x3_winograd_bf16(x: torch.Tensor, u_bf16: torch.Tensor, cout: int, shift: torch.Tensor, act: int = 0, dilation: int = 1,
+                          residual: Optional[torch.Tensor] = None, w2: Optional[torch.Tensor] = None,
+                          b2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    x = x.contiguous()
+    b, h, w, cin = x.shape
+    out = torch.empty((b, h, w) if w2 is not None else (b, h, w, cout), dtype=torch.float32, device=x.device)
+    N.call("awseg_conv3x3_winograd_bf16_nhwc", N.ptr(x), b, h, w, cin, cout, dilation, N.ptr(u_bf16), N.ptr(shift.contiguous()),
+           N.ptr(None if residual is None else residual.contiguous()), act, N.ptr(None if w2 is None else w2.contiguous()),
+           N.ptr(None if b2 is None else b2.contiguous()), N.ptr(out), N.stream())
     return out
 
 

@@ -90,6 +90,15 @@ def launch_work(name, args):
         # the same 16 multiplies per 2x2 output tile, each issued as THREE f16 MFMA products: priced as issued, against the f16 peak
         _, b, h, w, cin, cout = args[:6]
         return "mfma_f16", 3 * 2.0 * 16 * cin * cout * b * ((h + 1) // 2) * ((w + 1) // 2)
+    if name == "awseg_conv3x3_winograd_bf16_nhwc":
+        _, b, h, w, cin, cout = args[:6]
+        return "mfma_f16", 2.0 * 16 * cin * cout * b * ((h + 1) // 2) * ((w + 1) // 2)      # one bf16 product per multiply
+    if name == "awseg_gemm_bf16_bias_act":
+        m, n, k = args[6:9]
+        return "mfma_f16", 2.0 * m * n * k
+    if name == "awseg_attention_d32_bf16":
+        b, heads, nq, nkv = args[4:8]
+        return "mfma_f16", 4.0 * b * heads * nq * nkv * 32
     if name == "awseg_attention_d32":
         # (q, k, v, out, batch, heads, n_queries, n_keys, ...): QK^T and PV, head_dim 32
         b, heads, nq, nkv = args[4:8]
@@ -148,7 +157,7 @@ def algorithmic_work(name, B, H, W, C, info):
 
 
 # device-function names of the C-ABI launchers' dominant kernels (for the PMC traffic lookup)
-DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg_conv3x3_winograd_split_nhwc": "wino_split_kernel<1>", "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
+DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg_conv3x3_winograd_split_nhwc": "wino_split_kernel<1, false>", "awseg_conv3x3_winograd_bf16_nhwc": "wino_split_kernel<1, true>", "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_kernel"}
 
 

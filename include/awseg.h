@@ -479,6 +479,30 @@ int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int
                                       const uint16_t* u_split, const float* shift, const float* residual, int act,
                                       const float* w2, const float* b2, float* out, awseg_stream_t stream);
 
+/* ------------------------------------------------------------------------- *
+ *  BASELINE config 5: the bf16 MFMA path (SegFormer-B5 + DeepLabV3+-R101)
+ * ------------------------------------------------------------------------- *
+ * The three dense contractions of the eval forward with ONE v_mfma_f32_32x32x16_bf16 per product tile instead of
+ * three f16 products on split operands: operands are rounded to bfloat16 (round to nearest even) when they are staged,
+ * accumulation, softmax, Winograd transforms and epilogues stay float32, tensors in memory stay float32.  Same
+ * arguments, layouts, epilogues and error codes as the split-operand entry points they mirror; bfloat16 has float32's
+ * exponent range, so there is no operand-range guard.  The reference has no counterpart (it cannot select these
+ * backbones or a reduced precision: PKG/models/model.py:409-417); tolerance against the float32 path is stated in
+ * tests/test_gpu_bf16.py.
+ *   awseg_gemm_bf16_weights / awseg_gemm_bf16_bias_act  <->  awseg_gemm_split_weights / awseg_gemm_split_bias_act
+ *       (w_bf16: uint16 [2][N][K] + 8 like w_split; plane 0 holds bf16(w), plane 1 is unused, trailer exponent 0)
+ *   awseg_conv3x3_winograd_bf16_nhwc                    <->  awseg_conv3x3_winograd_split_nhwc
+ *       (u_bf16: the same image with bf16(U * 2^-eu) in the "high" slots; the "low" slots are not read)
+ *   awseg_attention_d32_bf16                            <->  awseg_attention_d32_split */
+int awseg_gemm_bf16_weights(const float* w, int n, int k, uint16_t* w_bf16, awseg_stream_t stream);
+int awseg_gemm_bf16_bias_act(const float* x, const uint16_t* w_bf16, const float* bias, const float* residual, int act,
+                             float* out, int64_t m, int n, int k, awseg_stream_t stream);
+int awseg_conv3x3_winograd_bf16_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
+                                     const uint16_t* u_bf16, const float* shift, const float* residual, int act,
+                                     const float* w2, const float* b2, float* out, awseg_stream_t stream);
+int awseg_attention_d32_bf16(const float* q, const float* k, const float* v, float* out, int batch, int heads,
+                             int n_queries, int n_keys, float scale, awseg_stream_t stream);
+
 /* awseg_im2col_nhwc: patch matrix of a strided / patch convolution on a channel-last tensor, so that the convolution
  * is ONE deterministic GEMM (awseg_gemm_split_bias_act / awseg_gemm_bias_act) with bias / folded BatchNorm / activation
  * in its epilogue: x float32 [B,H,W,C] -> cols float32 [B*Ho*Wo, k_padded], cols[m][(ky*kw + kx)*C + c] =

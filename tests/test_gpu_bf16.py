@@ -1,0 +1,115 @@
+"""-m gpu: BASELINE config 5 — the bf16 MFMA path (one v_mfma_f32_32x32x16_bf16 per product tile, float32 accumulation).
+Each kernel is checked twice: (1) its ARITHMETIC against a float64 product of the bf16-rounded operands (what the
+hardware is asked to compute: float32-accumulation noise only, 2e-5 relative), and (2) its PRECISION against the
+float32-grade path on the unrounded operands at the stated bf16 tolerance: operands carry 8 significant bits, so an
+entry of a K-term contraction is off by about 2^-8 * |x||w| * sqrt(K) — asserted as 2e-2 of the result's magnitude."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops(native):
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import ops
+    return ops
+
+
+def bf(t):
+    return t.to(torch.bfloat16).double()
+
+
+@pytest.mark.parametrize("shape", [(300, 256, 128), (257, 2048, 512), (4100, 320, 72), (38400, 256, 128), (1000, 64, 304), (20000, 32, 64)])
+def test_gemm_bf16(ops, shape):
+    M, Nn, K = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(M, K, device="cuda", generator=g) * 2.0
+    x[::9] *= 1e4                                                # bf16 has float32's range: no guard needed
+    w = torch.randn(Nn, K, device="cuda", generator=g) * 0.05
+    bias = torch.randn(Nn, device="cuda", generator=g)
+    res = torch.randn(M, Nn, device="cuda", generator=g)
+    wb = ops.gemm_bf16_weights(w)
+    got = ops.gemm_bf16_bias_act(x, wb, bias, 1, residual=res)
+    exact = (bf(x) @ bf(w).t() + bias.double() + res.double()).clamp_min(0)
+    full = (x.double() @ w.double().t() + bias.double() + res.double()).clamp_min(0)
+    rowmag = full.abs().amax(dim=1).clamp_min(1.0)
+    e_arith = ((got.double() - exact).abs().amax(dim=1) / rowmag).max().item()
+    e_prec = ((got.double() - full).abs().amax(dim=1) / rowmag).max().item()
+    print(f"gemm bf16 {shape}: vs bf16-rounded operands {e_arith:.2e}, vs float64 {e_prec:.2e}")
+    assert e_arith < 2e-5 and e_prec < 2e-2
+    with ops.precision("bf16"):                                  # the dispatcher picks it up
+        assert torch.equal(ops.gemm_bias_act(x, w, bias, 1, residual=res), got)
+    assert ops.PRECISION == "f32"
+
+
+@pytest.mark.parametrize("shape", [(2, 20, 36, 32, 64, 1), (1, 33, 47, 32, 128, 2), (1, 40, 72, 256, 256, 1), (2, 16, 32, 2048, 256, 1)])
+def test_conv3x3_winograd_bf16(ops, shape):
+    B, H, W, Cin, Cout, d = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + 3)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    wt = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (3.0 * Cin ** 0.5)
+    scale = torch.rand(Cout, device="cuda", generator=g) + 0.5
+    shift = torch.randn(Cout, device="cuda", generator=g)
+    res = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+    ub = ops.winograd_bf16_weights(wt, scale)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), (wt * scale.view(-1, 1, 1, 1)).double(), None, 1, d, d)
+    ref = (ref.permute(0, 2, 3, 1) + shift.double() + res.double()).clamp_min(0)
+    got = ops.conv3x3_winograd_bf16(x, ub, Cout, shift, act=1, dilation=d, residual=res)
+    f32 = ops.conv3x3_winograd_split(x, ops.winograd_split_weights(wt, scale), Cout, shift, act=1, dilation=d, residual=res)
+    mag = max(1.0, ref.abs().max().item())
+    e_bf, e_32 = (got.double() - ref).abs().max().item() / mag, (f32.double() - ref).abs().max().item() / mag
+    print(f"winograd bf16 {shape}: rel err {e_bf:.2e} (float32-grade kernel {e_32:.2e})")
+    assert e_bf < 2e-2 and e_32 < 1e-5
+    if Cout == 64:
+        w2 = torch.randn(64, device="cuda", generator=g) * 0.2
+        b2 = torch.randn(1, device="cuda", generator=g)
+        ref1 = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), (wt * scale.view(-1, 1, 1, 1)).double(), None, 1, d, d).permute(0, 2, 3, 1) + shift.double()
+        want = torch.sigmoid((ref1.clamp_min(0) * w2.double()).sum(-1) + b2.double())
+        got = ops.conv3x3_winograd_bf16(x, ub, Cout, shift, dilation=d, w2=w2, b2=b2)
+        assert got.shape == (B, H, W) and (got.double() - want).abs().max().item() < 2e-2
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 300, 2048), (2, 1, 200, 64), (1, 8, 128, 32)])
+def test_attention_d32_bf16(ops, shape):
+    B, nh, nq, nkv = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + 5)
+    C = nh * 32
+    q = torch.randn(B, nq, C, device="cuda", generator=g)
+    k = torch.randn(B, nkv, C, device="cuda", generator=g)
+    v = torch.randn(B, nkv, C, device="cuda", generator=g)
+    scale = 32 ** -0.5
+    with ops.precision("bf16"):
+        got = ops.attention_d32(q, k, v, nh, scale)
+    f32 = ops.attention_d32(q, k, v, nh, scale)
+    qh, kh, vh = (t.double().view(B, -1, nh, 32).transpose(1, 2) for t in (q, k, v))
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).transpose(1, 2).reshape(B, nq, C)
+    e_bf, e_32 = (got.double() - ref).abs().max().item(), (f32.double() - ref).abs().max().item()
+    print(f"attention bf16 {shape}: abs err {e_bf:.2e} (float32-grade kernel {e_32:.2e})")
+    assert e_bf < 3e-2 and e_32 < 2e-5 and not torch.equal(got, f32)
+
+
+def test_b5_r101_ensemble_bf16_matches_float32_path():
+    """SegFormer-B5 + DeepLabV3+-R101 (the constructor extensions of SURVEY §8(b)) with compute_dtype='bf16' against the
+    SAME weights on the float32-grade path: logits within 5 % of their magnitude, >= 97 % of the argmax labels equal."""
+    import adverse_weather_semantic_segmentation_robustness_benchmark_amd as P
+    torch.manual_seed(55)
+    m = P.EnsembleModel(num_classes=19, include_depth=True, pretrained=False, segformer_name="nvidia/segformer-b5-finetuned-cityscapes-1024-1024",
+                        deeplab_backbone="resnet101", compute_dtype="bf16")
+    assert m.segformer.segformer.config.depths == [3, 6, 40, 3] and len(m.deeplabv3plus.model.encoder.layer3) == 23
+    g = torch.Generator().manual_seed(0)
+    for mod in m.modules():                                      # calibrated BatchNorm statistics: O(1) logits
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) * 1.5 + 0.5)
+            mod.weight.data.copy_(torch.rand(mod.weight.shape, generator=g) * 0.5 + 0.25)
+    m = m.cuda().eval()
+    x = torch.randn(1, 3, 256, 256, device="cuda")
+    out_bf = m(x)
+    m.compute_dtype = m.segformer.compute_dtype = m.deeplabv3plus.compute_dtype = None
+    out_32 = m(x)
+    for k in ("segformer_seg", "deeplabv3plus_seg", "segmentation"):
+        a, b = out_bf[k], out_32[k]
+        rel = (a - b).abs().max().item() / b.abs().max().item()
+        agree = (a.argmax(1) == b.argmax(1)).float().mean().item()
+        print(f"b5+r101 bf16 vs float32 path, {k}: max rel diff {rel:.3e}, argmax agreement {agree:.4f}")
+        assert rel < 5e-2 and agree > 0.97 and not torch.equal(a, b)

@@ -260,6 +260,10 @@ def parse_args(argv=None):
     ap.add_argument("--conv-search", type=int, default=int(os.environ.get("AWSEG_CONV_SEARCH", "0")),
                     help="1: let MIOpen time its solvers per convolution shape during warm-up (torch.backends.cudnn.benchmark)")
     ap.add_argument("--deterministic-convs", action="store_true", help="torch.backends.cudnn.deterministic = True for the two 7x7 stems left on MIOpen (measured 6x slower)")
+    ap.add_argument("--mode", choices=["eval", "train"], default="eval",
+                    help="eval: the north-star metric (BASELINE configs[1]); train: one AdverseWeatherTrainer optimisation step per "
+                         "bench step (BASELINE configs[3]: ensemble + FogDensityAwareLoss + depth heads, bs 8 per GPU, DP gradient all-reduce)")
+    ap.add_argument("--no-conv-search", action="store_true", help="train mode: keep MIOpen in immediate mode (no solver search)")
     ap.add_argument("--dry-run", action="store_true",
                     help="rendezvous only (gloo, CPU): every rank reports its block of the global sample set, rank 0 prints the pooled "
                          "frame count — exercises the self-launch / sharding path where there is no GPU (tests/)")
@@ -323,6 +327,108 @@ def self_launch(args) -> int:
     return rc
 
 
+def train_main(args):
+    """BASELINE configs[3]: the AdverseWeatherTrainer step at its stated shape.  One bench step = one optimisation step on a
+    batch of B frames per rank: weather corruption + Normalize (HIP) and the depth target (HIP) from resident uint8 frames,
+    ensemble forward in TRAINING mode (the reference's op graph on torch-ROCm, autograd), per-batch fog-density field (HIP,
+    Philox), FogDensityAwareLoss forward + backward (HIP), backward, bucketed gradient all-reduce overlapped with backward
+    (RCCL), gradient clipping, AdamW.  value = N*B*K / max-over-ranks time."""
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import parallel
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import EnsembleModel
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.training.trainer import AdverseWeatherTrainer
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data.preprocessing import WeatherDegradationTransforms, DepthEstimationPreprocessor
+    import tempfile
+    n_dev = torch.cuda.device_count()
+    if int(os.environ.get("WORLD_SIZE", "1")) > max(n_dev, 1) and "AWSEG_DIST_BACKEND" not in os.environ:
+        os.environ["AWSEG_DIST_BACKEND"] = "gloo"
+    rank, local, world = parallel.init_from_env()
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    dev = torch.device("cuda", local % max(n_dev, 1))
+    torch.cuda.set_device(dev)
+    backend = torch.distributed.get_backend() if parallel.is_dist() else "none"
+    B, H, W, C = args.batch, args.height, args.width, 19
+    torch.manual_seed(42)
+    model = EnsembleModel(num_classes=C, include_depth=True, pretrained=False)
+    tf = WeatherDegradationTransforms(seed=None, rng="philox", device=dev)
+    tf._frame_seed = 1234
+    depth_pre = DepthEstimationPreprocessor(dev)
+    n_frames = min(args.frames, 4 * B * world)
+    mine = list(parallel.shard_range(n_frames, rank, world))
+    gen = torch.Generator(device=dev)
+    raw = torch.empty(len(mine), H, W, 3, dtype=torch.uint8, device=dev)
+    labels = torch.empty(len(mine), H, W, dtype=torch.uint8, device=dev)
+    for k, g in enumerate(mine):
+        gen.manual_seed(42 * 1000003 + g)
+        raw[k] = torch.randint(0, 255, (H, W, 3), dtype=torch.uint8, device=dev, generator=gen)
+        labels[k] = torch.randint(0, C, (H, W), dtype=torch.uint8, device=dev, generator=gen)
+
+    class Batches:
+        """`n` batches of B resident frames (cycling through the rank's block), born on the GPU."""
+        def __init__(self, first, n):
+            self.first, self.n = first, n
+
+        def __len__(self):
+            return self.n
+
+        def __iter__(self):
+            for i in range(self.first, self.first + self.n):
+                if rank == 0:
+                    print(f"[bench train] batch {i - self.first + 1}/{self.n} enqueued at {time.perf_counter() - t_start:.1f} s", file=sys.stderr, flush=True)
+                idx = [(i * B + k) % len(mine) for k in range(B)]
+                ids = [mine[k] for k in idx]
+                conds = [CONDITIONS[g % len(CONDITIONS)] for g in ids]
+                sel = torch.tensor(idx, dtype=torch.int64).pin_memory().to(dev, non_blocking=True)
+                r, l = raw.index_select(0, sel), labels.index_select(0, sel)
+                image = torch.empty(B, 3, H, W, dtype=torch.float32, device=dev)
+                frames = torch.empty_like(r)
+                tf.apply_batch(r, conds, out=frames, norm_out=image, frame_ids=ids)
+                yield {"image": image, "label": l, "weather_condition": conds, "depth": depth_pre.estimate_depth_batch(frames),
+                       "dataset": ["synthetic"] * B}
+
+    t_start = time.perf_counter()
+    # MIOpen's immediate-mode fall-back picks im2col + GEMM solvers for the backward 3x3 convolutions at these sizes (a
+    # bs-2 step did not finish in 300 s, gpurun_out/r02_train_bs2.err): let it time its solvers once per shape instead
+    torch.backends.cudnn.benchmark = not args.no_conv_search
+    config = {"epochs": 1, "num_classes": C, "optimizer": {"type": "adamw", "learning_rate": 1e-4, "weight_decay": 0.01},
+              "loss": {"type": "fog_density_aware"}, "grad_clip": 1.0, "seed": 42}
+    tmp = tempfile.mkdtemp(prefix="awseg_bench_")
+    trainer = AdverseWeatherTrainer(model, Batches(0, args.warmup), None, config, dev, checkpoint_dir=tmp + "/ck", log_dir=tmp + "/lg")
+    trainer.train_epoch()                                    # warm-up steps (allocator, MIOpen solver choice)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    trainer.train_loader = Batches(args.warmup, args.steps)
+    torch.cuda.reset_peak_memory_stats(dev)
+    t0 = time.perf_counter()
+    res = trainer.train_epoch()                              # ONE host synchronisation, at its end (device-resident running sums)
+    torch.cuda.synchronize()
+    parallel.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if parallel.is_dist():
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    if rank == 0:
+        line = {
+            "metric": f"images/sec ({H}x{W}, AdverseWeatherTrainer train step: ensemble + FogDensityAwareLoss + depth heads)",
+            "value": round(B * args.steps * world / dt, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"train_step_{H}x{W}_bs{B} (BASELINE.json configs[3]: SegFormer-B0 + DeepLabV3+-R50 ensemble, FogDensityAwareLoss, "
+                                   "depth heads, AdamW, grad clip 1.0)", "per_gpu_batch": B, "global_batch": B * world,
+                       "forward_backward": "reference op graph on torch-ROCm (autograd); loss forward/backward, density field, weather, "
+                                           "Normalize and depth target on HIP kernels", "dist_backend": backend,
+                       "gradient_all_reduce": "flat float32 buckets of 32 MB, launched from post-accumulate-grad hooks during backward"},
+            "rccl_ranks": world if backend == "nccl" else 0,
+            "roofline": None, "cpu_baseline": None,
+            "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
+            "losses": {k: round(float(v), 6) for k, v in res.items()},
+        }
+        print(json.dumps(line), flush=True)
+    if parallel.is_dist():
+        torch.distributed.destroy_process_group()
+
+
 def main():
     global np, torch
     args = parse_args()
@@ -330,8 +436,15 @@ def main():
         raise SystemExit(self_launch(args))
     if args.dry_run:
         return dry_run(args)
+    if args.mode == "train" and "MIOPEN_FIND_MODE" not in os.environ:
+        # training shapes miss MIOpen's find-db on a fresh box; its default (hybrid) mode then BENCHMARKS every candidate
+        # solver of every backward convolution — naive ones included — which takes minutes per shape at these sizes
+        # (gpurun_out/r02_train_bs2.err).  FAST = find-db, else the heuristic pick, no benchmarking.
+        os.environ["MIOPEN_FIND_MODE"] = "FAST"
     import numpy as np                     # noqa: F811
     import torch                           # noqa: F811
+    if args.mode == "train":
+        return train_main(args)
     torch.backends.cudnn.benchmark = bool(args.conv_search)
     # (the strided / patch convolutions run as im2col + GEMM on this repo's kernels: MIOpen's default pick for them is a
     # split-K igemm that accumulates with atomics, run-to-run different — tools/check_op_determinism.py.  Forcing

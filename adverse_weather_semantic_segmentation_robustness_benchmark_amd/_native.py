@@ -76,6 +76,8 @@ SIGNATURES = {
     "awseg_fog_density_from_depth": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_segformer_head_fused": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     "awseg_upconv3x3_bn_relu": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
+    "awseg_upconv3x3_linear": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
+    "awseg_upconv3x3_adjoint": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "awseg_aspp_depthwise3": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
     "awseg_dwconv3x3_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
     "awseg_bias_act_nhwc": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_i, c_p]),

@@ -136,7 +136,6 @@ void gemm_split_kernel(gemm_args a)
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int NA = BM / 64;                                  // float4 of x per thread per K tile
     constexpr int NB = BN / 64;                                  // 16-byte chunks of w per thread per K tile (hi and lo)
-    constexpr int NBL = BF16 ? NB / 2 : NB;                      // ... of which the bf16 form loads the first plane only
     __shared__ __attribute__((aligned(16))) _Float16 sA[2][BM * GROW];
     __shared__ __attribute__((aligned(16))) _Float16 sB[2][BN * GROW];
     __shared__ unsigned sMax[2];                                 // max|x| bits seen by the block in a pass (if >= 2^15), by pass parity

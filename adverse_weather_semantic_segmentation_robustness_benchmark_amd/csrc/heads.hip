@@ -223,14 +223,15 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) wf[r] = s_w2[(ot * 16 + r) * 64 + lane];
             }
+            const bool relu = !(out_nhwc & 2);                  // bit 1 of the layout flag: linear output (training forward)
             if (has_scale) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int o = ot * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
                     float v = fmaf(acc[r], s_scale[o], s_shift[o]);
-                    acc[r] = v > 0.f ? v : 0.f;
+                    acc[r] = (v > 0.f || !relu) ? v : 0.f;
                 }
-            } else {
+            } else if (relu) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
             }
@@ -238,7 +239,7 @@ void head_mfma_kernel(const float* __restrict__ g9, int h, int w, int H, int W, 
 #pragma unroll
                 for (int s2 = 0; s2 < 16; ++s2) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[s2], acc[s2], acc2, 0, 0, 0);
             } else if (x0 + lo < W) {
-                if (out_nhwc) {
+                if (out_nhwc & 1) {
                     // a lane holds channels {8q+4hh .. 8q+4hh+3} of its pixel: four 16-byte stores; the two
                     // half-waves fill adjacent halves of every 32-byte run
                     float* px = out + (((int64_t)b * H + y) * W + x0 + lo) * CM + ot * 32 + 4 * hh;
@@ -658,6 +659,109 @@ AWSEG_API int awseg_upconv3x3_bn_relu(const float* g9, int64_t batch, int cmid, 
     if (channels_last && ((uintptr_t)out & 15)) return AWSEG_EALIGN;
     return head_dispatch(false, g9, batch, cmid, h, w, height, width, scale, shift, nullptr, nullptr, 0, out,
                          channels_last ? 1 : 0, awseg_s(stream));
+}
+
+AWSEG_API int awseg_upconv3x3_linear(const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
+                                     const float* bias, float* out, int channels_last, awseg_stream_t stream)
+{
+    if (channels_last && ((uintptr_t)out & 15)) return AWSEG_EALIGN;
+    if ((cmid % 32) || cmid > 256) return AWSEG_ERANGE;
+    return head_dispatch(false, g9, batch, cmid, h, w, height, width, nullptr, bias, nullptr, nullptr, 0, out,
+                         (channels_last ? 1 : 0) | 2, awseg_s(stream));
+}
+
+namespace {
+// Adjoint of awseg_upconv3x3_linear with respect to g9 (the backward pass of conv3x3(interpolate(f)) in training):
+//   dG[b, ci, cj, tap, c] = sum over pixels (y, x) whose tap (ky, kx) lands on (y + ky - 1, x + kx - 1) inside the image
+//                           and whose bilinear stencil there touches cell (ci, cj):  l_i * l_j * dz[b, y, x, c]
+// Block = one 32 x 32 pixel tile of one image, thread = one channel (blockDim = Cmid): the shifted rows / columns of the
+// tile touch at most 3 cell rows / columns when H/h >= 32 (checked by the launcher), so a thread keeps 3 x 3 x 9
+// accumulators in registers; per-row and per-column stencil weights of the 34 shifted coordinates come from LDS tables
+// (zero outside the image).  dz is read exactly once, coalesced over channels; the 81 sums per channel are added to dG
+// with float atomics (<= 9 tiles meet in a cell).
+__global__ __launch_bounds__(256)
+void upconv3x3_adjoint_kernel(const float* __restrict__ dz, int h, int w, int H, int W, int C, float* __restrict__ dg)
+{
+    __shared__ float s_wy[34][3], s_wx[34][3];
+    const int b = blockIdx.z, y0 = blockIdx.y * 32, x0 = blockIdx.x * 32;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int ibase = bilinear_src(y0 > 0 ? y0 - 1 : 0, sh, h).i0;
+    const int jbase = bilinear_src(x0 > 0 ? x0 - 1 : 0, sw, w).i0;
+    for (int i = threadIdx.x; i < 34 * 2; i += blockDim.x) {
+        const bool isx = i >= 34;
+        const int k = isx ? i - 34 : i;
+        const int p = (isx ? x0 : y0) + k - 1;
+        float wv[3] = {0.f, 0.f, 0.f};
+        if (p >= 0 && p < (isx ? W : H)) {
+            const src_idx sidx = bilinear_src(p, isx ? sw : sh, isx ? w : h);
+            const int r0 = sidx.i0 - (isx ? jbase : ibase), r1 = sidx.i1 - (isx ? jbase : ibase);
+#pragma unroll
+            for (int a = 0; a < 3; ++a) wv[a] = (a == r0 ? sidx.l0 : 0.f) + (a == r1 ? sidx.l1 : 0.f);
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) (isx ? s_wx : s_wy)[k][a] = wv[a];
+    }
+    __syncthreads();
+    const int c = threadIdx.x;
+    float acc[3][3][9];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[a][bb][t] = 0.f;
+    const float* src = dz + (int64_t)b * H * W * C + c;
+    const int ny = (H - y0) < 32 ? (H - y0) : 32, nx = (W - x0) < 32 ? (W - x0) : 32;
+    for (int r = 0; r < ny; ++r) {
+        for (int q = 0; q < nx; ++q) {
+            const float v = src[((int64_t)(y0 + r) * W + x0 + q) * C];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float wy0 = s_wy[r + ky][0], wy1 = s_wy[r + ky][1], wy2 = s_wy[r + ky][2];
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float t0 = s_wx[q + kx][0] * v, t1 = s_wx[q + kx][1] * v, t2 = s_wx[q + kx][2] * v;
+                    float (&ac)[3][3][9] = acc;
+                    const int t = ky * 3 + kx;
+                    ac[0][0][t] = fmaf(wy0, t0, ac[0][0][t]); ac[0][1][t] = fmaf(wy0, t1, ac[0][1][t]); ac[0][2][t] = fmaf(wy0, t2, ac[0][2][t]);
+                    ac[1][0][t] = fmaf(wy1, t0, ac[1][0][t]); ac[1][1][t] = fmaf(wy1, t1, ac[1][1][t]); ac[1][2][t] = fmaf(wy1, t2, ac[1][2][t]);
+                    ac[2][0][t] = fmaf(wy2, t0, ac[2][0][t]); ac[2][1][t] = fmaf(wy2, t1, ac[2][1][t]); ac[2][2][t] = fmaf(wy2, t2, ac[2][2][t]);
+                }
+            }
+        }
+    }
+    float* dst = dg + (int64_t)b * h * w * 9 * C + c;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int ci = ibase + a;
+        if (ci >= h) continue;
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) {
+            const int cj = jbase + bb;
+            if (cj >= w) continue;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float s = acc[a][bb][t];
+                if (s != 0.f) atomicAdd(dst + (((int64_t)ci * w + cj) * 9 + t) * C, s);
+            }
+        }
+    }
+}
+}  // namespace
+
+AWSEG_API int awseg_upconv3x3_adjoint(const float* dz, int64_t batch, int cmid, int h, int w, int height, int width,
+                                      float* dg9, awseg_stream_t stream)
+{
+    if (!dz || !dg9 || batch < 1 || cmid < 1 || h < 1 || w < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (cmid > 256 || batch > 65535) return AWSEG_ERANGE;
+    // a 32-pixel tile (+1 halo) may touch at most 3 cells per axis: true when the upsampling factor is >= 32
+    if ((int64_t)h * 32 > height || (int64_t)w * 32 > width) return AWSEG_ERANGE;
+    hipError_t e = hipMemsetAsync(dg9, 0, (size_t)batch * h * w * 9 * cmid * sizeof(float), awseg_s(stream));
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((width + 31) / 32, (height + 31) / 32, (unsigned)batch);
+    hipLaunchKernelGGL(upconv3x3_adjoint_kernel, grid, dim3(cmid), 0, awseg_s(stream), dz, h, w, height, width, cmid, dg9);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
 }
 
 AWSEG_API int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int channels, const float* wdw,

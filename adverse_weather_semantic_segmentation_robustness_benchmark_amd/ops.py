@@ -388,6 +388,50 @@ def upconv3x3_bn_relu(g9: torch.Tensor, scale, shift, height: int, width: int, c
     return out.permute(0, 3, 1, 2) if channels_last else out          # logical NCHW either way
 
 
+class _UpConv3x3(torch.autograd.Function):
+    """conv3x3(F.interpolate(f, (H, W), bilinear, align_corners=False)) with zero padding, for TRAINING, without the
+    upsampled tensor and without a full-resolution convolution (PKG/models/model.py:209-214, :219-221): forward = one small
+    GEMM at the encoder's resolution + awseg_upconv3x3_linear; backward = awseg_upconv3x3_adjoint + two small GEMMs."""
+
+    @staticmethod
+    def forward(ctx, tok, weight, bias, height, width):
+        B, h, w, cin = tok.shape
+        cmid = weight.shape[0]
+        w1r = weight.permute(1, 2, 3, 0).reshape(cin, 9 * cmid)                     # [Cin, (ky, kx, cout)]
+        tok2 = tok.reshape(B * h * w, cin)
+        g9 = (tok2 @ w1r).view(B, h, w, 9, cmid).contiguous()
+        # NCHW out: the layers behind (BatchNorm, Conv2d) then run on MIOpen's NCHW kernels like the as-written graph — its
+        # heuristic pick for channels_last weight gradients is a CK kernel 50x slower (profiles/r02_train_step_kernels.csv)
+        z = torch.empty(B, cmid, height, width, dtype=torch.float32, device=tok.device)
+        b = bias if bias is not None else torch.zeros(cmid, dtype=torch.float32, device=tok.device)
+        N.call("awseg_upconv3x3_linear", N.ptr(g9), B, cmid, h, w, height, width, N.ptr(b.contiguous()), N.ptr(z), 0, N.stream())
+        ctx.save_for_backward(tok2, w1r)
+        ctx.shape = (B, h, w, cin, cmid, height, width, bias is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        tok2, w1r = ctx.saved_tensors
+        B, h, w, cin, cmid, height, width, has_bias = ctx.shape
+        dzl = dz.permute(0, 2, 3, 1).contiguous()                                   # NHWC for the adjoint kernel (one transpose pass)
+        dg9 = torch.empty(B, h, w, 9, cmid, dtype=torch.float32, device=dz.device)
+        N.call("awseg_upconv3x3_adjoint", N.ptr(dzl), B, cmid, h, w, height, width, N.ptr(dg9), N.stream())
+        dg2 = dg9.view(B * h * w, 9 * cmid)
+        dtok = (dg2 @ w1r.t()).view(B, h, w, cin)
+        dweight = (tok2.t() @ dg2).view(cin, 3, 3, cmid).permute(3, 0, 1, 2).contiguous()
+        dbias = dzl.sum(dim=(0, 1, 2)) if has_bias else None
+        return dtok, dweight, dbias, None, None
+
+
+def upconv3x3_train(tok: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], height: int, width: int) -> torch.Tensor:
+    """Differentiable conv3x3(interpolate(f)) for NHWC encoder tokens [B,h,w,Cin] -> [B,Cmid,H,W]."""
+    return _UpConv3x3.apply(tok.contiguous(), weight, bias, int(height), int(width))
+
+
+def upconv3x3_train_supported(cin: int, cmid: int, h: int, w: int, height: int, width: int) -> bool:
+    return cmid % 32 == 0 and cmid <= 256 and height >= 32 * h and width >= 32 * w
+
+
 def aspp_depthwise3(x_nhwc: torch.Tensor, wdw: torch.Tensor, rates) -> torch.Tensor:
     """Depthwise halves of smp's three ASPPSeparableConv branches in one pass.
     x [B,h,w,C] NHWC, wdw [3,9,C] -> [3,B,h,w,C]."""

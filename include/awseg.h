@@ -503,6 +503,22 @@ int awseg_conv3x3_winograd_bf16_nhwc(const float* x, int batch, int height, int 
 int awseg_attention_d32_bf16(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                              int n_queries, int n_keys, float scale, awseg_stream_t stream);
 
+/* awseg_upconv3x3_linear / awseg_upconv3x3_adjoint: the TRAINING form of the upsample-free head stage (BASELINE config 4).
+ * PKG/models/model.py:209-214 runs conv3x3(F.interpolate(f, (H,W), bilinear, align_corners=False)) at full resolution (2.47
+ * TFLOP and a 2.15 GB tensor per frame; its backward through MIOpen is what makes the as-written train step take seconds).
+ * Upsampling and convolution are linear, so with g9 = f . W (nine per-tap 1x1 products at the encoder's resolution, float32
+ * [B,h,w,9,Cmid]) the forward is z = sum_tap shift_tap(upsample(g9_tap)) + bias:
+ *   awseg_upconv3x3_linear  z float32 [B,Cmid,H,W] (channels_last = 0) or [B,H,W,Cmid] (1) — no BatchNorm, no activation:
+ *                           BatchNorm in training mode needs the batch statistics of z itself; bias float32 [Cmid];
+ *                           Cmid % 32 == 0, <= 256;
+ *   awseg_upconv3x3_adjoint dg9 = (d z / d g9)^T dz — dz float32 [B,H,W,Cmid] read once, dg9 zeroed and accumulated with
+ *                           float atomics; needs H >= 32 h and W >= 32 w (SegFormer: stride 32).
+ * The two small GEMMs either side (g9 = f W; df = dg9 W^T, dW = f^T dg9) are the caller's (torch.matmul). */
+int awseg_upconv3x3_linear(const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
+                           const float* bias, float* out, int channels_last, awseg_stream_t stream);
+int awseg_upconv3x3_adjoint(const float* dz, int64_t batch, int cmid, int h, int w, int height, int width,
+                            float* dg9, awseg_stream_t stream);
+
 /* awseg_im2col_nhwc: patch matrix of a strided / patch convolution on a channel-last tensor, so that the convolution
  * is ONE deterministic GEMM (awseg_gemm_split_bias_act / awseg_gemm_bias_act) with bias / folded BatchNorm / activation
  * in its epilogue: x float32 [B,H,W,C] -> cols float32 [B*Ho*Wo, k_padded], cols[m][(ky*kw + kx)*C + c] =

@@ -320,11 +320,13 @@ void wino_split_kernel(ws_args a)
         // chunk: the ring phase is the same in every chunk).  The kernel is bound by what a CU can pull from L2 (U: 64 KB
         // per chunk, patch: 21 KB; measured 12-14 B/clk/CU with two positions in flight): bytes in flight are what raises it.
         h8 u0h, u0l, u1h, u1l, u2h, u2l, u3h, u3l;
+        // only patch 0 has to be there to start: the DMAs of patches 1 and 2 (this wave's 2 x 5 or 2 x 6 youngest operations —
+        // the U loads are issued behind the wait, so the count is exact) stay in flight through the first transform
+        if (wave == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        __syncthreads();                                             // (also orders sMax[0] = 0 / the previous pass's V reads)
         u_load(0, 0, u0h, u0l);
         u_load(0, 1, u1h, u1l);
         u_load(0, 2, u2h, u2l);
-        vm_wait_all();
-        __syncthreads();                                             // (also orders sMax[0] = 0 / the previous pass's V reads)
         patch_rows(0, 0, tA);
         patch_rows(0, 1, tB);
         cols_store(0);
@@ -519,12 +521,19 @@ void wino_split_kernel(ws_args a)
     } else {
         // rows = couts n0 + 32 nt + (r & 3) + 8 (r >> 2) + 4 hk, columns = tiles of m-tile mt (tile = 32 mt + li)
         float z[4] = {0.f, 0.f, 0.f, 0.f};
+        // rows 4g .. 4g+3 of a lane are four consecutive couts: one 16-byte load each for the shift and the 1x1 weights
+        float shv[16], wv[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = n0 + nt * 32 + 8 * g4 + 4 * hk;
+            const float4 s4 = *reinterpret_cast<const float4*>(a.shift + co), w4 = *reinterpret_cast<const float4*>(a.w2 + co);
+            shv[4 * g4] = s4.x; shv[4 * g4 + 1] = s4.y; shv[4 * g4 + 2] = s4.z; shv[4 * g4 + 3] = s4.w;
+            wv[4 * g4] = w4.x; wv[4 * g4 + 1] = w4.y; wv[4 * g4 + 2] = w4.z; wv[4 * g4 + 3] = w4.w;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = n0 + nt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hk;
-            const float sh = a.shift[co], w = a.w2[co];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) z[o] += fmaxf(y[o][r] + sh, 0.f) * w;
+            for (int o = 0; o < 4; ++o) z[o] += fmaxf(y[o][r] + shv[r], 0.f) * wv[r];
         }
 #pragma unroll
         for (int o = 0; o < 4; ++o) z[o] += __shfl_xor(z[o], 32, 64);   // the other half-wave holds rows + 4 of the same tile
@@ -577,6 +586,7 @@ int ws_entry(bool bf16, const float* x, int batch, int height, int width, int ci
     if (cin < KC || (cin % KC) || cout < NB || (cout % NB)) return AWSEG_ERANGE;
     if ((w2 == nullptr) != (b2 == nullptr)) return AWSEG_EINVAL;
     if (w2 && (cout != NB || residual)) return AWSEG_ERANGE;
+    if (w2 && (((uintptr_t)w2 & 15) || ((uintptr_t)shift & 15))) return AWSEG_EALIGN;       // 16-byte loads in the fused-head epilogue
     if (act != AWSEG_ACT_NONE && act != AWSEG_ACT_RELU) return AWSEG_ERANGE;
     if (((uintptr_t)x & 15) || ((uintptr_t)u_split & 15)) return AWSEG_EALIGN;
     if ((int64_t)height * width * cin >= (int64_t)1 << 29 || (int64_t)height * width * cout >= (int64_t)1 << 29 ||

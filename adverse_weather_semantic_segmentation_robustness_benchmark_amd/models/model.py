@@ -205,13 +205,16 @@ class SegFormerModel(nn.Module):
                 raise N.AwsegError("eval-mode forward runs HIP kernels: it needs CUDA (HIP) tensors; no CPU fallback exists")
             with torch.no_grad(), ops.precision(self.compute_dtype):
                 return self._forward_hip(fused.mit_features_nhwc(self.segformer, x), H, W)
-        feats = self.encode(x)
+        return self.heads_forward(self.encode(x), H, W)
+
+    def heads_forward(self, feats: torch.Tensor, H: int, W: int) -> Dict[str, torch.Tensor]:
+        """The two heads on the encoder output [B,C,h,w] in the module's current mode, with autograd (model.py:209-221)."""
         hh, ww = feats.shape[2], feats.shape[3]
-        if (x.is_cuda and getattr(self, "fused_train", True) and
+        if (feats.is_cuda and getattr(self, "fused_train", True) and
                 ops.upconv3x3_train_supported(self.feature_dim, 256, hh, ww, H, W)):
-            # training on the GPU: the first convolution of each head — conv3x3(interpolate(f)), model.py:209-214 / :219-221 — as
-            # one small GEMM at the encoder's resolution + a HIP kernel, forward and backward (ops._UpConv3x3); BatchNorm (batch
-            # statistics), ReLU, Dropout2d and the remaining layers are the reference's modules on the result
+            # on the GPU: the first convolution of each head — conv3x3(interpolate(f)), model.py:209-214 / :219-221 — as one small
+            # GEMM at the encoder's resolution + a HIP kernel, forward and backward (ops._UpConv3x3); BatchNorm (batch
+            # statistics in training), ReLU, Dropout2d and the remaining layers are the reference's modules on the result
             tok = feats.permute(0, 2, 3, 1)
             head = self.segmentation_head
             results = {"segmentation": head[1:](ops.upconv3x3_train(tok, head[0].weight, head[0].bias, H, W))}

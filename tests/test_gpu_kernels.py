@@ -997,7 +997,8 @@ def test_im2col_patch_gemm_is_the_convolution(ops, case):
     assert y.shape == ref.shape and (y - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("case", [(2, 4, 6, 64, 128, 128, 192), (1, 5, 8, 32, 256, 160, 256), (1, 3, 4, 16, 32, 100, 130)])
+@pytest.mark.parametrize("case", [(2, 4, 6, 64, 128, 128, 192), (1, 5, 8, 32, 256, 160, 256), (1, 3, 4, 16, 32, 100, 130),
+                                  (2, 5, 8, 256, 256, 160, 256), (2, 5, 8, 256, 128, 160, 256)])
 def test_upconv3x3_train_forward_and_adjoint_vs_torch_autograd(ops, case):
     """ops.upconv3x3_train (awseg_upconv3x3_linear + awseg_upconv3x3_adjoint) against torch autograd of the expression it
     replaces in training — F.conv2d(F.interpolate(f, (H, W), bilinear, align_corners=False), w, b, padding=1), PKG/models/

@@ -401,14 +401,16 @@ def test_eval_forward_is_a_pure_function_of_the_frame(P):
 
 
 @pytest.mark.parametrize("size", [(128, 192), (160, 256)])
-def test_segformer_training_forward_backward_on_hip_matches_the_as_written_graph(P, size):
-    """BASELINE config 4 / VERDICT r1 #6: the training forward of SegFormerModel runs conv3x3(interpolate(f)) — the first
-    layer of both heads (PKG/models/model.py:209-214, :219-221) — as ops._UpConv3x3 (HIP forward + HIP adjoint backward).
-    Outputs, input gradient and EVERY parameter gradient are priced against the as-written graph (F.interpolate -> Conv2d,
-    batch-statistics BatchNorm) evaluated in FLOAT64 on the CPU, next to the same as-written graph in float32 on the GPU:
-    the HIP path may not be further from float64 than a small multiple of what the float32 as-written graph is (gradients
-    through batch-statistics BatchNorm and 8 encoder blocks differ by ~1e-4..1e-3 between any two float32 summation orders),
-    and outputs must agree to 1e-4 of their magnitude.  Dropout is switched off so the three runs see the same function."""
+def test_segformer_training_heads_on_hip_match_the_as_written_graph(P, size):
+    """BASELINE config 4 / VERDICT r1 #6: in training SegFormerModel runs conv3x3(interpolate(f)) — the first layer of both
+    heads (PKG/models/model.py:209-214, :219-221) — as ops._UpConv3x3 (HIP forward + HIP adjoint backward) in front of the
+    reference's BatchNorm (batch statistics) / ReLU / Dropout2d / convolution modules.  On well-conditioned encoder features:
+    outputs, the gradient with respect to the features and every head parameter gradient against the as-written graph
+    (F.interpolate -> Conv2d -> ...) with the same weights: <= 1e-4 of each tensor's magnitude, or — where batch-statistics
+    BatchNorm's backward cancels leading terms and ANY float32 evaluation is further than that from the truth — no further
+    from the as-written graph in FLOAT64 (CPU) than 4x what the as-written float32 graph is.  Dropout off (one function for
+    all three runs).  (A random-init ENCODER in front would not do: its output is nearly constant over the image, BatchNorm
+    then divides by a variance at rounding level and any two float32 evaluations differ by per cent.)"""
     import copy
     H, W = size
     torch.manual_seed(31)
@@ -416,38 +418,63 @@ def test_segformer_training_forward_backward_on_hip_matches_the_as_written_graph
     for mod in m.modules():
         if isinstance(mod, (torch.nn.Dropout, torch.nn.Dropout2d)):
             mod.p = 0.0
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            # ReLU is not differentiable at 0: with ~1e7 activations a handful sit within rounding distance of it and flip their
+            # mask between ANY two float32 evaluations, which moves a per-channel gradient sum by one element (measured 4e-3 of
+            # the sum).  A positive BatchNorm shift keeps every pre-activation away from 0, so the comparison prices the
+            # arithmetic and not the flips.
+            torch.nn.init.constant_(mod.bias, 8.0)
     m64 = copy.deepcopy(m).double().train()
     m = m.cuda().train()
-    x0 = torch.randn(2, 3, H, W)
+    f0 = torch.randn(2, 256, H // 32, W // 32)
     gseg, gdep = torch.randn(2, 19, H, W), torch.randn(2, 1, H, W)
 
     def run(model, fused, dev, dtype):
         model.fused_train = fused
         model.zero_grad(set_to_none=True)
-        x = x0.to(dev, dtype).requires_grad_(True)
-        out = model(x)
+        f = f0.to(dev, dtype).requires_grad_(True)
+        out = model.heads_forward(f, H, W)
         ((out["segmentation"] * gseg.to(dev, dtype)).sum() + (out["depth"] * gdep.to(dev, dtype)).sum()).backward()
         res = {"out." + k: v.detach().double().cpu() for k, v in out.items()}
-        res["d input"] = x.grad.double().cpu()
+        res["d features"] = f.grad.double().cpu()
         res.update({"grad " + n: p.grad.double().cpu() for n, p in model.named_parameters() if p.grad is not None})
         return res
 
-    r_hip = run(m, True, "cuda", torch.float32)
-    r_f32 = run(m, False, "cuda", torch.float32)
-    r_f64 = run(m64, False, "cpu", torch.float64)
-    assert set(r_hip) == set(r_f64) and "grad segmentation_head.0.weight" in r_hip and "grad depth_head.depth_head.0.bias" in r_hip
-    gmax = max(v.abs().max().item() for k, v in r_f64.items() if k.startswith("grad "))
-    worst_h = worst_t = 0.0
-    for k, ref in r_f64.items():
+    r_h, r_t, r_64 = run(m, True, "cuda", torch.float32), run(m, False, "cuda", torch.float32), run(m64, False, "cpu", torch.float64)
+    assert set(r_h) == set(r_64) and "grad segmentation_head.0.weight" in r_h and "grad depth_head.depth_head.0.bias" in r_h
+    gmax = max(v.abs().max().item() for k, v in r_64.items() if k.startswith("grad "))
+    worst = worst_t = 0.0
+    bad = []
+    for k, ref in r_64.items():
         mag = ref.abs().max().item()
-        scale = max(mag, 1e-3 * gmax) if k.startswith("grad ") else mag      # gradients that are ~0 in exact arithmetic: noise
-        e_h = (r_hip[k] - ref).abs().max().item() / scale
-        e_t = (r_f32[k] - ref).abs().max().item() / scale
-        worst_h, worst_t = max(worst_h, e_h), max(worst_t, e_t)
-        # (the kernels themselves are checked to 1e-6 against float64 autograd of the expression they replace:
-        # test_gpu_kernels.py::test_upconv3x3_train_forward_and_adjoint_vs_torch_autograd; at model level a random-init
-        # encoder under batch-statistics BatchNorm puts ANY two float32 evaluations 1e-3 .. 1e-2 apart, outputs included)
-        assert e_h <= 4 * e_t + 2e-5, f"{k}: HIP path {e_h:.3e} vs float64, as-written float32 graph {e_t:.3e}"
-    print(f"training forward/backward {size}: worst relative error vs float64: HIP path {worst_h:.2e}, as-written float32 graph {worst_t:.2e} "
-          f"({len(r_f64)} tensors)")
-    assert worst_h < 4 * worst_t + 1e-4
+        if k in ("grad segmentation_head.0.bias", "grad depth_head.depth_head.0.bias", "grad depth_head.depth_head.4.bias"):
+            # a convolution bias in front of batch-statistics BatchNorm has ZERO gradient in exact arithmetic
+            assert r_h[k].abs().max().item() < 1e-2 * gmax and r_t[k].abs().max().item() < 1e-2 * gmax, k
+            continue
+        scale = max(mag, 1e-4 * gmax) if k.startswith("grad ") else mag
+        e_h, e_t = (r_h[k] - ref).abs().max().item() / scale, (r_t[k] - ref).abs().max().item() / scale
+        worst, worst_t = max(worst, e_h), max(worst_t, e_t)
+        print(f"  {k}: HIP {e_h:.2e}  as-written f32 {e_t:.2e}  (|ref| {mag:.2e})")
+        bad = bad + [k] if e_h > max(1e-4, 4 * e_t) else bad
+    assert not bad, bad
+    print(f"training heads {size}: worst relative error vs float64: HIP path {worst:.2e}, as-written float32 graph {worst_t:.2e} ({len(r_64)} tensors)")
+
+
+def test_segformer_training_step_through_the_whole_model_runs_on_hip(P):
+    """Whole-model smoke test of the same path: loss decreases over a few SGD steps and every parameter receives a finite
+    gradient (values are pinned by the heads test above and by test_upconv3x3_train_forward_and_adjoint_vs_torch_autograd)."""
+    torch.manual_seed(32)
+    m = P.SegFormerModel(num_classes=19, include_depth=True, pretrained=False).cuda().train()
+    x = torch.randn(2, 3, 128, 192, device="cuda")
+    lab = torch.randint(0, 19, (2, 128, 192), device="cuda")
+    opt = torch.optim.SGD(m.parameters(), lr=0.05)
+    losses = []
+    for _ in range(4):
+        opt.zero_grad()
+        out = m(x)
+        loss = torch.nn.functional.cross_entropy(out["segmentation"], lab) + out["depth"].mean()
+        loss.backward()
+        assert all(p.grad is None or torch.isfinite(p.grad).all() for p in m.parameters())
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0], losses

@@ -75,6 +75,7 @@ SIGNATURES = {
     "awseg_density_workspace": (c_i64, [c_i64, c_i64]),
     "awseg_fog_density_from_depth": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_segformer_head_fused": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
+    "awseg_segformer_head_fused_split": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p, c_i, c_p, c_p]),
     "awseg_upconv3x3_bn_relu": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p]),
     "awseg_upconv3x3_linear": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "awseg_upconv3x3_adjoint": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
@@ -126,6 +127,16 @@ def call(name: str, *args) -> None:
     fn = getattr(lib(), name)
     rc = fn(*args) if launch_hook is None else launch_hook(name, lambda: fn(*args), args)
     check(rc, name)
+
+
+def try_call(name: str, *args, allow=(-2,)) -> int:
+    """call() for launchers that may decline a shape: return codes in `allow` (default AWSEG_ERANGE) are handed back to the
+    caller, which then uses the general entry point; anything else non-zero raises."""
+    fn = getattr(lib(), name)
+    rc = fn(*args) if launch_hook is None else launch_hook(name, lambda: fn(*args), args)
+    if rc != 0 and rc not in allow:
+        check(rc, name)
+    return rc
 
 
 def ptr(t):

@@ -116,6 +116,66 @@ void dwconv3x3_nhwc_strip_kernel(const float* __restrict__ x, int64_t batch, int
     }
 }
 
+// Two output rows per lane: the rolling window holds 4 input rows x 3 columns, a new column costs 4 loads and
+// finishes 2 outputs — 2.5 loads per output over a strip of 8 instead of 3.75 (the one-row form is bound by the
+// vector-memory pipe, not by HBM: every input row is fetched by the lanes of three output rows).
+template <int SX>
+__global__ __launch_bounds__(kThreads)
+void dwconv3x3_nhwc_strip2_kernel(const float* __restrict__ x, int64_t batch, int H, int W, int C,
+                                  const float* __restrict__ w9, const float* __restrict__ bias, int act,
+                                  float* __restrict__ out)
+{
+    const int c4n = C / 4;
+    const int nsx = (W + SX - 1) / SX, nry = (H + 1) / 2;
+    const int64_t total = batch * nry * nsx * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int xs = (int)(t % nsx); t /= nsx;
+        const int yy = (int)(t % nry) * 2;
+        const int64_t b = t / nry;
+        const float* xb = x + b * (int64_t)H * W * C + c4 * 4;
+        float4 k[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) k[j] = *reinterpret_cast<const float4*>(w9 + j * C + c4 * 4);
+        const float4 bz = bias ? *reinterpret_cast<const float4*>(bias + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto col = [&](int sx, float4* v) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int sy = yy + r - 1;
+                v[r] = (sx >= 0 && sx < W && sy >= 0 && sy < H) ? *reinterpret_cast<const float4*>(xb + ((int64_t)sy * W + sx) * C) : zero;
+            }
+        };
+        const int x0 = xs * SX;
+        float4 c0[4], c1[4], c2[4];
+        col(x0 - 1, c0); col(x0, c1);
+#pragma unroll
+        for (int u = 0; u < SX; ++u) {
+            const int xx = x0 + u;
+            col(xx + 1, c2);
+            if (xx < W) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o) {
+                    if (yy + o >= H) break;
+                    float4 acc = bz;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) {
+                        const float4 a = c0[ky + o], m = c1[ky + o], d = c2[ky + o];
+                        const float4 ka = k[ky * 3], km = k[ky * 3 + 1], kd = k[ky * 3 + 2];
+                        acc.x = fmaf(a.x, ka.x, acc.x); acc.y = fmaf(a.y, ka.y, acc.y); acc.z = fmaf(a.z, ka.z, acc.z); acc.w = fmaf(a.w, ka.w, acc.w);
+                        acc.x = fmaf(m.x, km.x, acc.x); acc.y = fmaf(m.y, km.y, acc.y); acc.z = fmaf(m.z, km.z, acc.z); acc.w = fmaf(m.w, km.w, acc.w);
+                        acc.x = fmaf(d.x, kd.x, acc.x); acc.y = fmaf(d.y, kd.y, acc.y); acc.z = fmaf(d.z, kd.z, acc.z); acc.w = fmaf(d.w, kd.w, acc.w);
+                    }
+                    *reinterpret_cast<float4*>(out + ((b * H + yy + o) * (int64_t)W + xx) * C + c4 * 4) = act4(acc, act);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { c0[r] = c1[r]; c1[r] = c2[r]; }
+        }
+    }
+}
+
 // DeepLabV3+ decoder (smp DeepLabV3PlusDecoder.forward: up(aspp) -> cat with the 48-channel skip -> SeparableConv2d):
 // the depthwise 3x3 of block2 applied to cat(UpsamplingBilinear2d(x4, align_corners=True)(a), hi) WITHOUT
 // materialising the upsampled map or the concatenation (1.07 + 1.27 GB per batch at 1024x2048).  Same strip
@@ -125,14 +185,15 @@ template <int SX>
 __global__ __launch_bounds__(kThreads)
 void dwconv3x3_upcat_strip_kernel(const float* __restrict__ a, int h, int w, int Ca, const float* __restrict__ hi, int Ch,
                                   int64_t batch, int H, int W, float ry, float rx, const float* __restrict__ w9,
-                                  float* __restrict__ out)
+                                  float* __restrict__ out, int c4_lo)
 {
     const int C = Ca + Ch, c4n = C / 4, ca4 = Ca / 4;
     const int nsx = (W + SX - 1) / SX;
-    const int64_t total = batch * H * nsx * c4n;
+    const int c4w = c4n - c4_lo;                                  // this launch covers channel quads [c4_lo, c4n)
+    const int64_t total = batch * H * nsx * c4w;
     for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
-        const int c4 = (int)(i % c4n);
-        int64_t t = i / c4n;
+        const int c4 = c4_lo + (int)(i % c4w);
+        int64_t t = i / c4w;
         const int xs = (int)(t % nsx); t /= nsx;
         const int yy = (int)(t % H);
         const int64_t b = t / H;
@@ -219,6 +280,94 @@ void dwconv3x3_upcat_strip_kernel(const float* __restrict__ a, int h, int w, int
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; }
         }
+    }
+}
+
+// The upsampled channels of the same operation with the source cells staged in LDS.  Block = one output row x 32 columns
+// x 64 channel quads (4 strips of 8 columns).  The <= n_src source columns the 34 tap columns touch are blended
+// vertically ONCE per (source column, tap row) and stored as [source column][tap row][quad] float4; a tap column is then
+// two 16-byte LDS reads per tap row at a computed address (lane stride 16 B: conflict-free) and one horizontal blend.
+// (The strip kernel above reloads its 12 corner values behind a data-dependent branch inside the serial column loop —
+// nothing can be prefetched across it: 18 % of the HBM roof.)  Same expressions, same order: bit-identical results.
+constexpr int kUpTile = 32, kUpQuads = 64;
+template <int SX>
+__global__ __launch_bounds__(kThreads)
+void dwconv3x3_upcat_lds_kernel(const float* __restrict__ a, int h, int w, int Ca, int Ch, int H, int W, float ry, float rx,
+                                const float* __restrict__ w9, float* __restrict__ out, int n_src)
+{
+    static_assert(SX * (kThreads / kUpQuads) == kUpTile, "4 strips of 8 columns");
+    extern __shared__ float4 s_cell[];                             // [n_src][3][kUpQuads]
+    const int C = Ca + Ch, qg = Ca / 4 / kUpQuads;
+    const int b = blockIdx.z / qg, g = blockIdx.z - b * qg;
+    const int yy = blockIdx.y, x0 = blockIdx.x * kUpTile;
+    const int q = threadIdx.x % kUpQuads, strip = threadIdx.x / kUpQuads;
+    const int c = (g * kUpQuads + q) * 4;
+    int r0[3], r1[3]; float l1[3], l0[3]; bool rok[3];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int sy = yy + ky - 1;
+        rok[ky] = sy >= 0 && sy < H;
+        const float f = ry * (float)(rok[ky] ? sy : 0);
+        const int i0 = (int)f;
+        r0[ky] = i0; r1[ky] = i0 + (i0 < h - 1 ? 1 : 0);
+        l1[ky] = f - (float)i0; l0[ky] = 1.0f - l1[ky];
+    }
+    const int jbase = (int)(rx * (float)(x0 > 0 ? x0 - 1 : 0));
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < n_src * 3 * kUpQuads; i += kThreads) {
+        const int iq = i % kUpQuads, t = i / kUpQuads;
+        const int ky = t % 3;
+        int j = jbase + t / 3;
+        if (j > w - 1) j = w - 1;
+        const float* p = a + (int64_t)b * h * w * Ca + (g * kUpQuads + iq) * 4;
+        const int ra = ky == 0 ? r0[0] : (ky == 1 ? r0[1] : r0[2]), rb = ky == 0 ? r1[0] : (ky == 1 ? r1[1] : r1[2]);
+        const float la = ky == 0 ? l0[0] : (ky == 1 ? l0[1] : l0[2]), lb = ky == 0 ? l1[0] : (ky == 1 ? l1[1] : l1[2]);
+        const float4 v0 = *reinterpret_cast<const float4*>(p + ((int64_t)ra * w + j) * Ca);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + ((int64_t)rb * w + j) * Ca);
+        s_cell[i] = make_float4(la * v0.x + lb * v1.x, la * v0.y + lb * v1.y, la * v0.z + lb * v1.z, la * v0.w + lb * v1.w);
+    }
+    float4 k[9];
+#pragma unroll
+    for (int j = 0; j < 9; ++j) k[j] = *reinterpret_cast<const float4*>(w9 + j * C + c);
+    __syncthreads();
+    auto col = [&](int sx, float4* v) {
+        const bool cok = sx >= 0 && sx < W;
+        const float f = rx * (float)(cok ? sx : 0);
+        const int j0 = (int)f, j1 = j0 + (j0 < w - 1 ? 1 : 0);
+        const float m1 = f - (float)j0, m0 = 1.0f - m1;
+        const float4* c0p = s_cell + (j0 - jbase) * 3 * kUpQuads + q;
+        const float4* c1p = s_cell + (j1 - jbase) * 3 * kUpQuads + q;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            if (cok && rok[ky]) {
+                const float4 a0 = c0p[ky * kUpQuads], a1 = c1p[ky * kUpQuads];
+                v[ky] = make_float4(m0 * a0.x + m1 * a1.x, m0 * a0.y + m1 * a1.y, m0 * a0.z + m1 * a1.z, m0 * a0.w + m1 * a1.w);
+            } else {
+                v[ky] = zero;
+            }
+        }
+    };
+    const int xs = x0 + strip * SX;
+    float4 c0[3], c1[3], c2[3];
+    col(xs - 1, c0); col(xs, c1);
+#pragma unroll
+    for (int u = 0; u < SX; ++u) {
+        const int xx = xs + u;
+        col(xx + 1, c2);
+        if (xx < W) {
+            float4 acc = zero;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const float4 p = c0[ky], m = c1[ky], d = c2[ky];
+                const float4 ka = k[ky * 3], km = k[ky * 3 + 1], kd = k[ky * 3 + 2];
+                acc.x = fmaf(p.x, ka.x, acc.x); acc.y = fmaf(p.y, ka.y, acc.y); acc.z = fmaf(p.z, ka.z, acc.z); acc.w = fmaf(p.w, ka.w, acc.w);
+                acc.x = fmaf(m.x, km.x, acc.x); acc.y = fmaf(m.y, km.y, acc.y); acc.z = fmaf(m.z, km.z, acc.z); acc.w = fmaf(m.w, km.w, acc.w);
+                acc.x = fmaf(d.x, kd.x, acc.x); acc.y = fmaf(d.y, kd.y, acc.y); acc.z = fmaf(d.z, kd.z, acc.z); acc.w = fmaf(d.w, kd.w, acc.w);
+            }
+            *reinterpret_cast<float4*>(out + (((int64_t)b * H + yy) * (int64_t)W + xx) * C + c) = acc;
+        }
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) { c0[ky] = c1[ky]; c1[ky] = c2[ky]; }
     }
 }
 
@@ -389,6 +538,15 @@ AWSEG_API int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, in
     if (!x || !w9 || !out || batch < 1 || height < 1 || width < 1 || channels < 4 || (channels & 3) || dilation < 1) return AWSEG_EINVAL;
     if (act < 0 || act > 2 || x == out) return AWSEG_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)w9 & 15) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15))) return AWSEG_EALIGN;
+    static const bool one_row = getenv("AWSEG_DW_ONE_ROW") != nullptr;
+    if (dilation == 1 && width >= 8 && height >= 2 && !one_row) {
+        constexpr int SX = 8;
+        const int64_t total = batch * ((height + 1) / 2) * ((width + SX - 1) / SX) * (channels / 4);
+        hipLaunchKernelGGL((dwconv3x3_nhwc_strip2_kernel<SX>), dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream),
+                           x, batch, height, width, channels, w9, bias, act, out);
+        AWSEG_LAUNCH_CHECK();
+        return 0;
+    }
     if (dilation == 1 && width >= 8) {
         constexpr int SX = 8;
         const int64_t total = batch * height * ((width + SX - 1) / SX) * (channels / 4);
@@ -452,9 +610,33 @@ AWSEG_API int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_wid
     const float ry = height > 1 ? (float)(a_height - 1) / (float)(height - 1) : 0.f;
     const float rx = width > 1 ? (float)(a_width - 1) / (float)(width - 1) : 0.f;
     constexpr int SX = 8;
-    const int64_t items = batch * height * ((width + SX - 1) / SX) * ((a_channels + hi_channels) / 4);
+    int c4_lo = 0;
+    static const bool no_lds = getenv("AWSEG_UPCAT_STRIP") != nullptr;
+    const int ca4 = a_channels / 4;
+    if (!no_lds && ca4 % kUpQuads == 0 && batch * (ca4 / kUpQuads) <= 65535 && height <= 65535) {
+        // source columns a 32-column tile (+ its two halo columns) touches: the device's own float expressions
+        int n_src = 1;
+        for (int x0 = 0; x0 < width; x0 += kUpTile) {
+            const int first = (int)(rx * (float)(x0 > 0 ? x0 - 1 : 0));
+            const int sx = x0 + kUpTile < width - 1 ? x0 + kUpTile : width - 1;
+            int last = (int)(rx * (float)sx);
+            last += last < a_width - 1 ? 1 : 0;
+            if (last - first + 1 > n_src) n_src = last - first + 1;
+        }
+        const size_t lds = (size_t)n_src * 3 * kUpQuads * sizeof(float4);
+        if (lds <= 64 * 1024) {
+            auto kern = dwconv3x3_upcat_lds_kernel<SX>;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AWSEG_EINVAL;
+            dim3 grid((width + kUpTile - 1) / kUpTile, height, (unsigned)(batch * (ca4 / kUpQuads)));
+            hipLaunchKernelGGL(kern, grid, dim3(kThreads), lds, awseg_s(stream), a, a_height, a_width, a_channels, hi_channels, height,
+                               width, ry, rx, w9, out, n_src);
+            AWSEG_LAUNCH_CHECK();
+            c4_lo = ca4;
+        }
+    }
+    const int64_t items = batch * height * ((width + SX - 1) / SX) * ((a_channels + hi_channels) / 4 - c4_lo);
     hipLaunchKernelGGL((dwconv3x3_upcat_strip_kernel<SX>), dim3(awseg_grid_1d(items, kThreads)), dim3(kThreads), 0, awseg_s(stream),
-                       a, a_height, a_width, a_channels, hi, hi_channels, batch, height, width, ry, rx, w9, out);
+                       a, a_height, a_width, a_channels, hi, hi_channels, batch, height, width, ry, rx, w9, out, c4_lo);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -426,6 +426,255 @@ void head_mfma_classify_kernel(const float* __restrict__ g9, int h, int w, int H
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// v4: the classifier form on the f16 matrix cores with SPLIT operands.  v_mfma_f32_32x32x16_f16 issues 16x the
+// multiply-adds of v_mfma_f32_32x32x2_f32 per cycle; an operand x is carried as hi = f16(x) and lo = f16(x - hi) and a
+// product as hi*hi + lo*hi + hi*lo (float32 accumulation, the lo*lo term is 2^-22 of the product).
+//   GEMM 1   K = 12 slots padded to one 16-deep step: lane (hh, row) holds slots {2j + hh, j < 6} in halves 0..5 of its
+//            operand vector, zeros in 6..7, for A (the vertically blended cells T) and for B (the horizontal weights) alike.
+//            Horizontal weights that are exact in f16 (power-of-two upsampling ratios) make the hi*lo product vanish:
+//            block-uniform test, two MFMAs instead of three.
+//   GEMM 2   the accumulator tile of GEMM 1 is the B operand again: registers 0..7 / 8..15 of a lane are the k = 8 hh + j
+//            values of the two 16-deep steps; W2 is split once per block into LDS in that k order.
+// Per 32 pixels: OT * (2..3 + 6) MFMAs of 32 cycles instead of OT * 22 of 64.
+// Operand range: every |T| and every activation a wave converts is tracked (v_max3); a row whose maximum reaches 2^15 — f16
+// would overflow — is recomputed by the same wave on the float32 instruction (the v3 arithmetic, W2 read from memory).
+// ---------------------------------------------------------------------------------------
+typedef _Float16 hd8 __attribute__((ext_vector_type(8)));
+typedef unsigned hu4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void head_split_pair(float a, float b, unsigned& hi, unsigned& lo)
+{
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo) : "v"(a), "v"(b), "v"(hi));
+}
+__device__ __forceinline__ float head_max3(float m, float a, float b)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+
+template <int OT>
+__global__ __launch_bounds__(512, 1)
+void head_split_classify_kernel(const float* __restrict__ g9, int h, int w, int H, int W, int R,
+                                const float* __restrict__ shift, const float* __restrict__ w2,
+                                const float* __restrict__ b2, int cout, float* __restrict__ out)
+{
+    static_assert(OT % 4 == 0, "groups of four o-tiles");
+    constexpr int CM = OT * 32, NG = OT / 4, kT = 512;
+    extern __shared__ float smem[];
+    float* Gl = smem;                           // [3][4][9][CM]
+    float* s_sh = smem + 108 * CM;              // [OT][2 (hh)][16 (acc reg)]
+    hu4* s_w2 = reinterpret_cast<hu4*>(s_sh + OT * 32);   // [OT][2 (k step)][2 (hi, lo)][64 lanes] x 8 halves
+    float* s_b2 = reinterpret_cast<float*>(s_w2 + OT * 256);   // [32]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lo = lane & 31, hh = lane >> 5;
+    const int b = blockIdx.z, y0 = blockIdx.y * R, x0 = blockIdx.x * 32;
+    const float sh = (float)h / (float)H, sw = (float)w / (float)W;
+    const int ibase = bilinear_src(y0 > 0 ? y0 - 1 : 0, sh, h).i0;
+    const int jbase = bilinear_src(x0 > 0 ? x0 - 1 : 0, sw, w).i0;
+    auto chan = [](int ot, int i) { return (ot >> 2) * 128 + 4 * i + (ot & 3); };
+
+    const float* g = g9 + (int64_t)b * h * w * 9 * CM;
+    constexpr int CELL4 = 9 * CM / 4;
+    for (int i = tid; i < 12 * CELL4; i += kT) {
+        int cell = i / CELL4, q = i - cell * CELL4;
+        int ci = ibase + (cell >> 2), cj = jbase + (cell & 3);
+        if (ci > h - 1) ci = h - 1;
+        if (cj > w - 1) cj = w - 1;
+        reinterpret_cast<float4*>(Gl)[i] = reinterpret_cast<const float4*>(g + ((int64_t)ci * w + cj) * 9 * CM)[q];
+    }
+    for (int i = tid; i < OT * 32; i += kT) {
+        const int r = i & 15, h2 = (i >> 4) & 1, ot = i >> 5;
+        s_sh[i] = shift[chan(ot, (r & 3) + 8 * (r >> 2) + 4 * h2)];
+    }
+    for (int i = tid; i < OT * 2 * 64; i += kT) {
+        const int ln = i & 63, ks = (i >> 6) & 1, ot = i >> 7;
+        const int cls = ln & 31, kk = ln >> 5;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int row = (j & 3) + 8 * (j >> 2) + 16 * ks + 4 * kk;       // accumulator row of register 8 ks + j
+            v[j] = (cls < cout) ? w2[(int64_t)cls * CM + chan(ot, row)] : 0.f;
+        }
+        hu4 Hh, Ll; unsigned a, c;
+        head_split_pair(v[0], v[1], a, c); Hh[0] = a; Ll[0] = c;
+        head_split_pair(v[2], v[3], a, c); Hh[1] = a; Ll[1] = c;
+        head_split_pair(v[4], v[5], a, c); Hh[2] = a; Ll[2] = c;
+        head_split_pair(v[6], v[7], a, c); Hh[3] = a; Ll[3] = c;
+        s_w2[((ot * 2 + ks) * 2 + 0) * 64 + ln] = Hh;
+        s_w2[((ot * 2 + ks) * 2 + 1) * 64 + ln] = Ll;
+    }
+    float cx[6];
+    int lbase[6];
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+        const int k = 2 * s + hh, kx = k >> 2, c = k & 3;
+        const int xx = x0 + lo + kx - 1;
+        float v = 0.f;
+        if (xx >= 0 && xx < W && x0 + lo < W) {
+            src_idx sx = bilinear_src(xx, sw, w);
+            if (sx.i0 - jbase == c) v += sx.l0;
+            if (sx.i1 - jbase == c) v += sx.l1;
+        }
+        cx[s] = v;
+        lbase[s] = (c * 9 + kx) * CM + lo * 4;
+    }
+    hu4 cxh, cxl;
+    {
+        unsigned a, c;
+        head_split_pair(cx[0], cx[1], a, c); cxh[0] = a; cxl[0] = c;
+        head_split_pair(cx[2], cx[3], a, c); cxh[1] = a; cxl[1] = c;
+        head_split_pair(cx[4], cx[5], a, c); cxh[2] = a; cxl[2] = c;
+        cxh[3] = 0u; cxl[3] = 0u;
+    }
+    // lo halves are +0 or -0 when a weight is exact in f16
+    const bool cx_exact = __builtin_amdgcn_ballot_w64(((cxl[0] | cxl[1] | cxl[2]) & 0x7FFF7FFFu) != 0u) == 0ull;
+    if (tid < 32) s_b2[tid] = tid < cout ? b2[tid] : 0.f;
+    __syncthreads();
+#define HMFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(hd8, A), __builtin_bit_cast(hd8, B), C, 0, 0, 0)
+
+    const int64_t HW = (int64_t)H * W;
+    for (int ry = wv; ry < R; ry += kT / 64) {
+        const int y = y0 + ry;
+        if (y >= H) break;
+        int ub[6]; float lw[6];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int yy = y + ky - 1;
+            const bool ok = (yy >= 0 && yy < H);
+            src_idx sy = bilinear_src(ok ? yy : 0, sh, h);
+            const int r0 = __builtin_amdgcn_readfirstlane(sy.i0 - ibase), r1 = __builtin_amdgcn_readfirstlane(sy.i1 - ibase);
+            ub[2 * ky] = (r0 * 36 + ky * 3) * CM;
+            ub[2 * ky + 1] = (r1 * 36 + ky * 3) * CM;
+            lw[2 * ky] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ok ? sy.l0 : 0.f)));
+            lw[2 * ky + 1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ok ? sy.l1 : 0.f)));
+        }
+        auto gather4 = [&](int gi, float (*t)[6]) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s) {
+                const float* base = Gl + lbase[s] + gi * 128;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const float4 a = *reinterpret_cast<const float4*>(base + ub[j]);
+                    v.x = fmaf(lw[j], a.x, v.x); v.y = fmaf(lw[j], a.y, v.y);
+                    v.z = fmaf(lw[j], a.z, v.z); v.w = fmaf(lw[j], a.w, v.w);
+                }
+                t[0][s] = v.x; t[1][s] = v.y; t[2][s] = v.z; t[3][s] = v.w;
+            }
+        };
+        auto shift_init = [&](int ot) {
+            f32x16 a;
+            const float4* sp = reinterpret_cast<const float4*>(s_sh + (ot * 2 + hh) * 16);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { const float4 v = sp[q]; a[4 * q] = v.x; a[4 * q + 1] = v.y; a[4 * q + 2] = v.z; a[4 * q + 3] = v.w; }
+            return a;
+        };
+        float amax = 0.f;
+        f32x16 acc2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+        auto gemm1 = [&](int ot, const float* t) {
+            f32x16 a = shift_init(ot);
+            hu4 th, tl; unsigned p, q;
+            head_split_pair(t[0], t[1], p, q); th[0] = p; tl[0] = q;
+            head_split_pair(t[2], t[3], p, q); th[1] = p; tl[1] = q;
+            head_split_pair(t[4], t[5], p, q); th[2] = p; tl[2] = q;
+            th[3] = 0u; tl[3] = 0u;
+            amax = head_max3(amax, t[0], t[1]); amax = head_max3(amax, t[2], t[3]); amax = head_max3(amax, t[4], t[5]);
+            a = HMFMA(th, cxh, a);
+            a = HMFMA(tl, cxh, a);
+            if (!cx_exact) a = HMFMA(th, cxl, a);
+            return a;
+        };
+        auto finish = [&](int ot, f32x16& acc) {
+            const hu4* wp = s_w2 + ot * 256 + lane;
+            const hu4 wh0 = wp[0], wl0 = wp[64], wh1 = wp[128], wl1 = wp[192];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
+            hu4 mh0, ml0, mh1, ml1; unsigned p, q;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                head_split_pair(acc[2 * j], acc[2 * j + 1], p, q); mh0[j] = p; ml0[j] = q;
+                head_split_pair(acc[8 + 2 * j], acc[9 + 2 * j], p, q); mh1[j] = p; ml1[j] = q;
+                amax = head_max3(amax, acc[2 * j], acc[2 * j + 1]);
+                amax = head_max3(amax, acc[8 + 2 * j], acc[9 + 2 * j]);
+            }
+            acc2 = HMFMA(wh0, mh0, acc2);
+            acc2 = HMFMA(wl0, mh0, acc2);
+            acc2 = HMFMA(wh0, ml0, acc2);
+            acc2 = HMFMA(wh1, mh1, acc2);
+            acc2 = HMFMA(wl1, mh1, acc2);
+            acc2 = HMFMA(wh1, ml1, acc2);
+        };
+        float ta[4][6];
+        gather4(0, ta);
+#pragma unroll 1
+        for (int gi = 0; gi < NG; ++gi) {
+            f32x16 accA = gemm1(4 * gi, ta[0]);
+            f32x16 accB = gemm1(4 * gi + 1, ta[1]);
+            finish(4 * gi, accA);
+            accA = gemm1(4 * gi + 2, ta[2]);
+            finish(4 * gi + 1, accB);
+            accB = gemm1(4 * gi + 3, ta[3]);
+            if (gi + 1 < NG) gather4(gi + 1, ta);
+            finish(4 * gi + 2, accA);
+            finish(4 * gi + 3, accB);
+        }
+        // range guard: a value at or beyond 2^15 (or an infinity) anywhere in this row -> the row again, in float32
+        if (__builtin_amdgcn_ballot_w64(!(amax < 32768.f)) != 0ull) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+            gather4(0, ta);
+#pragma unroll 1
+            for (int gi = 0; gi < NG; ++gi) {
+#pragma unroll 1
+                for (int q = 0; q < 4; ++q) {
+                    const int ot = 4 * gi + q;
+                    f32x16 a = shift_init(ot);
+#pragma unroll
+                    for (int s = 0; s < 6; ++s) a = __builtin_amdgcn_mfma_f32_32x32x2f32(q == 0 ? ta[0][s] : (q == 1 ? ta[1][s] : (q == 2 ? ta[2][s] : ta[3][s])), cx[s], a, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a[r] = a[r] > 0.f ? a[r] : 0.f;
+#pragma unroll
+                    for (int s2 = 0; s2 < 16; ++s2) {
+                        const int o = chan(ot, (s2 & 3) + 8 * (s2 >> 2) + 4 * hh);
+                        const float wf = lo < cout ? w2[(int64_t)lo * CM + o] : 0.f;
+                        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wf, a[s2], acc2, 0, 0, 0);
+                    }
+                }
+                if (gi + 1 < NG) gather4(gi + 1, ta);
+            }
+        }
+        if (x0 + lo < W) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cls = (r & 3) + 8 * (r >> 2) + 4 * hh;
+                if (cls < cout) out[((int64_t)b * cout + cls) * HW + (int64_t)y * W + x0 + lo] = acc2[r] + s_b2[cls];
+            }
+        }
+    }
+#undef HMFMA
+}
+
+template <int OT>
+static int launch_head_split_classify(const float* g9, int64_t batch, int h, int w, int H, int W, int R, const float* shift,
+                                      const float* w2, const float* b2, int cout, float* out, hipStream_t s)
+{
+    constexpr int CM = OT * 32;
+    const size_t lds = (size_t)(108 * CM + OT * 32 + OT * 1024 + 32) * sizeof(float);
+    auto kern = head_split_classify_kernel<OT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    dim3 grid((W + 31) / 32, (H + R - 1) / R, (unsigned)batch);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, g9, h, w, H, W, R, shift, w2, b2, cout, out);
+    e = hipGetLastError();
+    return e == hipSuccess ? 0 : (int)e;
+}
+
 template <int OT>
 static int launch_head_classify(const float* g9, int64_t batch, int h, int w, int H, int W, int R, const float* shift,
                                 const float* w2, const float* b2, int cout, float* out, hipStream_t s)
@@ -585,6 +834,75 @@ void aspp_dw3_sliced_kernel(const float* __restrict__ x, int64_t batch, int h, i
     }
 }
 
+// Same units and XCD order; a lane owns (rate, row class j mod d, column, channel quad) and walks the rows j, j+d, j+2d, ...
+// of its class.  An input row s feeds the outputs s-d, s, s+d of the SAME class (tap rows 2, 1, 0), so the lane loads
+// each input row once — 3 loads (the three tap columns) per output instead of 9 — and carries two partial outputs:
+//   out[s-d] = (h0(s-2d) + h1(s-d)) + h2(s),   h_ky(s) = sum_kx k[ky][kx] * x[s][xx + (kx-1)d]   (zero outside the map).
+// The next row's loads are issued before the current row's arithmetic.
+__global__ __launch_bounds__(kThreads)
+void aspp_dw3_walk_kernel(const float* __restrict__ x, int64_t batch, int h, int w, int C,
+                          const float* __restrict__ wdw, int r0, int r1, int r2, float* __restrict__ out,
+                          int n_units, int blocks_per_unit, int slice_q)
+{
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int unit = (jb / blocks_per_unit) * 8 + xcd, blk = jb % blocks_per_unit;
+    if (unit >= n_units) return;
+    const int slices = (C / 4) / slice_q;
+    const int b = unit / slices, sl = unit - b * slices;
+    const int n0 = r0 < h ? r0 : h, n1 = r1 < h ? r1 : h, n2 = r2 < h ? r2 : h;
+    const int item = blk * kThreads + threadIdx.x;                 // (class, column, quad within the slice)
+    const int q = item % slice_q, t = item / slice_q;
+    const int xx = t % w, cls = t / w;
+    if (cls >= n0 + n1 + n2) return;
+    const int r = cls < n0 ? 0 : (cls < n0 + n1 ? 1 : 2);
+    const int j = cls - (r == 0 ? 0 : (r == 1 ? n0 : n0 + n1));
+    const int d = r == 0 ? r0 : (r == 1 ? r1 : r2);
+    const int c = (sl * slice_q + q) * 4;
+    const float* xb = x + (int64_t)b * h * w * C + c;
+    float* ob = out + (int64_t)r * (batch * (int64_t)h * w * C) + (int64_t)b * h * w * C + c;
+    float4 k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = *reinterpret_cast<const float4*>(wdw + ((int64_t)r * 9 + i) * C + c);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool okl = xx - d >= 0, okr = xx + d < w;
+    auto row = [&](int s, float4* v) {
+        const float* p = xb + ((int64_t)s * w + xx) * C;
+        v[0] = okl ? *reinterpret_cast<const float4*>(p - (int64_t)d * C) : zero;
+        v[1] = *reinterpret_cast<const float4*>(p);
+        v[2] = okr ? *reinterpret_cast<const float4*>(p + (int64_t)d * C) : zero;
+    };
+    auto hsum = [&](int ky, const float4* v) {
+        float4 a;
+        a.x = v[0].x * k[ky * 3].x; a.y = v[0].y * k[ky * 3].y; a.z = v[0].z * k[ky * 3].z; a.w = v[0].w * k[ky * 3].w;
+        a.x = fmaf(v[1].x, k[ky * 3 + 1].x, a.x); a.y = fmaf(v[1].y, k[ky * 3 + 1].y, a.y);
+        a.z = fmaf(v[1].z, k[ky * 3 + 1].z, a.z); a.w = fmaf(v[1].w, k[ky * 3 + 1].w, a.w);
+        a.x = fmaf(v[2].x, k[ky * 3 + 2].x, a.x); a.y = fmaf(v[2].y, k[ky * 3 + 2].y, a.y);
+        a.z = fmaf(v[2].z, k[ky * 3 + 2].z, a.z); a.w = fmaf(v[2].w, k[ky * 3 + 2].w, a.w);
+        return a;
+    };
+    // rows in groups of three: the nine loads of a group are in flight together (a lane's rows are megabytes apart, every
+    // load is a separate trip to L2 / the Infinity Cache, and one row at a time left the kernel latency-bound)
+    float4 accA = zero, accB = zero;
+    for (int s0 = j; s0 < h; s0 += 3 * d) {
+        float4 v[3][3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+            if (s0 + g * d < h) row(s0 + g * d, v[g]);
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+            const int s = s0 + g * d;
+            if (s >= h) break;
+            const float4 h0 = hsum(0, v[g]), h1 = hsum(1, v[g]), h2 = hsum(2, v[g]);
+            if (s != j)
+                *reinterpret_cast<float4*>(ob + ((int64_t)(s - d) * w + xx) * C) =
+                    make_float4(accA.x + h2.x, accA.y + h2.y, accA.z + h2.z, accA.w + h2.w);
+            accA = make_float4(accB.x + h1.x, accB.y + h1.y, accB.z + h1.z, accB.w + h1.w);
+            accB = h0;
+            if (s + d >= h) *reinterpret_cast<float4*>(ob + ((int64_t)s * w + xx) * C) = accA;
+        }
+    }
+}
+
 }  // namespace
 
 template <int OT, bool CLASSIFY>
@@ -650,6 +968,23 @@ AWSEG_API int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmi
                                          int cout, float* out, awseg_stream_t stream)
 {
     return head_dispatch(true, g9, batch, cmid, h, w, height, width, scale, shift, w2, b2, cout, out, 0, awseg_s(stream));
+}
+
+AWSEG_API int awseg_segformer_head_fused_split(const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
+                                               const float* scale, const float* shift, const float* w2, const float* b2,
+                                               int cout, float* out, awseg_stream_t stream)
+{
+    if (!g9 || !shift || !out || !w2 || !b2 || cout < 1 || cout > 32) return AWSEG_EINVAL;
+    if (batch < 1 || cmid < 1 || h < 1 || w < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (batch > 65535 || height > 65535) return AWSEG_ERANGE;
+    if ((int64_t)h * w * 9 * cmid > 0x7fffffffLL) return AWSEG_ERANGE;
+    if (scale || (cmid != 128 && cmid != 256)) return AWSEG_ERANGE;             // scale folded into g9 by the caller
+    if (((uintptr_t)g9 & 15)) return AWSEG_EALIGN;
+    const int R = mfma_tile_rows(h, w, height, width);
+    if (R <= 0) return AWSEG_ERANGE;                                             // geometry outside the 3 x 4 cell tile
+    hipStream_t s = awseg_s(stream);
+    if (cmid == 256) return launch_head_split_classify<8>(g9, batch, h, w, height, width, R, shift, w2, b2, cout, out, s);
+    return launch_head_split_classify<4>(g9, batch, h, w, height, width, R, shift, w2, b2, cout, out, s);
 }
 
 AWSEG_API int awseg_upconv3x3_bn_relu(const float* g9, int64_t batch, int cmid, int h, int w, int height, int width,
@@ -770,6 +1105,21 @@ AWSEG_API int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w,
     if (!x || !wdw || !out || batch < 1 || h < 1 || w < 1 || channels < 4 || (channels & 3)) return AWSEG_EINVAL;
     if (((uintptr_t)x & 15) || ((uintptr_t)wdw & 15) || ((uintptr_t)out & 15)) return AWSEG_EALIGN;
     static const bool flat = getenv("AWSEG_ASPP_FLAT") != nullptr;
+    static const bool taps = getenv("AWSEG_ASPP_TAPS") != nullptr;
+    if (rate0 < 1 || rate1 < 1 || rate2 < 1) return AWSEG_EINVAL;
+    const int64_t ncls = (int64_t)(rate0 < h ? rate0 : h) + (rate1 < h ? rate1 : h) + (rate2 < h ? rate2 : h);
+    static const int slice_q = getenv("AWSEG_ASPP_SLICE") ? atoi(getenv("AWSEG_ASPP_SLICE")) : kAsppSlice;
+    if (!flat && !taps && slice_q >= 1 && (channels / 4) % slice_q == 0 && ncls * w * slice_q < ((int64_t)1 << 30)) {
+        const int n_units = (int)batch * ((channels / 4) / slice_q);
+        const int bpu = (int)((ncls * w * slice_q + kThreads - 1) / kThreads);
+        const int64_t grid = (int64_t)((n_units + 7) / 8) * bpu * 8;
+        if (grid < ((int64_t)1 << 31)) {
+            hipLaunchKernelGGL(aspp_dw3_walk_kernel, dim3((unsigned)grid), dim3(kThreads), 0, awseg_s(stream), x, batch, h, w, channels,
+                               wdw, rate0, rate1, rate2, out, n_units, bpu, slice_q);
+            AWSEG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (!flat && (channels / 4) % kAsppSlice == 0 && (int64_t)h * w * kAsppSlice < ((int64_t)1 << 30)) {
         const int n_units = (int)batch * ((channels / 4) / kAsppSlice);
         const int bpu = (int)(((int64_t)h * w * kAsppSlice + kThreads - 1) / kThreads);

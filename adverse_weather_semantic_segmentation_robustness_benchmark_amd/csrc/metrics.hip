@@ -268,6 +268,70 @@ struct ece_cell { uint32_t cnt; uint32_t correct; unsigned long long sum_conf; }
 constexpr float kConfQ = 1073741824.0f;                          // 2^30
 __device__ __forceinline__ unsigned long long conf_q30(float conf) { return (unsigned long long)(conf * kConfQ); }
 
+// Bin of a confidence on the reference's float32 linspace, bins (lo, hi] (metrics.py:179-188): the uniform-grid guess is
+// checked against the staged edges with the reference's own comparisons and moved by one where rounding put it next door;
+// anything else (edges that are not a uniform grid) falls back to the linear scan.  -1 = in no bin.
+__device__ __forceinline__ int ece_find_bin(float conf, const float* s_edges, int n_bins)
+{
+    int b = (int)ceilf(conf * (float)n_bins) - 1;
+    b = b < 0 ? 0 : (b > n_bins - 1 ? n_bins - 1 : b);
+    if (!(conf > s_edges[b])) b = b > 0 ? b - 1 : 0;
+    else if (!(conf <= s_edges[b + 1])) b = b < n_bins - 1 ? b + 1 : b;
+    if (conf > s_edges[b] && conf <= s_edges[b + 1]) return b;
+    for (int k = 0; k < n_bins; ++k)
+        if (conf > s_edges[k] && conf <= s_edges[k + 1]) return k;
+    return -1;
+}
+
+// C = 19, hw % 4 == 0: four pixels per lane, the 19 x 4 logits of a lane live in registers (one 16-byte load per class
+// plane instead of two 4-byte passes), fast exponentials.
+template <int LDT>
+__global__ __launch_bounds__(kThreads)
+void ece19_kernel(const float* __restrict__ logits, int64_t hw, const void* __restrict__ label,
+                  const float* __restrict__ edges, int n_bins, ece_cell* __restrict__ partial)
+{
+    constexpr int C = 19;
+    __shared__ uint32_t s_cnt[64], s_cor[64];
+    __shared__ unsigned long long s_sum[64];
+    __shared__ float s_edges[65];
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0ull; }
+    for (int i = threadIdx.x; i <= n_bins; i += kThreads) s_edges[i] = edges[i];
+    __syncthreads();
+    const int64_t img = blockIdx.y;
+    const float* x = logits + img * C * hw;
+    const int64_t nvec = hw / 4;
+    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kThreads) {
+        const int64_t p = v * 4;
+        float4 xv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[c] = *reinterpret_cast<const float4*>(x + (int64_t)c * hw + p);
+        int64_t t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = awseg_ld_label<LDT>(label, img * hw + p + k);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (t[k] == 255) continue;                    // metrics.py:170 hard-codes 255
+            auto at = [&](int c) { return k == 0 ? xv[c].x : (k == 1 ? xv[c].y : (k == 2 ? xv[c].z : xv[c].w)); };
+            float m = at(0); int bi = 0;
+#pragma unroll
+            for (int c = 1; c < C; ++c) { const float q = at(c); if (q > m) { m = q; bi = c; } }
+            float sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < C; ++c) sum += __expf(at(c) - m);
+            const float conf = 1.0f / sum;
+            const int b = ece_find_bin(conf, s_edges, n_bins);
+            if (b >= 0) {
+                atomicAdd(&s_cnt[b], 1u);
+                if (bi == (int)t[k]) atomicAdd(&s_cor[b], 1u);
+                atomicAdd(&s_sum[b], conf_q30(conf));
+            }
+        }
+    }
+    __syncthreads();
+    ece_cell* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_bins;
+    for (int i = threadIdx.x; i < n_bins; i += kThreads) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = s_sum[i]; }
+}
+
 template <int LDT>
 __global__ __launch_bounds__(kThreads)
 void ece_kernel(const float* __restrict__ logits, int C, int64_t hw, const void* __restrict__ label,
@@ -291,13 +355,12 @@ void ece_kernel(const float* __restrict__ logits, int C, int64_t hw, const void*
         float conf = 1.0f / s;
         // bins are (lo, hi] on a float32 linspace (metrics.py:179-188); linear scan keeps the
         // reference's comparison semantics exactly.
-        for (int k = 0; k < n_bins; ++k)
-            if (conf > s_edges[k] && conf <= s_edges[k + 1]) {
-                atomicAdd(&s_cnt[k], 1u);
-                if (bi == t) atomicAdd(&s_cor[k], 1u);
-                atomicAdd(&s_sum[k], conf_q30(conf));
-                break;
-            }
+        const int k = ece_find_bin(conf, s_edges, n_bins);
+        if (k >= 0) {
+            atomicAdd(&s_cnt[k], 1u);
+            if (bi == t) atomicAdd(&s_cor[k], 1u);
+            atomicAdd(&s_sum[k], conf_q30(conf));
+        }
     }
     __syncthreads();
     ece_cell* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_bins;
@@ -384,16 +447,10 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
         for (int k = 0; k < 4; ++k) {
             const int64_t t = awseg_ld_label<LDT>(label, img * hw + p + k);
             if (t == 255) continue;                               // metrics.py:170, :426
-            float m1 = x[0][k], m2 = y[0][k];
-#pragma unroll
-            for (int c = 1; c < C; ++c) { m1 = fmaxf(m1, x[c][k]); m2 = fmaxf(m2, y[c][k]); }
-            float z1 = 0.f, z2 = 0.f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) { z1 += __expf(x[c][k] - m1); z2 += __expf(y[c][k] - m2); }
-            const float i1 = 1.0f / z1, i2 = 1.0f / z2;
             // ensemble logits r, their max / argmax / sum-exp for the calibration part
             float rmax = -INFINITY, rsum = 0.f; int rarg = 0;
             float r[C];
+            float m1 = x[0][k], m2 = y[0][k];
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 float rv;
@@ -402,26 +459,39 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
                 if (has_t) rv = rv / T;
                 r[c] = rv;
                 if (c == 0 || rv > rmax) { rmax = rv; rarg = c; }
+                m1 = fmaxf(m1, x[c][k]); m2 = fmaxf(m2, y[c][k]);
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) rsum += __expf(r[c] - rmax);
             const float conf = 1.0f / rsum;
-            for (int b = 0; b < n_bins; ++b)
-                if (conf > s_edges[b] && conf <= s_edges[b + 1]) {
-                    atomicAdd(&s_cnt[b], 1u);
-                    if (rarg == (int)t) atomicAdd(&s_cor[b], 1u);
-                    atomicAdd(&s_sum[b], conf_q30(conf));
-                    break;
-                }
-            // disagreement (mutual information) and the error flag of the mean-probability prediction
-            float hm = 0.f, h1 = 0.f, h2 = 0.f, mbest = -1.f; int marg = 0;
+            const int eb = ece_find_bin(conf, s_edges, n_bins);
+            if (eb >= 0) {
+                atomicAdd(&s_cnt[eb], 1u);
+                if (rarg == (int)t) atomicAdd(&s_cor[eb], 1u);
+                atomicAdd(&s_sum[eb], conf_q30(conf));
+            }
+            // member softmaxes: the raw logits are dead from here on, their registers take the exponentials.
+            // Member entropies without logarithms: p = e / z with e = exp(x - m), so log p = (x - m) - log z and
+            //   H(p) = -sum p log p = log z - (sum e (x - m)) / z;
+            // the reference's -sum p log(p + 1e-8) differs from it by sum p log(1 + 1e-8/p) <= 19e-8 (metrics.py:353-367),
+            // below the float32 rounding of the sum itself.  The mixture entropy keeps its per-class logarithm.
+            float z1 = 0.f, z2 = 0.f, t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int c = 0; c < C; ++c) {
-                const float p1 = __expf(x[c][k] - m1) * i1, p2 = __expf(y[c][k] - m2) * i2;
+                const float d1 = x[c][k] - m1, d2 = y[c][k] - m2;
+                x[c][k] = __expf(d1); y[c][k] = __expf(d2);
+                z1 += x[c][k]; z2 += y[c][k];
+                t1 = fmaf(x[c][k], d1, t1); t2 = fmaf(y[c][k], d2, t2);
+            }
+            const float i1 = 1.0f / z1, i2 = 1.0f / z2;
+            const float h1 = __logf(z1) - t1 * i1, h2 = __logf(z2) - t2 * i2;
+            // disagreement (mutual information) and the error flag of the mean-probability prediction
+            float hm = 0.f, mbest = -1.f; int marg = 0;
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float p1 = x[c][k] * i1, p2 = y[c][k] * i2;
                 const float mp = (p1 + p2) * 0.5f;
                 hm -= mp * __logf(mp + 1e-8f);
-                h1 -= p1 * __logf(p1 + 1e-8f);
-                h2 -= p2 * __logf(p2 + 1e-8f);
                 if (mp > mbest) { mbest = mp; marg = c; }
             }
             const float score = hm - (h1 + h2) * 0.5f;
@@ -597,9 +667,15 @@ AWSEG_API int awseg_ece_accumulate(const float* logits, int64_t batch, int num_c
     if (n_bins < 1 || n_bins > 64 || n_slots < 1 || batch < 1 || batch > 65535 || hw < 1) return AWSEG_EINVAL;
     if (num_classes < 1 || num_classes > AWSEG_MAX_CLASSES) return AWSEG_EINVAL;
     hipStream_t s = awseg_s(stream);
-    const int bpi = blocks_per_image(hw, batch, 1);
+    const bool vec19 = (num_classes == 19) && !(hw & 3) && !((uintptr_t)logits & 15);
+    const int bpi = blocks_per_image(hw, batch, vec19 ? 4 : 1);
     dim3 grid(bpi, (unsigned)batch), block(kThreads);
-    if (label_dtype == AWSEG_U8)
+    if (label_dtype != AWSEG_U8 && label_dtype != AWSEG_I64) return AWSEG_EINVAL;
+    if (vec19 && label_dtype == AWSEG_U8)
+        hipLaunchKernelGGL((ece19_kernel<AWSEG_U8>), grid, block, 0, s, logits, hw, label, edges, n_bins, (ece_cell*)workspace);
+    else if (vec19)
+        hipLaunchKernelGGL((ece19_kernel<AWSEG_I64>), grid, block, 0, s, logits, hw, label, edges, n_bins, (ece_cell*)workspace);
+    else if (label_dtype == AWSEG_U8)
         hipLaunchKernelGGL((ece_kernel<AWSEG_U8>), grid, block, 0, s, logits, num_classes, hw, label, edges, n_bins, (ece_cell*)workspace);
     else if (label_dtype == AWSEG_I64)
         hipLaunchKernelGGL((ece_kernel<AWSEG_I64>), grid, block, 0, s, logits, num_classes, hw, label, edges, n_bins, (ece_cell*)workspace);

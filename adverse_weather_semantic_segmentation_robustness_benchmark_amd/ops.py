@@ -362,13 +362,22 @@ def fog_density_from_depth(depth: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- heads
-def segformer_head_fused(g9: torch.Tensor, scale, shift, w2, b2, height: int, width: int) -> torch.Tensor:
-    """Upsample-free SegFormer head (PKG/models/model.py:209-214).  g9 [B,h,w,9,Cmid]."""
+HEAD_SPLIT = os.environ.get("AWSEG_HEAD_SPLIT", "1") != "0"
+
+
+def segformer_head_fused(g9: torch.Tensor, scale, shift, w2, b2, height: int, width: int, split: Optional[bool] = None) -> torch.Tensor:
+    """Upsample-free SegFormer head (PKG/models/model.py:209-214).  g9 [B,h,w,9,Cmid].
+    split: True = the split-operand f16-MFMA kernel where it applies (scale folded into g9, Cmid 128/256, tile geometry),
+    False = the float32-input MFMA kernel; None takes the process default (HEAD_SPLIT, env AWSEG_HEAD_SPLIT=0/1)."""
     g9 = g9.contiguous()
     b, h, w, nine, cmid = g9.shape
     assert nine == 9
     cout = w2.shape[0]
     out = torch.empty(b, cout, height, width, dtype=torch.float32, device=g9.device)
+    if (HEAD_SPLIT if split is None else split) and scale is None and cmid in (128, 256):
+        if N.try_call("awseg_segformer_head_fused_split", N.ptr(g9), b, cmid, h, w, height, width, None, N.ptr(shift.contiguous()),
+                      N.ptr(w2.contiguous()), N.ptr(b2.contiguous()), cout, N.ptr(out), N.stream()) == 0:
+            return out
     N.call("awseg_segformer_head_fused", N.ptr(g9), b, cmid, h, w, height, width, N.ptr(None if scale is None else scale.contiguous()),
                                                N.ptr(shift.contiguous()), N.ptr(w2.contiguous()), N.ptr(b2.contiguous()),
                                                cout, N.ptr(out), N.stream())
@@ -734,17 +743,18 @@ def conv3x3_winograd_bf16(x: torch.Tensor, u_bf16: torch.Tensor, cout: int, shif
 def set_split(on: bool) -> None:
     """Process-wide switch between the split-operand f16-MFMA kernels (float32-grade results) and
     their float32-input MFMA counterparts, for every operator that has both."""
-    global ATTENTION_SPLIT, GEMM_SPLIT, WINO_SPLIT
-    ATTENTION_SPLIT = GEMM_SPLIT = WINO_SPLIT = bool(on)
+    global ATTENTION_SPLIT, GEMM_SPLIT, WINO_SPLIT, HEAD_SPLIT
+    ATTENTION_SPLIT = GEMM_SPLIT = WINO_SPLIT = HEAD_SPLIT = bool(on)
 
 
 def split_state() -> dict:
-    return {"attention": ATTENTION_SPLIT, "gemm_1x1": GEMM_SPLIT, "winograd_3x3": WINO_SPLIT}
+    return {"attention": ATTENTION_SPLIT, "gemm_1x1": GEMM_SPLIT, "winograd_3x3": WINO_SPLIT, "segformer_head": HEAD_SPLIT}
 
 
 def restore_split(state: dict) -> None:
-    global ATTENTION_SPLIT, GEMM_SPLIT, WINO_SPLIT
+    global ATTENTION_SPLIT, GEMM_SPLIT, WINO_SPLIT, HEAD_SPLIT
     ATTENTION_SPLIT, GEMM_SPLIT, WINO_SPLIT = bool(state["attention"]), bool(state["gemm_1x1"]), bool(state["winograd_3x3"])
+    HEAD_SPLIT = bool(state.get("segformer_head", HEAD_SPLIT))
 
 
 def depth_upsample_combine(d1: torch.Tensor, d2_low: torch.Tensor, weights: Optional[torch.Tensor]):

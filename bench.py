@@ -151,13 +151,15 @@ def algorithmic_work(name, B, H, W, C, info):
         return "hbm", (2048 * 4 + 3 * 2048 * 4) * h * w * B
     if name == "awseg_segformer_head_fused":           # executed MFMA flops: GEMM1 K=12 + GEMM2 N padded to 32
         return "mfma", 2.0 * (12 * 256 + 256 * 32) * px * B
+    if name == "awseg_segformer_head_fused_split":     # issued f16 MFMA flops: GEMM1 K padded to 16, 2 products; GEMM2 3 products
+        return "mfma_f16", 2.0 * (2 * 16 * 256 + 3 * 256 * 32) * px * B
     if name == "awseg_upconv3x3_bn_relu":              # 24 MFMAs per 32 px, but 512 B/px of output: the write is the roofline
         return "hbm", 128 * 4 * px * B
     return "hbm", 0
 
 
 # device-function names of the C-ABI launchers' dominant kernels (for the PMC traffic lookup)
-DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg_conv3x3_winograd_split_nhwc": "wino_split_kernel<1, false>", "awseg_conv3x3_winograd_bf16_nhwc": "wino_split_kernel<1, true>", "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
+DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg_conv3x3_winograd_split_nhwc": "wino_split_kernel<1, false>", "awseg_conv3x3_winograd_bf16_nhwc": "wino_split_kernel<1, true>", "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_kernel"}
 
 

@@ -367,6 +367,18 @@ int awseg_segformer_head_fused(const float* g9, int64_t batch, int cmid, int h, 
                                const float* w2, const float* b2, int cout,
                                float* out, awseg_stream_t stream);
 
+/* The same head on v_mfma_f32_32x32x16_f16 with split operands (x = hi + lo in f16, three products per
+ * float32-grade product, float32 accumulation): both contractions run at the f16 rate.  Rows in
+ * which an operand reaches 2^15 are recomputed inside the kernel on the float32 instruction, so the result
+ * is float32-grade for any finite input.  Same arguments; scale must be NULL (folded into g9), Cmid 128 or
+ * 256; AWSEG_ERANGE for a geometry or width the kernel does not cover (the caller then uses the entry above).
+ * Replaces the same reference lines (PKG/models/model.py:209-214). */
+int awseg_segformer_head_fused_split(const float* g9, int64_t batch, int cmid, int h, int w,
+                                     int height, int width,
+                                     const float* scale, const float* shift,
+                                     const float* w2, const float* b2, int cout,
+                                     float* out, awseg_stream_t stream);
+
 /* First stage only (no classifier): relu(bn(conv3x3(interpolate(f)))) written at full
  * resolution, out float32 [B,Cmid,H,W] (channels_last = 0) or [B,H,W,Cmid] (channels_last = 1).  Used for the first 3x3 of DepthEstimationHead on
  * the SegFormer branch (PKG/models/model.py:42-45 applied to the upsampled features, :219-221).

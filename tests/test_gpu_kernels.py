@@ -615,8 +615,51 @@ def test_segformer_head_mfma_vs_v1_and_torch(ops, cfg, monkeypatch):
         # BatchNorm scale folded into g9 (scale=None): the 16-byte-gather kernel (v3) when Cmid is 128 / 256
         g9f = torch.einsum("bchw,ockl->bhwklo", feat, conv1.weight * scale.view(-1, 1, 1, 1)).reshape(B, h, w, 9, cmid).contiguous()
         if cmid % 32 == 0 and min(H / h, W / w) >= 17:
-            v3 = ops.segformer_head_fused(g9f, None, shift, w2, conv2.bias, H, W)
+            v3 = ops.segformer_head_fused(g9f, None, shift, w2, conv2.bias, H, W, split=False)
             assert (v3 - v1).abs().max().item() < 1e-4 * max(1.0, v1.abs().max().item())
+            # the split-operand f16-MFMA kernel (v4) where it applies (Cmid 128 / 256), else the same float32 kernel
+            v4 = ops.segformer_head_fused(g9f, None, shift, w2, conv2.bias, H, W, split=True)
+            assert (v4 - v1).abs().max().item() < 1e-4 * max(1.0, v1.abs().max().item())
+
+
+@pytest.mark.parametrize("cmid", [128, 256])
+def test_segformer_head_split_is_float32_grade_and_guards_its_operand_range(ops, cmid):
+    """v4 (split f16 operands) against the as-written op sequence in FLOAT64, next to the float32-MFMA kernel on the same
+    inputs; then with a patch of the feature map scaled to 1e5 — beyond f16 — where the rows it reaches are recomputed on the
+    float32 instruction inside the kernel, and with an infinity (propagates as in torch)."""
+    B, h, w, H, W, cout, cin = 2, 5, 7, 160, 224, 19, 32
+    torch.manual_seed(cmid)
+    feat = torch.randn(B, cin, h, w, device="cuda")
+    conv1 = torch.nn.Conv2d(cin, cmid, 3, padding=1).cuda()
+    conv2 = torch.nn.Conv2d(cmid, cout, 1).cuda()
+    shift = (torch.randn(cmid, device="cuda") * 0.3).contiguous()
+    w2 = conv2.weight.view(cout, cmid).contiguous()
+
+    def both(f):
+        with torch.no_grad():
+            g9 = torch.einsum("bchw,ockl->bhwklo", f, conv1.weight).reshape(B, h, w, 9, cmid).contiguous()
+            up = torch.nn.functional.interpolate(f.double(), size=(H, W), mode="bilinear", align_corners=False)
+            mid = torch.relu(torch.nn.functional.conv2d(up, conv1.weight.double(), None, padding=1) + shift.double().view(1, -1, 1, 1))
+            ref = torch.nn.functional.conv2d(mid, conv2.weight.double(), conv2.bias.double())
+            f32 = ops.segformer_head_fused(g9, None, shift, w2, conv2.bias, H, W, split=False)
+            spl = ops.segformer_head_fused(g9, None, shift, w2, conv2.bias, H, W, split=True)
+        return ref, f32, spl
+
+    ref, f32, spl = both(feat)
+    mag = ref.abs().max().item()
+    e32, esp = (f32.double() - ref).abs().max().item() / mag, (spl.double() - ref).abs().max().item() / mag
+    print(f"head Cmid {cmid}: float32 MFMA {e32:.2e}, split f16 {esp:.2e} of max |logit| {mag:.2f}")
+    assert esp < 1e-5 and esp < 8 * max(e32, 2e-7)
+    big = feat.clone(); big[0, :, 1:3, 2:4] *= 1e5
+    ref, f32, spl = both(big)
+    mag = ref.abs().max().item()
+    esp = (spl.double() - ref).abs().max().item() / mag
+    assert torch.isfinite(spl).all() and esp < 1e-5, esp
+    # away from the patch (rows of image 1 never see it) the result is the small-magnitude one
+    assert (spl[1].double() - ref[1]).abs().max().item() < 1e-5 * ref[1].abs().max().item()
+    inf = feat.clone(); inf[1, 0, 2, 3] = float("inf")
+    ref, f32, spl = both(inf)
+    assert torch.equal(torch.isfinite(spl), torch.isfinite(f32))
 
 
 def test_dwconv3x3_nhwc_and_bias_act(ops):
@@ -754,7 +797,7 @@ def test_gemm_tune_keeps_results(ops, native):
     assert (ops.gemm_bias_act(x, w, b, 1).double() - ref).abs().max().item() < 1e-4
 
 
-@pytest.mark.parametrize("shape", [(2, 5, 7, 8, 4), (1, 16, 32, 256, 48), (1, 3, 3, 4, 4)])
+@pytest.mark.parametrize("shape", [(2, 5, 7, 8, 4), (1, 16, 32, 256, 48), (1, 3, 3, 4, 4), (2, 9, 13, 256, 8), (1, 4, 21, 512, 48)])
 def test_dwconv3x3_upcat_matches_torch(ops, shape):
     """Decoder fusion: depthwise3x3(cat(UpsamplingBilinear2d(x4)(a), hi)) against the torch ops it replaces (1e-5)."""
     B, h, w, Ca, Ch = shape
@@ -768,10 +811,12 @@ def test_dwconv3x3_upcat_matches_torch(ops, shape):
     assert (got.permute(0, 3, 1, 2) - ref).abs().max().item() < 1e-5
 
 
-def test_aspp_depthwise3_xcd_sliced_path(ops):
-    """The XCD-aware (image, 64-channel slice) work order of the ASPP depthwise kernel (C % 64 == 0), real rates."""
+@pytest.mark.parametrize("geom", [(2, 40, 52, 128), (1, 64, 20, 64), (3, 10, 7, 64), (1, 37, 75, 192)])
+def test_aspp_depthwise3_xcd_sliced_path(ops, geom):
+    """The XCD-aware (image, 64-channel slice) work order of the ASPP depthwise kernel (C % 64 == 0), real rates: row classes
+    with 1..6 rows, maps lower than a rate (every row its own class), widths below a rate (no horizontal neighbours)."""
     torch.manual_seed(1)
-    B, h, w, Cc = 2, 40, 52, 128
+    B, h, w, Cc = geom
     x = torch.randn(B, Cc, h, w, device="cuda")
     wdw = torch.randn(3, Cc, 1, 3, 3, device="cuda")
     rates = (12, 24, 36)

@@ -103,8 +103,11 @@ def main():
     g9 = torch.randn(B, h, w, 9, 256, device=dev)
     sc, sf = torch.rand(256, device=dev) + 0.5, torch.randn(256, device=dev) * 0.1
     w2, b2 = torch.randn(C, 256, device=dev) * 0.05, torch.zeros(C, device=dev)
-    cases["segformer_head_fused (MFMA)"] = (lambda: ops.segformer_head_fused(g9, None, sf, w2, b2, H, W), "mfma",
+    cases["segformer_head_fused (MFMA)"] = (lambda: ops.segformer_head_fused(g9, None, sf, w2, b2, H, W, split=False), "mfma",
                                              2.0 * (12 * 256 + 256 * 32) * px * B)
+    # split operands: the same products three times over (two for GEMM 1 when the bilinear weights are exact in f16, as here)
+    cases["segformer_head_fused [split f16x3, issued flops]"] = (lambda: ops.segformer_head_fused(g9, None, sf, w2, b2, H, W, split=True), "mfma_f16",
+                                                                 2.0 * (2 * 16 * 256 + 3 * 256 * 32) * px * B)
     g9d = torch.randn(B, h, w, 9, 128, device=dev)
     cases["upconv3x3_bn_relu 128ch NHWC (512 B/px written)"] = (lambda: ops.upconv3x3_bn_relu(g9d, None, sf[:128].contiguous(), H, W, True),
                                                                 "hbm", 128 * 4 * px * B)

@@ -442,6 +442,8 @@ void head_mfma_classify_kernel(const float* __restrict__ g9, int h, int w, int H
 // ---------------------------------------------------------------------------------------
 typedef _Float16 hd8 __attribute__((ext_vector_type(8)));
 typedef unsigned hu4 __attribute__((ext_vector_type(4)));
+typedef float hf2 __attribute__((ext_vector_type(2)));
+typedef float hf4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void head_split_pair(float a, float b, unsigned& hi, unsigned& lo)
 {
     hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
@@ -528,7 +530,16 @@ void head_split_classify_kernel(const float* __restrict__ g9, int h, int w, int 
         head_split_pair(cx[0], cx[1], a, c); cxh[0] = a; cxl[0] = c;
         head_split_pair(cx[2], cx[3], a, c); cxh[1] = a; cxl[1] = c;
         head_split_pair(cx[4], cx[5], a, c); cxh[2] = a; cxl[2] = c;
-        cxh[3] = 0u; cxl[3] = 0u;
+        // the two spare K slots of the first half-wave carry the BatchNorm shift: B = (1, 1) against A = (shift hi, shift lo)
+        cxh[3] = hh == 0 ? 0x3C003C00u : 0u; cxl[3] = 0u;
+    }
+    unsigned shp[OT];                           // this lane's row of every o-tile: f16 (hi, lo) of its shift; zero in half-wave 1
+#pragma unroll
+    for (int ot = 0; ot < OT; ++ot) {
+        const float sv = shift[chan(ot, lo)];
+        const _Float16 sh_hi = (_Float16)sv, sh_lo = (_Float16)(sv - (float)sh_hi);
+        const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, sh_hi) | ((unsigned)__builtin_bit_cast(unsigned short, sh_lo) << 16);
+        shp[ot] = hh == 0 ? pk : 0u;
     }
     // lo halves are +0 or -0 when a weight is exact in f16
     const bool cx_exact = __builtin_amdgcn_ballot_w64(((cxl[0] | cxl[1] | cxl[2]) & 0x7FFF7FFFu) != 0u) == 0ull;
@@ -552,18 +563,20 @@ void head_split_classify_kernel(const float* __restrict__ g9, int h, int w, int 
             lw[2 * ky] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ok ? sy.l0 : 0.f)));
             lw[2 * ky + 1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ok ? sy.l1 : 0.f)));
         }
+        // packed float32 FMAs on the register pairs a 16-byte LDS read delivers (v_pk_fma_f32, no operand shuffles)
         auto gather4 = [&](int gi, float (*t)[6]) {
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
                 const float* base = Gl + lbase[s] + gi * 128;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                hf2 v01 = { 0.f, 0.f }, v23 = { 0.f, 0.f };
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
-                    const float4 a = *reinterpret_cast<const float4*>(base + ub[j]);
-                    v.x = fmaf(lw[j], a.x, v.x); v.y = fmaf(lw[j], a.y, v.y);
-                    v.z = fmaf(lw[j], a.z, v.z); v.w = fmaf(lw[j], a.w, v.w);
+                    const hf4 a = *reinterpret_cast<const hf4*>(base + ub[j]);
+                    const hf2 wj = { lw[j], lw[j] };
+                    v01 = __builtin_elementwise_fma(wj, __builtin_shufflevector(a, a, 0, 1), v01);
+                    v23 = __builtin_elementwise_fma(wj, __builtin_shufflevector(a, a, 2, 3), v23);
                 }
-                t[0][s] = v.x; t[1][s] = v.y; t[2][s] = v.z; t[3][s] = v.w;
+                t[0][s] = v01[0]; t[1][s] = v01[1]; t[2][s] = v23[0]; t[3][s] = v23[1];
             }
         };
         auto shift_init = [&](int ot) {
@@ -577,14 +590,38 @@ void head_split_classify_kernel(const float* __restrict__ g9, int h, int w, int 
         f32x16 acc2;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
-        auto gemm1 = [&](int ot, const float* t) {
-            f32x16 a = shift_init(ot);
-            hu4 th, tl; unsigned p, q;
-            head_split_pair(t[0], t[1], p, q); th[0] = p; tl[0] = q;
-            head_split_pair(t[2], t[3], p, q); th[1] = p; tl[1] = q;
-            head_split_pair(t[4], t[5], p, q); th[2] = p; tl[2] = q;
-            th[3] = 0u; tl[3] = 0u;
-            amax = head_max3(amax, t[0], t[1]); amax = head_max3(amax, t[2], t[3]); amax = head_max3(amax, t[4], t[5]);
+        // A operands of the four tiles of a group, already split: th[q] / tl[q] halves 0..5 = slots, 6..7 = shift / zero.
+        // A group's operands are produced in three steps (slot pairs) so that the LDS reads and packed FMAs of the NEXT
+        // group can sit between the matrix instructions of this one instead of in one exposed block behind them.
+        auto gather_step = [&](int gi, int sp, hu4* th, hu4* tl) {
+            float t[4][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int s = 2 * sp + e;
+                const float* base = Gl + lbase[s] + gi * 128;
+                hf2 v01 = { 0.f, 0.f }, v23 = { 0.f, 0.f };
+#pragma unroll
+                for (int j = 0; j < 6; ++j) {
+                    const hf4 a = *reinterpret_cast<const hf4*>(base + ub[j]);
+                    const hf2 wj = { lw[j], lw[j] };
+                    v01 = __builtin_elementwise_fma(wj, __builtin_shufflevector(a, a, 0, 1), v01);
+                    v23 = __builtin_elementwise_fma(wj, __builtin_shufflevector(a, a, 2, 3), v23);
+                }
+                t[0][e] = v01[0]; t[1][e] = v01[1]; t[2][e] = v23[0]; t[3][e] = v23[1];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                unsigned p, r;
+                head_split_pair(t[q][0], t[q][1], p, r);
+                th[q][sp] = p; tl[q][sp] = r;
+                amax = head_max3(amax, t[q][0], t[q][1]);
+            }
+        };
+        auto gemm1 = [&](unsigned shpk, hu4 th, hu4 tl) {
+            f32x16 a;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a[r] = 0.f;
+            th[3] = shpk; tl[3] = 0u;
             a = HMFMA(th, cxh, a);
             a = HMFMA(tl, cxh, a);
             if (!cx_exact) a = HMFMA(th, cxl, a);
@@ -594,7 +631,11 @@ void head_split_classify_kernel(const float* __restrict__ g9, int h, int w, int 
             const hu4* wp = s_w2 + ot * 256 + lane;
             const hu4 wh0 = wp[0], wl0 = wp[64], wh1 = wp[128], wl1 = wp[192];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = acc[r] > 0.f ? acc[r] : 0.f;
+            for (int r = 0; r < 16; ++r) {                           // one v_max_f32 (fmaxf() adds a canonicalising v_max x, x)
+                float v;
+                asm("v_max_f32 %0, 0, %1" : "=v"(v) : "v"(acc[r]));
+                acc[r] = v;
+            }
             hu4 mh0, ml0, mh1, ml1; unsigned p, q;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -610,24 +651,30 @@ void head_split_classify_kernel(const float* __restrict__ g9, int h, int w, int 
             acc2 = HMFMA(wl1, mh1, acc2);
             acc2 = HMFMA(wh1, ml1, acc2);
         };
-        float ta[4][6];
-        gather4(0, ta);
-#pragma unroll 1
+        hu4 oh[2][4], ol[2][4];                                      // operands of the current / next group
+#pragma unroll
+        for (int sp = 0; sp < 3; ++sp) gather_step(0, sp, oh[0], ol[0]);
+#pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
-            f32x16 accA = gemm1(4 * gi, ta[0]);
-            f32x16 accB = gemm1(4 * gi + 1, ta[1]);
+            const int c = gi & 1, n = c ^ 1;
+            const bool more = gi + 1 < NG;
+            f32x16 accA = gemm1(shp[4 * gi], oh[c][0], ol[c][0]);
+            f32x16 accB = gemm1(shp[4 * gi + 1], oh[c][1], ol[c][1]);
             finish(4 * gi, accA);
-            accA = gemm1(4 * gi + 2, ta[2]);
+            if (more) gather_step(gi + 1, 0, oh[n], ol[n]);
+            accA = gemm1(shp[4 * gi + 2], oh[c][2], ol[c][2]);
             finish(4 * gi + 1, accB);
-            accB = gemm1(4 * gi + 3, ta[3]);
-            if (gi + 1 < NG) gather4(gi + 1, ta);
+            if (more) gather_step(gi + 1, 1, oh[n], ol[n]);
+            accB = gemm1(shp[4 * gi + 3], oh[c][3], ol[c][3]);
             finish(4 * gi + 2, accA);
+            if (more) gather_step(gi + 1, 2, oh[n], ol[n]);
             finish(4 * gi + 3, accB);
         }
         // range guard: a value at or beyond 2^15 (or an infinity) anywhere in this row -> the row again, in float32
         if (__builtin_amdgcn_ballot_w64(!(amax < 32768.f)) != 0ull) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+            float ta[4][6];
             gather4(0, ta);
 #pragma unroll 1
             for (int gi = 0; gi < NG; ++gi) {

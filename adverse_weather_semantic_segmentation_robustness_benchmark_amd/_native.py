@@ -66,8 +66,9 @@ SIGNATURES = {
     "awseg_fog_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_fog_fused": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_night_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "awseg_rain_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "awseg_snow_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_rain_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_snow_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_streak_workspace": (c_i64, [c_i, c_i, c_i]),
     "awseg_fog_density_field": (c_i, [c_p, c_i, c_i64, c_u64, c_p, c_p, c_p]),
     "awseg_loss_partials": (c_i64, [c_i64, c_i64]),
     "awseg_fog_ce_forward": (c_i, [c_p, c_p, c_i, c_p, c_i64, c_i, c_i64, c_i, c_f, c_p, c_p, c_p, c_p, c_p]),

@@ -393,12 +393,15 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<aw
         } else {
             for (int k = 0; k < nvalid * 3; ++k) px[k] = src[p * 3 + k];
         }
+        // blend and quantise in byte units: trunc(clip(px/255 * t + A (1 - t), 0, 1) * 255) = trunc(clip(px * t + 255 A (1 - t), 0, 255)) up to
+        // float32 rounding — one v_cvt_f32_ubyteN + one FMA + one v_med3 + one conversion per value, no table
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float t = __expf(-beta * depth[k]);
-            const float hz = A32 * (1.0f - t);
+            const float hz = (255.0f * A32) * (1.0f - t);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) res[k * 3 + c] = quant_f32(fmaf(L.in[px[k * 3 + c]], t, hz));
+            for (int c = 0; c < 3; ++c)
+                res[k * 3 + c] = (uint8_t)(int)__builtin_amdgcn_fmed3f(fmaf((float)px[k * 3 + c], t, hz), 0.f, 255.f);
         }
         if (dst) {
             if (vec) {
@@ -495,14 +498,12 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_n
             awseg_philox::gen(job.seed, (uint64_t)q * 2 + 1, 0x0A17u, r + 4);
 #pragma unroll
             for (int j = 0; j < 6; ++j) awseg_box_muller16(r[j], nf[2 * j], nf[2 * j + 1]);
-            const float amp = (float)(sigma * ni * 0.5);
+            // byte units, as in the throughput-mode fog: trunc(clip(px/255 * b * g + n, 0, 1) * 255) = trunc(clip(px * (b g) + 255 n, 0, 255))
+            const float amp = (float)(sigma * ni * 0.5 * 255.0);
+            const float kg[3] = { bf * g0, bf * g1, bf * g2 };
 #pragma unroll
-            for (int k = 0; k < 12; ++k) {
-                float v = L.in[px[k]];
-                v = v * bf;
-                v = v * gains[k % 3];
-                res[k] = quant_f32(fmaf(nf[k], amp, v));
-            }
+            for (int k = 0; k < 12; ++k)
+                res[k] = (uint8_t)(int)__builtin_amdgcn_fmed3f(fmaf(nf[k], amp, (float)px[k] * kg[k % 3]), 0.f, 255.f);
         } else if (nvalid == 4) {
             const double2* n2 = reinterpret_cast<const double2*>(noise + p * 3);
 #pragma unroll
@@ -554,7 +555,13 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_n
 struct tile_mask {
     uint8_t* m; int x0, y0, w, h;   // rect origin / size in image coordinates
     int W, H;                       // image size (OpenCV clips to the image first)
+    uint32_t* bits; int wd;         // frame-wide 1-bit coverage map (wd dwords per row) instead of the byte rect, or NULL
 };
+__device__ __forceinline__ void m_set(const tile_mask& k, int rx, int ry)
+{
+    if (k.bits) atomicOr(&k.bits[(int64_t)ry * k.wd + (rx >> 5)], 1u << (rx & 31));
+    else k.m[ry * k.w + rx] = 1;
+}
 __device__ __forceinline__ void m_hline(const tile_mask& k, int y, int xa, int xb, int lane)
 {
     if (y < 0 || y >= k.H) return;
@@ -565,14 +572,14 @@ __device__ __forceinline__ void m_hline(const tile_mask& k, int y, int xa, int x
     int a = xa - k.x0, b = xb - k.x0;
     if (a < 0) a = 0;
     if (b >= k.w) b = k.w - 1;
-    for (int x = a + lane; x <= b; x += 64) k.m[ry * k.w + x] = 1;
+    for (int x = a + lane; x <= b; x += 64) m_set(k, x, ry);
 }
 __device__ __forceinline__ void m_point(const tile_mask& k, int x, int y)
 {
     if (x < 0 || x >= k.W || y < 0 || y >= k.H) return;
     const int rx = x - k.x0, ry = y - k.y0;
     if (rx < 0 || rx >= k.w || ry < 0 || ry >= k.h) return;
-    k.m[ry * k.w + rx] = 1;
+    m_set(k, rx, ry);
 }
 // cv::Line (LineIterator, 8-connected, left to right): closed form per step -> one step per lane.
 __device__ void m_line_thin(const tile_mask& k, int x0, int y0, int x1, int y1, int lane)
@@ -735,11 +742,17 @@ struct blur_taps { float k[2 * BRMAX + 1]; int r; };
 
 // RR = blur radius (1: 3x3, 3: 7x7).  RR == 1 fuses the row and the column pass in registers
 // (no s_row, 4 blocks per CU); RR == 3 keeps the two LDS passes.
-template <bool SNOW, int RR>
+// BITS = true: the primitives were rasterised beforehand, once per frame, into a 1-bit coverage map (raster_kernel below;
+// bits[job][H][wd] dwords) and this kernel is a pure stencil — no bounding-box scan, no per-tile rasterisation, two barriers
+// fewer.  (With the rasteriser inside, a tile a thick drop touches keeps 7 of its 8 waves waiting on the wave that walks the
+// drop's scanlines, and 44 % of the tiles of a rain frame are touched: 197 us per 8 frames against 128 us without drops.)
+// BITS = false (no workspace given) keeps the self-contained form; both give the same bytes.
+template <bool SNOW, int RR, bool BITS>
 __global__ __launch_bounds__(kSThreads)
 void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_prim_job> jobs,
                    const int32_t* __restrict__ prims, blur_taps bt,
-                   uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
+                   uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc,
+                   const uint32_t* __restrict__ bits_all, int wd)
 {
     constexpr int R = RR;
     constexpr int sw = BTW + 2 * R, sh = BTH + 2 * R;
@@ -748,8 +761,9 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
     __shared__ __attribute__((aligned(16))) float s_src[sh * BSW * 3];
     __shared__ __attribute__((aligned(16))) float s_row[RR == 1 ? 4 : sh * BTW * 3];
     __shared__ uint32_t s_raw[sh * RAWD];
-    __shared__ uint8_t s_mask[sh * BSW];
-    __shared__ int s_hits[MAXHIT];
+    __shared__ uint8_t s_mask[BITS ? 4 : sh * BSW];
+    __shared__ uint32_t s_mbits[BITS ? sh * 4 : 1];                          // BITS: the <= 4 coverage dwords a staged row touches
+    __shared__ int s_hits[BITS ? 1 : MAXHIT];
     __shared__ int s_nhit;
     __shared__ weather_lut L;
     const awseg_prim_job job = jobs.j[blockIdx.z];
@@ -776,11 +790,20 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
             else pre[u] = 0u;
         }
     }
+    // BITS: coverage dwords of the staged rows (columns x0-R .. x0+BTW+R-1 span at most 4 dwords)
+    const uint32_t* bits = BITS ? bits_all + (int64_t)blockIdx.z * H * wd : nullptr;
+    const int mb0 = (x0 - R) >> 5;                                          // first coverage dword of an interior tile's staged rows
+    uint32_t mpre = 0u;
+    if (BITS && interior && (int)threadIdx.x < sh * 4) {
+        const int ty = threadIdx.x >> 2, di = threadIdx.x & 3;
+        const int dw = mb0 + di;
+        mpre = dw < wd ? bits[(int64_t)(y0 - R + ty) * wd + dw] : 0u;
+    }
     // this lane's primitive for the bounding-box scan
     const int32_t* pl = prims + (int64_t)job.prim_offset * (SNOW ? 3 : 5);
     constexpr int PW = SNOW ? 3 : 5;
     int pv[5] = { 0, 0, 0, 0, 0 };
-    if ((int)threadIdx.x < job.prim_count) {
+    if (!BITS && (int)threadIdx.x < job.prim_count) {
 #pragma unroll
         for (int f = 0; f < PW; ++f) pv[f] = pl[threadIdx.x * PW + f];
     }
@@ -804,14 +827,16 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
             const int i = threadIdx.x + u * kSThreads;
             if (i < sh * RAWD) s_raw[i] = pre[u];
         }
+        if (BITS && (int)threadIdx.x < sh * 4) s_mbits[threadIdx.x] = mpre;
     }
     // coverage mask over the part of tile+halo that lies inside the image
     tile_mask mk;
-    mk.m = s_mask; mk.W = W; mk.H = H;
+    mk.m = s_mask; mk.W = W; mk.H = H; mk.bits = nullptr; mk.wd = 0;
     mk.x0 = x0 - R < 0 ? 0 : x0 - R;
     mk.y0 = y0 - R < 0 ? 0 : y0 - R;
     const int xe = x0 + BTW + R > W ? W : x0 + BTW + R, ye = y0 + BTH + R > H ? H : y0 + BTH + R;
     mk.w = xe - mk.x0; mk.h = ye - mk.y0;
+    if (!BITS) {
     for (int i = threadIdx.x; i < mk.w * mk.h; i += kSThreads) s_mask[i] = 0;
     if (threadIdx.x == 0) s_nhit = 0;
     __syncthreads();
@@ -848,6 +873,7 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
             else m_line_thick(mk, ax, ay, bx, by, th, lane);
         }
     }
+    }   // !BITS
     __syncthreads();
     // 3. stage the pre-blur float image of tile + halo: one lane per (row, pixel quad)
     const float col[3] = { SNOW ? 1.0f : 0.8f, SNOW ? 1.0f : 0.9f, 1.0f };
@@ -863,12 +889,19 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
             d[0] = sft ? (w0 >> sft) | (w1 << (32 - sft)) : w0;
             d[1] = sft ? (w1 >> sft) | (w2 << (32 - sft)) : w1;
             d[2] = sft ? (w2 >> sft) | (w3 << (32 - sft)) : w2;
-            const uint8_t* mrow = s_mask + (y0 - R + ty - mk.y0) * mk.w + (x0 - R + tq * 4 - mk.x0);
+            const uint8_t* mrow = s_mask + (BITS ? 0 : (y0 - R + ty - mk.y0) * mk.w + (x0 - R + tq * 4 - mk.x0));
+            uint32_t cbits = 0u;                                            // BITS: coverage of the quad's four pixels in bits 0..3
+            if (BITS) {
+                const int bo2 = (x0 - R + tq * 4) - (mb0 << 5);             // bit offset inside the row's staged dwords (0 .. 127)
+                const uint32_t* mr = s_mbits + ty * 4 + (bo2 >> 5);
+                const uint32_t lo = mr[0], hi = (bo2 >> 5) < 3 ? mr[1] : 0u;
+                cbits = (uint32_t)((((uint64_t)hi << 32) | lo) >> (bo2 & 31));
+            }
             float v[12];
 #pragma unroll
             for (int e = 0; e < 12; ++e) {
                 const int k = e / 3, c = e - k * 3;
-                const bool cov = (tq * 4 + k < sw) && mrow[k];
+                const bool cov = (tq * 4 + k < sw) && (BITS ? ((cbits >> k) & 1u) != 0u : mrow[k] != 0);
                 v[e] = cov ? col[c] : L.in[(d[e >> 2] >> ((e & 3) * 8)) & 0xFF];
             }
             float4* o4 = reinterpret_cast<float4*>(s_src + (ty * BSW + tq * 4) * 3);
@@ -879,7 +912,8 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
             const int ty = i / sw, tx = i - ty * sw;
             const int gy = reflect_101(y0 - R + ty, H), gx = reflect_101(x0 - R + tx, W);
             const bool inrect = (gy >= mk.y0 && gy < ye && gx >= mk.x0 && gx < xe);
-            const bool cov = inrect && s_mask[(gy - mk.y0) * mk.w + (gx - mk.x0)];
+            const bool cov = BITS ? ((bits[(int64_t)gy * wd + (gx >> 5)] >> (gx & 31)) & 1u) != 0u
+                                  : (inrect && s_mask[(gy - mk.y0) * mk.w + (gx - mk.x0)]);
             const uint8_t* px = src + ((int64_t)gy * W + gx) * 3;
 #pragma unroll
             for (int c = 0; c < 3; ++c) s_src[(ty * BSW + tx) * 3 + c] = cov ? col[c] : L.in[px[c]];
@@ -970,6 +1004,194 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
                     for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = L.nrm[c][res[k * 3 + c]];
             }
         }
+    }
+}
+
+// The same transform with the coverage map, as a STRIP kernel: a lane owns 4 adjacent pixels and walks NR rows of them; no
+// float image in LDS, no barrier after the table fill.  Per input row a lane loads the (4 + 2R) pixels of its window as
+// aligned dwords (bytes picked with compile-time shifts), maps them through the LDS table (or the streak colour where the
+// coverage bit is set), runs OpenCV's row pass for its 12 values and keeps the last 2R + 1 row-pass results in registers;
+// every row after the first 2R closes one output row: column pass, quantise, 12 B / 3 x 16 B stores.  The row loop is
+// unrolled by 2R + 1, so the ring slots are register names.  Same operations in the same order as the tile kernel (the
+// file is built with -ffp-contract=off): byte-identical output.  ~265 instructions per pixel quad against ~750: the tile
+// kernel converts 1.2 pixels per output, makes two LDS passes over the float image and pays its prologue per 2048 pixels.
+template <int RR> struct strip_rows { static constexpr int value = RR == 1 ? 16 : 15; };   // NR + 2R is a multiple of 2R + 1
+
+// FAST (W % 4 == 0, W >= 16; chosen by the launcher): every lane takes the aligned-dword window.  A lane at the left / right
+// image edge loads with its dword indices clamped into the row and then copies the BORDER_REFLECT_101 source pixels over the
+// out-of-image ones (pixel -j <- pixel j, pixel W-1+j <- pixel W-1-j: 3R selects per side) — no divergent second path.
+template <bool SNOW, int RR, bool FAST>
+__global__ __launch_bounds__(256)
+void streak_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_prim_job> jobs, blur_taps bt,
+                         uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc,
+                         const uint32_t* __restrict__ bits_all, int wd)
+{
+    constexpr int R = RR, NR = strip_rows<RR>::value, NW = 4 + 2 * R, NBYTE = NW * 3, RING = 2 * R + 1;
+    constexpr int OFF = (4 - ((3 * R) & 3)) & 3;                 // (gx - R) * 3 mod 4 for gx % 4 == 0: 1 (R = 1), 3 (R = 3)
+    constexpr int ND = (OFF + NBYTE + 3) / 4;                    // dwords that hold the window's bytes: 5 / 9
+    __shared__ weather_lut L;
+    __shared__ float s_in[256 + 4];                              // pre-blur value of a byte; entries 256..258: the streak colour per channel,
+                                                                 // so a covered pixel is an index select in front of ONE table read
+    const awseg_prim_job job = jobs.j[blockIdx.z];
+    float pm, pa;
+    if (SNOW) { pm = 1.f; pa = (float)(job.intensity * 0.2); }
+    else { double haze = job.intensity * 0.3; pm = (float)(1.0 - haze); pa = (float)(haze * 0.7); }
+    for (int i = threadIdx.x; i < 256; i += 256) {
+        float v = (float)i / 255.0f;
+        if (SNOW) { v = v + pa; v = v < 0.f ? 0.f : (v > 1.f ? 1.f : v); }
+        else { v = v * pm; v = v + pa; }
+        s_in[i] = v;
+        if (i < 3) s_in[256 + i] = i == 2 ? 1.0f : (SNOW ? 1.0f : (i == 0 ? 0.8f : 0.9f));
+        if (norm_out) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) L.nrm[c][i] = norm1((uint8_t)i, nc.mean[c], nc.std[c]);
+        }
+    }
+    __syncthreads();
+    const int64_t hw = (int64_t)H * W;
+    const int gx = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * NR;
+    if (gx >= W || y0 >= H) return;
+    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
+    const uint32_t* bits = bits_all + (int64_t)blockIdx.z * H * wd;
+    uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
+    float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
+    const int nvalid = (W - gx) < 4 ? (W - gx) : 4;
+    const bool fast = FAST;
+    const float col[3] = { SNOW ? 1.0f : 0.8f, SNOW ? 1.0f : 0.9f, 1.0f };
+    const bool edge_l = gx - R < 0, edge_r = gx + 3 + R >= W;     // FAST: W >= 16, so never both
+    const int d0 = ((gx - R) * 3) >> 2;                           // first dword of the window in a row (arithmetic shift: -1 / -3 at the left edge)
+    int doff[ND];                                                 // byte offsets of the window's dwords in a row, clamped into the row
+#pragma unroll
+    for (int d = 0; d < ND; ++d) {
+        int di = d0 + d;
+        di = di < 0 ? 0 : (di > (W * 3) / 4 - 1 ? (W * 3) / 4 - 1 : di);
+        doff[d] = di * 4;
+    }
+    const int mb = (gx - R) >> 5, ms = (gx - R) & 31;             // coverage dword / shift of the window's first pixel (mb = -1 at the left edge)
+
+    uint32_t raw[ND]; uint32_t mlo = 0u, mhi = 0u;
+    auto issue = [&](int i) {                                     // loads of input row i (image row reflect(y0 - R + i))
+        const int gy = reflect_101(y0 - R + i, H);
+        if (fast) {
+            const uint8_t* rp = src + (int64_t)gy * W * 3;
+#pragma unroll
+            for (int d = 0; d < ND; ++d) raw[d] = *reinterpret_cast<const uint32_t*>(rp + doff[d]);
+            const uint32_t* mp = bits + (int64_t)gy * wd;
+            mlo = mb >= 0 ? mp[mb] : 0u; mhi = (mb + 1 < wd) ? mp[mb + 1] : 0u;
+        }
+    };
+    // pre-blur values of the window (NW pixels x 3) of input row i: from the registers `issue` filled, or pixel by pixel
+    auto window = [&](int i, float* win) {
+        if (fast) {
+            const uint32_t cb = (uint32_t)((((uint64_t)mhi << 32) | mlo) >> ms);
+#pragma unroll
+            for (int e = 0; e < NBYTE; ++e) {
+                const int k = e / 3, c = e - k * 3, bp = OFF + e;
+                const uint32_t byte = (raw[bp >> 2] >> (8 * (bp & 3))) & 0xFFu;
+                win[e] = s_in[((cb >> k) & 1u) ? 256u + c : byte];
+            }
+#pragma unroll
+            for (int j = 1; j <= R; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    win[(R - j) * 3 + c] = edge_l ? win[(R + j) * 3 + c] : win[(R - j) * 3 + c];
+                    win[(R + 3 + j) * 3 + c] = edge_r ? win[(R + 3 - j) * 3 + c] : win[(R + 3 + j) * 3 + c];
+                }
+        } else {
+            const int gy = reflect_101(y0 - R + i, H);
+#pragma unroll
+            for (int k = 0; k < NW; ++k) {
+                const int xk = reflect_101(gx - R + k, W);
+                const bool cov = ((bits[(int64_t)gy * wd + (xk >> 5)] >> (xk & 31)) & 1u) != 0u;
+                const uint8_t* px = src + ((int64_t)gy * W + xk) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) win[k * 3 + c] = cov ? col[c] : s_in[px[c]];
+            }
+        }
+    };
+    float ring[RING][12];
+    auto row_pass = [&](const float* win, float* o) {
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            float acc = bt.k[R] * win[e + 3 * R];
+#pragma unroll
+            for (int j = 1; j <= R; ++j) { float ab = win[e + 3 * R - 3 * j] + win[e + 3 * R + 3 * j]; float m = bt.k[R + j] * ab; acc = acc + m; }
+            o[e] = acc;
+        }
+    };
+    // output row o (image row y0 + o) from the ring; `ctr` = ring slot of its centre row
+    auto emit = [&](int o, int ctr) {
+        const int gy = y0 + o;
+        float acc[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) acc[e] = bt.k[R] * ring[ctr][e];
+#pragma unroll
+        for (int j = 1; j <= R; ++j) {
+            const int up = (ctr - j + 2 * RING) % RING, dn = (ctr + j) % RING;
+#pragma unroll
+            for (int e = 0; e < 12; ++e) { float ab = ring[up][e] + ring[dn][e]; float m = bt.k[R + j] * ab; acc[e] = acc[e] + m; }
+        }
+        uint8_t res[12];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) res[e] = (uint8_t)(int)(__builtin_amdgcn_fmed3f(acc[e], 0.f, 1.f) * 255.0f);   // quant_f32 with one v_med3
+        const int64_t p = (int64_t)gy * W + gx;
+        if (dst) {
+            if (FAST || (nvalid == 4 && ((p * 3) & 3) == 0)) {
+                uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    d4[q] = (uint32_t)res[4 * q] | ((uint32_t)res[4 * q + 1] << 8) | ((uint32_t)res[4 * q + 2] << 16) | ((uint32_t)res[4 * q + 3] << 24);
+            } else {
+                for (int k = 0; k < nvalid * 3; ++k) dst[p * 3 + k] = res[k];
+            }
+        }
+        if (ndst) {
+            if (FAST || (nvalid == 4 && (p & 3) == 0 && (hw & 3) == 0)) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
+                        make_float4(L.nrm[c][res[c]], L.nrm[c][res[3 + c]], L.nrm[c][res[6 + c]], L.nrm[c][res[9 + c]]);
+            } else {
+                for (int c = 0; c < 3; ++c)
+                    for (int k = 0; k < nvalid; ++k) ndst[(int64_t)c * hw + p + k] = L.nrm[c][res[k * 3 + c]];
+            }
+        }
+    };
+    const int rows_out = (H - y0) < NR ? (H - y0) : NR;           // output rows of this strip (wave-uniform)
+    issue(0);
+    for (int i0 = 0; i0 < NR + 2 * R; i0 += RING) {
+#pragma unroll
+        for (int u = 0; u < RING; ++u) {
+            const int i = i0 + u;                                  // ring slot of input row i is u (i0 is a multiple of RING)
+            if (i - 2 * R >= rows_out) return;                     // nothing left to emit (wave-uniform)
+            float win[NBYTE];
+            window(i, win);
+            if (i + 1 < NR + 2 * R) issue(i + 1);                  // next row's loads fly during this row's arithmetic
+            row_pass(win, ring[u]);
+            if (i >= 2 * R) emit(i - 2 * R, (u - R + RING) % RING);
+        }
+    }
+}
+
+// Coverage pre-pass: one wave per primitive of a frame, the same integer rasteriser writing a frame-wide 1-bit map
+// (atomicOr; bits[job][H][wd]).  The map is zeroed by the launcher.
+template <bool SNOW>
+__global__ __launch_bounds__(256)
+void raster_kernel(int H, int W, job_pack<awseg_prim_job> jobs, const int32_t* __restrict__ prims, uint32_t* __restrict__ bits_all, int wd)
+{
+    const awseg_prim_job job = jobs.j[blockIdx.y];
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= job.prim_count) return;                                        // wave-uniform
+    tile_mask mk;
+    mk.m = nullptr; mk.W = W; mk.H = H; mk.x0 = 0; mk.y0 = 0; mk.w = W; mk.h = H;
+    mk.bits = bits_all + (int64_t)blockIdx.y * H * wd; mk.wd = wd;
+    const int32_t* pl = prims + (int64_t)job.prim_offset * (SNOW ? 3 : 5);
+    if (SNOW) m_disc(mk, pl[i * 3], pl[i * 3 + 1], pl[i * 3 + 2], lane);
+    else {
+        const int ax = pl[i * 5], ay = pl[i * 5 + 1], bx = pl[i * 5 + 2], by = pl[i * 5 + 3], th = pl[i * 5 + 4];
+        if (th <= 1) m_line_thin(mk, ax, ay, bx, by, lane);
+        else m_line_thick(mk, ax, ay, bx, by, th, lane);
     }
 }
 
@@ -1157,8 +1379,11 @@ AWSEG_API int awseg_night_apply(const uint8_t* imgs, int height, int width, cons
 
 static int streak_common(bool snow, const uint8_t* imgs, int H, int W, const awseg_prim_job* jobs, int n_jobs,
                          const int32_t* prims, uint8_t* out, float* norm_out, const float* mean_host,
-                         const float* std_host, hipStream_t s)
+                         const float* std_host, void* workspace, hipStream_t s)
 {
+    if (workspace && ((uintptr_t)workspace & 3)) return AWSEG_EALIGN;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(workspace);
+    const int wd = (W + 31) / 32;
     if (!imgs || !jobs || (!out && !norm_out) || H < 1 || W < 1 || n_jobs < 0) return AWSEG_EINVAL;
     if (norm_out && (!mean_host || !std_host)) return AWSEG_EINVAL;
     if (n_jobs == 0) return 0;
@@ -1179,9 +1404,37 @@ static int streak_common(bool snow, const uint8_t* imgs, int H, int W, const aws
             if (cnt == kMaxJobs || (j == n_jobs && cnt > 0)) {
                 const job_pack<awseg_prim_job> pk = pack_jobs(sel, 0, cnt);
                 dim3 grid((W + BTW - 1) / BTW, (H + BTH - 1) / BTH, cnt);
-                if (!snow) hipLaunchKernelGGL((streak_kernel<false, 1>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 0.5), out, norm_out, nc);
-                else if (!want7) hipLaunchKernelGGL((streak_kernel<true, 1>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 1.0), out, norm_out, nc);
-                else hipLaunchKernelGGL((streak_kernel<true, 3>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(7, 1.0), out, norm_out, nc);
+                if (bits) {
+                    // the group's coverage maps live at the start of the workspace (groups run back to back on the stream)
+                    int maxp = 0;
+                    for (int q = 0; q < cnt; ++q) maxp = sel[q].prim_count > maxp ? sel[q].prim_count : maxp;
+                    if (hipMemsetAsync(bits, 0, (size_t)cnt * H * wd * sizeof(uint32_t), s) != hipSuccess) return AWSEG_EINVAL;
+                    if (maxp > 0) {
+                        dim3 rgrid((maxp + 3) / 4, cnt);
+                        if (snow) hipLaunchKernelGGL((raster_kernel<true>), rgrid, dim3(256), 0, s, H, W, pk, prims, bits, wd);
+                        else hipLaunchKernelGGL((raster_kernel<false>), rgrid, dim3(256), 0, s, H, W, pk, prims, bits, wd);
+                        AWSEG_LAUNCH_CHECK();
+                    }
+                    static const bool tiles = getenv("AWSEG_STREAK_TILES") != nullptr;   // measurements: the tile kernel on the coverage map
+                    const int nr = want7 ? strip_rows<3>::value : strip_rows<1>::value;
+                    dim3 sgrid((W + 255) / 256, (H + 4 * nr - 1) / (4 * nr), cnt);
+                    if (tiles || sgrid.y > 65535 || want7) {            // 7x7 as a strip needs 222 registers (two waves per SIMD): 303 us against 161
+                        if (!snow) hipLaunchKernelGGL((streak_kernel<false, 1, true>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 0.5), out, norm_out, nc, bits, wd);
+                        else if (!want7) hipLaunchKernelGGL((streak_kernel<true, 1, true>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 1.0), out, norm_out, nc, bits, wd);
+                        else hipLaunchKernelGGL((streak_kernel<true, 3, true>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(7, 1.0), out, norm_out, nc, bits, wd);
+                    }
+#define AWSEG_STRIP(SN, RV, TAPS)                                                                                                       \
+    do {                                                                                                                              \
+        if ((W & 3) == 0 && W >= 16) hipLaunchKernelGGL((streak_strip_kernel<SN, RV, true>), sgrid, dim3(256), 0, s, imgs, H, W, pk, TAPS, out, norm_out, nc, bits, wd); \
+        else hipLaunchKernelGGL((streak_strip_kernel<SN, RV, false>), sgrid, dim3(256), 0, s, imgs, H, W, pk, TAPS, out, norm_out, nc, bits, wd);                          \
+    } while (0)
+                    else if (!snow) AWSEG_STRIP(false, 1, make_blur(3, 0.5));
+                    else if (!want7) AWSEG_STRIP(true, 1, make_blur(3, 1.0));
+#undef AWSEG_STRIP
+                }
+                else if (!snow) hipLaunchKernelGGL((streak_kernel<false, 1, false>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 0.5), out, norm_out, nc, bits, wd);
+                else if (!want7) hipLaunchKernelGGL((streak_kernel<true, 1, false>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(3, 1.0), out, norm_out, nc, bits, wd);
+                else hipLaunchKernelGGL((streak_kernel<true, 3, false>), grid, dim3(kSThreads), 0, s, imgs, H, W, pk, prims, make_blur(7, 1.0), out, norm_out, nc, bits, wd);
                 AWSEG_LAUNCH_CHECK();
                 cnt = 0;
             }
@@ -1190,18 +1443,25 @@ static int streak_common(bool snow, const uint8_t* imgs, int H, int W, const aws
     return 0;
 }
 
+AWSEG_API int64_t awseg_streak_workspace(int n_jobs, int height, int width)
+{
+    if (n_jobs < 1 || height < 1 || width < 1) return 0;
+    const int64_t group = n_jobs < kMaxJobs ? n_jobs : kMaxJobs;     // frames of one launch group share the buffer's start
+    return group * height * ((width + 31) / 32) * (int64_t)sizeof(uint32_t);
+}
+
 AWSEG_API int awseg_rain_apply(const uint8_t* imgs, int height, int width, const awseg_prim_job* jobs, int n_jobs,
                                const int32_t* drops, uint8_t* out, float* norm_out, const float* mean_host,
-                               const float* std_host, awseg_stream_t stream)
+                               const float* std_host, void* workspace, awseg_stream_t stream)
 {
-    return streak_common(false, imgs, height, width, jobs, n_jobs, drops, out, norm_out, mean_host, std_host, awseg_s(stream));
+    return streak_common(false, imgs, height, width, jobs, n_jobs, drops, out, norm_out, mean_host, std_host, workspace, awseg_s(stream));
 }
 
 AWSEG_API int awseg_snow_apply(const uint8_t* imgs, int height, int width, const awseg_prim_job* jobs, int n_jobs,
                                const int32_t* flakes, uint8_t* out, float* norm_out, const float* mean_host,
-                               const float* std_host, awseg_stream_t stream)
+                               const float* std_host, void* workspace, awseg_stream_t stream)
 {
-    return streak_common(true, imgs, height, width, jobs, n_jobs, flakes, out, norm_out, mean_host, std_host, awseg_s(stream));
+    return streak_common(true, imgs, height, width, jobs, n_jobs, flakes, out, norm_out, mean_host, std_host, workspace, awseg_s(stream));
 }
 
 AWSEG_API int awseg_fog_density_field(const float* scale_offset, int batch, int64_t hw, uint64_t seed, const float* uniform,

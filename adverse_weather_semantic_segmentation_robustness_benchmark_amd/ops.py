@@ -278,18 +278,28 @@ def night(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = 
                                       N.ptr(norm_out), N.host(m), N.host(s), N.stream())
 
 
-def rain(imgs: torch.Tensor, jobs: np.ndarray, drops: np.ndarray, out=None, norm_out=None, mean=None, std=None) -> None:
-    """_apply_rain (PKG/data/preprocessing.py:125-168)."""
+def _streak_workspace(imgs: torch.Tensor, n_jobs: int, h: int, w: int, prepass: bool):
+    """Coverage-map scratch of the rain / snow launchers (awseg_streak_workspace); None = rasterise inside the blur kernel."""
+    if not prepass or n_jobs < 1:
+        return None
+    return N.workspace.get(imgs.device, N.lib().awseg_streak_workspace(n_jobs, h, w), tag="streak")
+
+
+def rain(imgs: torch.Tensor, jobs: np.ndarray, drops: np.ndarray, out=None, norm_out=None, mean=None, std=None,
+         prepass: bool = True) -> None:
+    """_apply_rain (PKG/data/preprocessing.py:125-168).  prepass: rasterise the drops once per frame into a coverage bit map
+    (a second small kernel) instead of in every tile they touch — same bytes out."""
     imgs = imgs.contiguous()
     _, h, w, _ = imgs.shape
     jd = N.host_jobs(jobs)
     pd = torch.from_numpy(np.ascontiguousarray(drops, dtype=np.int32)).to(imgs.device, non_blocking=True)
     m, s = _mean_std(mean, std)
     N.call("awseg_rain_apply", N.ptr(imgs), h, w, jd, len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
-                                     N.host(m), N.host(s), N.stream())
+                                     N.host(m), N.host(s), N.ptr(_streak_workspace(imgs, len(jobs), h, w, prepass)), N.stream())
 
 
-def snow(imgs: torch.Tensor, jobs: np.ndarray, flakes: np.ndarray, out=None, norm_out=None, mean=None, std=None) -> None:
+def snow(imgs: torch.Tensor, jobs: np.ndarray, flakes: np.ndarray, out=None, norm_out=None, mean=None, std=None,
+         prepass: bool = True) -> None:
     """_apply_snow (PKG/data/preprocessing.py:170-202)."""
     imgs = imgs.contiguous()
     _, h, w, _ = imgs.shape
@@ -297,7 +307,7 @@ def snow(imgs: torch.Tensor, jobs: np.ndarray, flakes: np.ndarray, out=None, nor
     pd = torch.from_numpy(np.ascontiguousarray(flakes, dtype=np.int32)).to(imgs.device, non_blocking=True)
     m, s = _mean_std(mean, std)
     N.call("awseg_snow_apply", N.ptr(imgs), h, w, jd, len(jobs), N.ptr(pd), N.ptr(out), N.ptr(norm_out),
-                                     N.host(m), N.host(s), N.stream())
+                                     N.host(m), N.host(s), N.ptr(_streak_workspace(imgs, len(jobs), h, w, prepass)), N.stream())
 
 
 _DENSITY_TABLE = {"fog": (0.5, 0.5), "rain": (0.3, 0.2), "snow": (0.3, 0.2)}   # trainer.py:501-509, else (0.1, 0)

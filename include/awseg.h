@@ -282,7 +282,12 @@ int awseg_rain_apply(const uint8_t* imgs, int height, int width,
                      const awseg_prim_job* jobs, int n_jobs, const int32_t* drops,
                      uint8_t* out, float* norm_out,
                      const float* mean_host, const float* std_host,
-                     awseg_stream_t stream);
+                     void* workspace, awseg_stream_t stream);
+
+/* Device scratch for awseg_rain_apply / awseg_snow_apply: with a workspace of this many bytes the primitives of a frame are
+ * rasterised ONCE into a 1-bit coverage map (one wave per primitive) and the blur kernel is a pure stencil; with
+ * workspace == NULL every 64x32 tile rasterises the primitives that touch it.  Same bytes out either way. */
+int64_t awseg_streak_workspace(int n_jobs, int height, int width);
 
 /* ------------------------------------------------------------------------- *
  *  A5  _apply_snow           replaces PKG/data/preprocessing.py:176-202
@@ -295,7 +300,7 @@ int awseg_snow_apply(const uint8_t* imgs, int height, int width,
                      const awseg_prim_job* jobs, int n_jobs, const int32_t* flakes,
                      uint8_t* out, float* norm_out,
                      const float* mean_host, const float* std_host,
-                     awseg_stream_t stream);
+                     void* workspace, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A16  AdverseWeatherTrainer._estimate_fog_density

@@ -427,6 +427,148 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<aw
     }
 }
 
+// Throughput-mode fog as a STRIP kernel (W % 4 == 0): a lane owns 4 adjacent pixels and walks the rows of a strip; a wave is
+// 64 adjacent pixel quads of which the inner 60 produce output (two halo quads per side feed the horizontal taps).
+//   noise        one Philox call per (row pair, quad): its 16 bytes are the 2 x 4 byte-difference samples of the lane's four
+//                pixels in two consecutive rows — drawn once per sample of the strip (+ the 16 halo rows), not once per tile.
+//   horizontal   17 taps over the 20-value window the lane assembles from its own quad and its neighbours' (wave shifts by one
+//                lane: v_mov_b32 dpp wave_shr / wave_shl, no LDS); scipy's 'reflect' at the image border = the reflected quad's
+//                samples in reverse order, chosen per lane.
+//   vertical     17 taps over the last 17 horizontal results, kept in a per-lane LDS column (one 16-byte write, 17 reads per
+//                row at a dynamic slot: no register ring to rotate, no 17-fold unrolled body).
+//   blend        in byte units as in the tile kernel.
+// The depth pipeline is float32 and the order of the two passes is swapped against the tile kernel (separable filter); parity
+// in this mode is in distribution (tests: the depth field against scipy on the SAME Philox samples, and its moments).
+__device__ __forceinline__ float dpp_from_prev(float v)     // lane i <- lane i - 1 (lane 0 <- 0)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float dpp_from_next(float v)     // lane i <- lane i + 1 (lane 63 <- 0)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xF, 0xF, true));
+}
+constexpr int kFogStripQuads = 60;                           // output quads per wave
+constexpr int kFogRing = 2 * FR + 1;                         // 17
+
+__global__ __launch_bounds__(256)
+void fog_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_fog_job> jobs, int job0,
+                      gauss_taps_f32 taps, uint8_t* __restrict__ out, float* __restrict__ norm_out,
+                      double* __restrict__ depth_out, norm_consts nc, int rows_per_strip)
+{
+    __shared__ weather_lut L;
+    extern __shared__ float4 s_ring[];                       // [17][256]
+    lut_fill(L, nc, norm_out != nullptr);
+    __syncthreads();
+    const awseg_fog_job job = jobs.j[blockIdx.z];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int Wq = W >> 2;
+    const int q = blockIdx.x * kFogStripQuads - 2 + lane;    // this lane's pixel quad (may lie outside the row)
+    const int y0 = (blockIdx.y * 4 + wv) * rows_per_strip;
+    if (y0 >= H) return;                                     // wave-uniform
+    const int rows_out = (H - y0) < rows_per_strip ? (H - y0) : rows_per_strip;
+    // scipy 'reflect' (d c b a | a b c d | d c b a) on pixels = the mirrored quad, its four samples in reverse order
+    int qs = q; bool rev = false;
+    if (q < 0) { qs = -q - 1; rev = true; } else if (q >= Wq) { qs = 2 * Wq - 1 - q; rev = true; }
+    qs = qs < 0 ? 0 : (qs > Wq - 1 ? Wq - 1 : qs);
+    const bool own = lane >= 2 && lane < 62 && q < Wq;
+    const int gx = q * 4;
+    const int64_t hw = (int64_t)H * W;
+    const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
+    uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
+    float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
+    double* ddst = depth_out ? depth_out + (int64_t)(job0 + blockIdx.z) * hw : nullptr;
+    const float beta = (float)job.beta, A255 = 255.0f * (float)job.atmos;
+    const float inv_h = 100.0f / (float)H;
+    const float kAmp = 10.0f * 0.009584116f;                 // sigma 10 x 1 / sqrt(2 (256^2 - 1) / 12): unit-variance byte differences
+    float4* col = s_ring + threadIdx.x;                      // this lane's column: slot s at col[s * 256]
+    int pair = -1; uint32_t r[4] = { 0u, 0u, 0u, 0u };
+    for (int i = 0; i < rows_out + 2 * FR; ++i) {
+        const int gy = reflect_sym(y0 - FR + i, H);
+        uint32_t px0 = 0u, px1 = 0u, px2 = 0u;               // the output row this iteration closes: its source pixels, requested early
+        const int oy = y0 + i - 2 * FR;
+        if (i >= 2 * FR && own) {
+            const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + ((int64_t)oy * W + gx) * 3);
+            px0 = s4[0]; px1 = s4[1]; px2 = s4[2];
+        }
+        if ((gy >> 1) != pair) {                             // wave-uniform
+            pair = gy >> 1;
+            awseg_philox::gen(job.seed, (uint64_t)pair * Wq + qs, 0x0F07u, r);
+        }
+        const uint32_t w0 = (gy & 1) ? r[2] : r[0], w1 = (gy & 1) ? r[3] : r[1];
+        float n0 = (float)(w0 & 0xFFu) - (float)((w0 >> 8) & 0xFFu), n1 = (float)((w0 >> 16) & 0xFFu) - (float)(w0 >> 24);
+        float n2 = (float)(w1 & 0xFFu) - (float)((w1 >> 8) & 0xFFu), n3 = (float)((w1 >> 16) & 0xFFu) - (float)(w1 >> 24);
+        const float base = (float)gy * inv_h;
+        float win[20];
+        win[8] = fmaf(kAmp, rev ? n3 : n0, base); win[9] = fmaf(kAmp, rev ? n2 : n1, base);
+        win[10] = fmaf(kAmp, rev ? n1 : n2, base); win[11] = fmaf(kAmp, rev ? n0 : n3, base);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            win[4 + k] = dpp_from_prev(win[8 + k]); win[k] = dpp_from_prev(win[4 + k]);
+            win[12 + k] = dpp_from_next(win[8 + k]); win[16 + k] = dpp_from_next(win[12 + k]);
+        }
+        float4 hres;
+        {
+            float o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float a = win[k + FR] * taps.w[FR];
+#pragma unroll
+                for (int j = 1; j <= FR; ++j) a = fmaf(win[k + FR - j] + win[k + FR + j], taps.w[FR + j], a);
+                o[k] = a;
+            }
+            hres = make_float4(o[0], o[1], o[2], o[3]);
+        }
+        col[(i % kFogRing) * 256] = hres;                    // only this lane reads its column: no barrier
+        if (i < 2 * FR) continue;
+        // vertical taps over input rows i-16 .. i (centre i-8)
+        // (an f16 ring of the noise part, read back through v_fma_mix_f32, halves the LDS footprint but the grid — not LDS —
+        // bounds residency at this strip height, and 68 mixed FMAs replace 34 packed float32 ones: measured 93 us against 79)
+        float d[4];
+        {
+            const int c = (i - FR) % kFogRing;
+            const float4 ctr = col[c * 256];
+            d[0] = ctr.x * taps.w[FR]; d[1] = ctr.y * taps.w[FR]; d[2] = ctr.z * taps.w[FR]; d[3] = ctr.w * taps.w[FR];
+#pragma unroll
+            for (int j = 1; j <= FR; ++j) {
+                int up = c - j; up += up < 0 ? kFogRing : 0;
+                int dn = c + j; dn -= dn >= kFogRing ? kFogRing : 0;
+                const float4 a = col[up * 256], b = col[dn * 256];
+                d[0] = fmaf(a.x + b.x, taps.w[FR + j], d[0]); d[1] = fmaf(a.y + b.y, taps.w[FR + j], d[1]);
+                d[2] = fmaf(a.z + b.z, taps.w[FR + j], d[2]); d[3] = fmaf(a.w + b.w, taps.w[FR + j], d[3]);
+            }
+        }
+        if (!own) continue;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d[k] = d[k] > 1.0f ? d[k] : 1.0f;                 // np.maximum(depth, 1.0), :246
+        const int64_t p = (int64_t)oy * W + gx;
+        if (ddst) { for (int k = 0; k < 4; ++k) ddst[p + k] = (double)d[k]; }
+        uint8_t res[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float t = __expf(-beta * d[k]);
+            const float hz = A255 * (1.0f - t);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int e = k * 3 + c;
+                const uint32_t word = (e >> 2) == 0 ? px0 : ((e >> 2) == 1 ? px1 : px2);
+                res[e] = (uint8_t)(int)__builtin_amdgcn_fmed3f(fmaf((float)((word >> (8 * (e & 3))) & 0xFFu), t, hz), 0.f, 255.f);
+            }
+        }
+        if (dst) {
+            uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
+#pragma unroll
+            for (int wq = 0; wq < 3; ++wq)
+                d4[wq] = (uint32_t)res[4 * wq] | ((uint32_t)res[4 * wq + 1] << 8) | ((uint32_t)res[4 * wq + 2] << 16) | ((uint32_t)res[4 * wq + 3] << 24);
+        }
+        if (ndst) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
+                    make_float4(L.nrm[c][res[c]], L.nrm[c][res[3 + c]], L.nrm[c][res[6 + c]], L.nrm[c][res[9 + c]]);
+        }
+    }
+}
+
 // fog from a caller-provided depth map (the two-step form of the reference).
 __global__ __launch_bounds__(kThreads)
 void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_fog_job> jobs, int job0,
@@ -1307,7 +1449,30 @@ static int fog_common(int mode, const uint8_t* imgs, int H, int W, const awseg_f
 #define AWSEG_FOG(P, M) hipLaunchKernelGGL((fog_kernel<P, M>), grid, dim3(kThreads), 0, s, imgs, H, W, pk, j0, noise, t, out, norm_out, depth_out, nc)
         if (noise) { if (mode) AWSEG_FOG(false, 1); else AWSEG_FOG(false, 0); }
         else if (mode == 0) AWSEG_FOG(true, 0);      // depth-only request keeps the float64 pipeline
-        else hipLaunchKernelGGL(fog_fast_kernel, grid, dim3(kFogFastThreads), 0, s, imgs, H, W, pk, j0, tf, out, norm_out, depth_out, nc);
+        else {
+            const char* sr_env = getenv("AWSEG_FOG_STRIP_ROWS");             // rows per strip; 0: the tile kernel (read per call: tests vary it)
+            int strip_rows = sr_env ? atoi(sr_env) : -1;
+            if (strip_rows < 0) {
+                // two 256-thread blocks fit a CU (70 KB LDS ring each): the strip height that makes the grid ONE round of them
+                const int64_t per_round = (int64_t)AWSEG_CUS * 2 / (((W >> 2) + kFogStripQuads - 1) / kFogStripQuads) / cnt;   // y-blocks (4 strips each) available
+                strip_rows = per_round >= 1 ? (int)((H + 4 * per_round - 1) / (4 * per_round)) : H;
+                if (strip_rows < 24) strip_rows = 24;                     // below that the 16 halo rows dominate: take more rounds instead
+            }
+            const bool strip_ok = strip_rows >= 1 && (W & 3) == 0 && W >= 16 && (((uintptr_t)imgs & 3) == 0) &&
+                                  (!out || ((uintptr_t)out & 3) == 0) && (!norm_out || ((uintptr_t)norm_out & 15) == 0);
+            const int strips = strip_ok ? (H + strip_rows - 1) / strip_rows : 0;
+            if (strip_ok && (strips + 3) / 4 <= 65535) {
+                const size_t lds = (size_t)kFogRing * 256 * sizeof(float4);
+                static bool attr_set = false;
+                if (!attr_set) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(fog_strip_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AWSEG_EINVAL;
+                    attr_set = true;
+                }
+                dim3 sgrid(((W >> 2) + kFogStripQuads - 1) / kFogStripQuads, (strips + 3) / 4, cnt);
+                hipLaunchKernelGGL(fog_strip_kernel, sgrid, dim3(256), lds, s, imgs, H, W, pk, j0, tf, out, norm_out, depth_out, nc, strip_rows);
+            }
+            else hipLaunchKernelGGL(fog_fast_kernel, grid, dim3(kFogFastThreads), 0, s, imgs, H, W, pk, j0, tf, out, norm_out, depth_out, nc);
+        }
 #undef AWSEG_FOG
         AWSEG_LAUNCH_CHECK();
     }

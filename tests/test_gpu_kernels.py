@@ -267,6 +267,48 @@ def test_philox_modes_are_deterministic_and_plausible(ops):
     assert 0.2 <= f[1].min().item() and f[1].max().item() < 0.5 and f[2].max().item() < 0.1
 
 
+def _philox4x32_7(seed, ctr, stream):
+    """numpy restatement of awseg_philox::gen (csrc/awseg_common.h): Philox4x32 with 7 rounds; ctr is a uint64 array."""
+    M0, M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+    mask = np.uint64(0xFFFFFFFF)
+    c0, c1 = ctr & mask, ctr >> np.uint64(32)
+    c2, c3 = np.full_like(ctr, stream), np.full_like(ctr, 0x9E3779B9)
+    k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
+    for _ in range(7):
+        p0, p1 = M0 * c0, M1 * c2
+        n0, n2 = (p1 >> np.uint64(32)) ^ c1 ^ k0, (p0 >> np.uint64(32)) ^ c3 ^ k1
+        c0, c1, c2, c3 = n0, p1 & mask, n2, p0 & mask
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return [c0, c1, c2, c3]
+
+
+@pytest.mark.parametrize("geom", [(70, 256, 32), (200, 512, 32), (64, 128, 7), (37, 16, 32)])
+def test_philox_fog_strip_kernel_depth_equals_scipy_on_the_same_samples(ops, geom, monkeypatch):
+    """The strip form of throughput-mode fog (lane = 4 pixels, wave shifts for the horizontal taps, LDS column for the
+    vertical ones, scipy 'reflect' by mirrored quads / reflected rows): its depth output against scipy.ndimage on the field
+    rebuilt from the SAME Philox bytes — strips that end inside the image, waves that end inside a row, every border."""
+    from scipy.ndimage import gaussian_filter
+    h, w, rows = geom
+    monkeypatch.setenv("AWSEG_FOG_STRIP_ROWS", str(rows))
+    imgs = torch.randint(0, 255, (2, h, w, 3), dtype=torch.uint8, device="cuda")
+    seeds = [0x1234567 + h, (7 << 40) + w]
+    a = torch.empty_like(imgs)
+    d = torch.empty(2, h, w, dtype=torch.float64, device="cuda")
+    ops.fog(imgs, ops.fog_jobs([0, 1], [0.5, 0.3], seeds=seeds), out=a, depth_out=d)
+    wq = w // 4
+    gy, q = np.meshgrid(np.arange(h, dtype=np.uint64), np.arange(wq, dtype=np.uint64), indexing="ij")
+    for b in range(2):
+        words = _philox4x32_7(seeds[b], (gy >> np.uint64(1)) * np.uint64(wq) + q, 0x0F07)
+        odd = (gy & np.uint64(1)).astype(bool)
+        w0, w1 = np.where(odd, words[2], words[0]), np.where(odd, words[3], words[1])
+        byte = lambda x, k: ((x >> np.uint64(8 * k)) & np.uint64(0xFF)).astype(np.float64)
+        n = np.stack([byte(w0, 0) - byte(w0, 1), byte(w0, 2) - byte(w0, 3), byte(w1, 0) - byte(w1, 1), byte(w1, 2) - byte(w1, 3)], axis=-1)
+        field = (np.arange(h)[:, None] * (100.0 / h)) + 10.0 * 0.009584116 * n.reshape(h, w)
+        ref = np.maximum(gaussian_filter(field, sigma=2, mode="reflect", truncate=4.0), 1.0)
+        err = np.abs(d[b].cpu().numpy() - ref).max()
+        assert err < 2e-3, (geom, b, err)                                # float32 filter on values up to 100
+
+
 def test_philox_fog_noise_field_has_the_reference_moments(ops):
     """Throughput-mode fog synthesises its depth noise in the kernel from cheap non-Gaussian white noise (differences of
     random bytes); what the transform uses is that noise through scipy's 17-tap sigma-2 Gaussian on both axes.  The field

@@ -848,7 +848,100 @@ __device__ void m_fill_convex4(const tile_mask& k, const int64_t* vx, const int6
         xB += dxB;
     } while (++y <= (int)ymax);
 }
-__device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1, int thickness, int lane)
+// The same polygon fill with the SCANLINES spread over the lanes (coverage pre-pass: one wave owns the whole primitive).
+// The edge walk above changes state only at the scanlines where an edge ends; between two such events an edge's abscissa
+// is x_start + (y - y_start) * dx in exact integer arithmetic — what the serial walk reaches by adding dx once per scanline.
+// Every lane runs the (wave-uniform, at most npts + 1 iterations) event loop with the serial code's own transition
+// statements, and draws its scanline when the loop passes over it.  A lane writes its whole span itself.
+__device__ __forceinline__ void m_hline_lane(const tile_mask& k, int y, int xa, int xb)
+{
+    if (y < 0 || y >= k.H) return;
+    if (xa < 0) xa = 0;
+    if (xb >= k.W) xb = k.W - 1;
+    const int ry = y - k.y0;
+    if (ry < 0 || ry >= k.h) return;
+    int a = xa - k.x0, b = xb - k.x0;
+    if (a < 0) a = 0;
+    if (b >= k.w) b = k.w - 1;
+    if (k.bits) {
+        for (int dw = a >> 5; dw <= (b >> 5); ++dw) {
+            const int lo = a > dw * 32 ? a - dw * 32 : 0, hi = b < dw * 32 + 31 ? b - dw * 32 : 31;
+            if (hi < lo) continue;
+            const uint32_t m = (hi - lo == 31) ? 0xFFFFFFFFu : (((1u << (hi - lo + 1)) - 1u) << lo);
+            atomicOr(&k.bits[(int64_t)ry * k.wd + dw], m);
+        }
+    } else {
+        for (int x = a; x <= b; ++x) k.m[ry * k.w + x] = 1;
+    }
+}
+__device__ void m_fill_convex4_lanes(const tile_mask& k, const int64_t* vx, const int64_t* vy, int lane)
+{
+    const int npts = 4;
+    const int64_t delta = XY_ONE >> 1;
+    int imin = 0, edges = npts;
+    int64_t xmin = vx[0], xmax = vx[0], ymin = vy[0], ymax = vy[0];
+    int64_t px = vx[3], py = vy[3];
+#pragma unroll
+    for (int i = 0; i < npts; ++i) {
+        if (vy[i] < ymin) { ymin = vy[i]; imin = i; }
+        if (vy[i] > ymax) ymax = vy[i];
+        if (vx[i] > xmax) xmax = vx[i];
+        if (vx[i] < xmin) xmin = vx[i];
+        m_line2(k, px, py, vx[i], vy[i], lane);
+        px = vx[i]; py = vy[i];
+    }
+    xmin = (xmin + delta) >> XY_SHIFT; xmax = (xmax + delta) >> XY_SHIFT;
+    ymin = (ymin + delta) >> XY_SHIFT; ymax = (ymax + delta) >> XY_SHIFT;
+    if ((int)xmax < 0 || (int)ymax < 0 || (int)xmin >= k.W || (int)ymin >= k.H) return;
+    if (ymax > k.H - 1) ymax = k.H - 1;
+    int y = (int)ymin;
+    int idxA = imin, idxB = imin, yeA = y, yeB = y;
+    int ysA = y, ysB = y;                                        // scanline at which the current edge of a side was entered
+    int64_t xsA = -XY_ONE, xsB = -XY_ONE, dxA = 0, dxB = 0;      // abscissa there, slope per scanline
+    while (y <= (int)ymax) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int& e_idx = i == 0 ? idxA : idxB;
+            int& e_ye = i == 0 ? yeA : yeB;
+            int& e_ys = i == 0 ? ysA : ysB;
+            int64_t& e_x = i == 0 ? xsA : xsB;
+            int64_t& e_dx = i == 0 ? dxA : dxB;
+            const int di = i == 0 ? 1 : npts - 1;
+            if (y >= e_ye) {
+                int idx0 = e_idx;
+                int idx = idx0 + di; if (idx >= npts) idx -= npts;
+                for (; edges-- > 0;) {
+                    const int ty = (int)((sel4(vy, idx) + delta) >> XY_SHIFT);
+                    if (ty > y) {
+                        const int64_t xs = sel4(vx, idx0), xe = sel4(vx, idx);
+                        e_ye = ty;
+                        e_dx = div_trunc((xe - xs) * 2 + (ty - y), 2 * (ty - y));
+                        e_x = xs; e_ys = y;
+                        e_idx = idx;
+                        break;
+                    }
+                    idx0 = idx; idx += di; if (idx >= npts) idx -= npts;
+                }
+            }
+        }
+        if (edges < 0) break;
+        // scanlines y .. ynext-1 keep both edges; lanes take them 64 at a time
+        int ynext = yeA < yeB ? yeA : yeB;
+        if (ynext > (int)ymax + 1) ynext = (int)ymax + 1;
+        for (int yy = y + lane; yy < ynext; yy += 64) {
+            if (yy >= 0) {
+                const int64_t xa = xsA + (int64_t)(yy - ysA) * dxA, xb = xsB + (int64_t)(yy - ysB) * dxB;
+                const int64_t xl = xa > xb ? xb : xa, xr = xa > xb ? xa : xb;
+                const int xx1 = (int)((xl + (XY_ONE >> 1)) >> XY_SHIFT);
+                const int xx2 = (int)((xr + (XY_ONE >> 1)) >> XY_SHIFT);
+                if (xx2 >= 0 && xx1 < k.W) m_hline_lane(k, yy, xx1, xx2);
+            }
+        }
+        y = ynext;
+    }
+}
+template <bool LANES>
+__device__ void m_line_thick_t(const tile_mask& k, int x0, int y0, int x1, int y1, int thickness, int lane)
 {
     int64_t p0x = (int64_t)x0 << XY_SHIFT, p0y = (int64_t)y0 << XY_SHIFT;
     int64_t p1x = (int64_t)x1 << XY_SHIFT, p1y = (int64_t)y1 << XY_SHIFT;
@@ -862,11 +955,15 @@ __device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1,
         int64_t dpx = (int64_t)rint(dy * r), dpy = (int64_t)rint(dx * r);
         int64_t vx[4] = { p0x + dpx, p0x - dpx, p1x - dpx, p1x + dpx };
         int64_t vy[4] = { p0y + dpy, p0y - dpy, p1y - dpy, p1y + dpy };
-        m_fill_convex4(k, vx, vy, lane);
+        if (LANES) m_fill_convex4_lanes(k, vx, vy, lane); else m_fill_convex4(k, vx, vy, lane);
     }
     int rad = (int)((th + (XY_ONE >> 1)) >> XY_SHIFT);
     m_disc(k, x0, y0, rad, lane);
     m_disc(k, x1, y1, rad, lane);
+}
+__device__ void m_line_thick(const tile_mask& k, int x0, int y0, int x1, int y1, int thickness, int lane)
+{
+    m_line_thick_t<false>(k, x0, y0, x1, y1, thickness, lane);
 }
 
 // ---------------------------------------------------------------------- A4 rain / A5 snow
@@ -1333,7 +1430,7 @@ void raster_kernel(int H, int W, job_pack<awseg_prim_job> jobs, const int32_t* _
     else {
         const int ax = pl[i * 5], ay = pl[i * 5 + 1], bx = pl[i * 5 + 2], by = pl[i * 5 + 3], th = pl[i * 5 + 4];
         if (th <= 1) m_line_thin(mk, ax, ay, bx, by, lane);
-        else m_line_thick(mk, ax, ay, bx, by, th, lane);
+        else m_line_thick_t<true>(mk, ax, ay, bx, by, th, lane);
     }
 }
 

@@ -159,32 +159,43 @@ def algorithmic_work(name, B, H, W, C, info):
 
 
 # device-function names of the C-ABI launchers' dominant kernels (for the PMC traffic lookup)
-DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg_conv3x3_winograd_split_nhwc": "wino_split_kernel<1, false>", "awseg_conv3x3_winograd_bf16_nhwc": "wino_split_kernel<1, true>", "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
-                 "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_kernel"}
+DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg_conv3x3_winograd_split_nhwc": ("wino_split_kernel<0, false>", "wino_split_kernel<1, false>"), "awseg_conv3x3_winograd_bf16_nhwc": ("wino_split_kernel<0, true>", "wino_split_kernel<1, true>"), "awseg_gemm_split_bias_act": ("gemm_split_kernel<2, 2, 2, 4, false, false>", "gemm_split_kernel<1, 2, 4, 2, false, false>", "gemm_split_kernel<2, 2, 2, 4, true, false>", "gemm_split_kernel<1, 2, 4, 2, true, false>"),
+                 "awseg_gemm_bf16_bias_act": ("gemm_split_kernel<2, 2, 2, 4, false, true>", "gemm_split_kernel<1, 2, 4, 2, false, true>"),
+                 "awseg_attention_d32_split": "attention_d32_split_kernel",
+                 "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
+                 "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_walk_kernel"}
 
 
-TRAFFIC_TABLES = ["r02_kernel_bench_stats_and_traffic.csv", "r01_kernel_bench_v4_stats_and_traffic.csv"]   # newest first
+TRAFFIC_TABLES = ["r02_bench_step_stats_and_traffic.csv", "r02_kernel_bench_stats_and_traffic.csv",
+                  "r01_kernel_bench_v4_stats_and_traffic.csv"]   # first match wins
 
 
 def pmc_traffic(name):
     """(HBM bytes per launch of `name`, source) from the committed PMC passes (profiles/: separate rocprofv3
-    --pmc FETCH_SIZE and --pmc WRITE_SIZE runs of tools/kernel_bench.py at this same problem size;
-    FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for wide coalesced reads).  (None, None) if no
+    --pmc FETCH_SIZE and --pmc WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
+    wide coalesced reads).  The first table is from THIS command (bench.py, mean over the launches of a
+    step); the older ones are tools/kernel_bench.py at the same problem size.  A launcher whose work is split
+    over several device-function instances is the call-weighted mean of their rows.  (None, None) if no
     committed profile has the kernel — bench.py itself does not collect counters."""
     import csv
-    key = DEVICE_KERNEL.get(name)
-    if not key:
+    keys = DEVICE_KERNEL.get(name)
+    if not keys:
         return None, None
+    if isinstance(keys, str):
+        keys = (keys,)
     for fname in TRAFFIC_TABLES:
         path = ROOT / "profiles" / fname
         if not path.exists():
             continue
         with open(path) as f:
             rows = list(csv.DictReader(l for l in f if not l.startswith("#")))
-        for r in rows:
-            if key in r["kernel"] and r["FETCH_SIZE_KB"] and r["WRITE_SIZE_KB"]:
-                return (int((2.0 * float(r["FETCH_SIZE_KB"]) + float(r["WRITE_SIZE_KB"])) * 1024),
-                        f"profiles/{fname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes of tools/kernel_bench.py; largest launch shape of this kernel)")
+        hit = [r for r in rows if any(k in r["kernel"] for k in keys) and r["FETCH_SIZE_KB"] and r["WRITE_SIZE_KB"]]
+        if hit:
+            calls = sum(float(r["calls"]) for r in hit)
+            kb = sum(float(r["calls"]) * (2.0 * float(r["FETCH_SIZE_KB"]) + float(r["WRITE_SIZE_KB"])) for r in hit) / calls
+            what = ("this command under rocprofv3, mean over a step's launches" if "bench_step" in fname
+                    else "tools/kernel_bench.py, median per dispatch of its shapes")
+            return int(kb * 1024), f"profiles/{fname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes; {what})"
     return None, None
 
 

@@ -186,7 +186,7 @@ def main():
     only = [s for s in a.only.split(",") if s]
     rows = []
     for name, (fn, bound, work) in cases.items():
-        if only and not any(o in name for o in only):
+        if only and not any(o in name or o.replace("_", " ") in name for o in only):
             continue
         med, best = timeit(fn, a.iters)
         if bound == "hbm":

@@ -29,7 +29,7 @@ def short(name, n=160):
     return name.replace("void ", "", 1)[:n]
 
 
-def kernel_table(trace_dir, fetch_dir, write_dir, out, header):
+def kernel_table(trace_dir, fetch_dir, write_dir, out, header, stat="median"):
     dur = collections.defaultdict(list)
     for r in rows_of(trace_dir, "kernel_trace"):
         dur[r["Kernel_Name"]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
@@ -39,10 +39,10 @@ def kernel_table(trace_dir, fetch_dir, write_dir, out, header):
         for r in rows_of(d, "counter_collection"):
             if r["Counter_Name"] == tag:
                 acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
-        pmc[tag] = {k: statistics.median(v) for k, v in acc.items()}
+        pmc[tag] = {k: (statistics.median(v) if stat == "median" else sum(v) / len(v)) for k, v in acc.items()}
     with open(out, "w") as f:
         f.write(f"# {header}\n")
-        f.write("# traffic: separate passes rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (KB per dispatch, median); hbm_read_MB applies "
+        f.write("# traffic: separate passes rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (KB per dispatch, " + stat + "); hbm_read_MB applies "
                 "the gfx950 x2 correction for wide coalesced reads (MI355X_MICROARCH.md §HBM)\n")
         w = csv.writer(f)
         w.writerow(["kernel", "calls", "avg_us", "FETCH_SIZE_KB", "WRITE_SIZE_KB", "hbm_read_MB_corrected", "hbm_write_MB"])
@@ -98,7 +98,7 @@ if __name__ == "__main__":
     if sys.argv[1] == "check-log":
         check_log(sys.argv[2:])
     elif sys.argv[1] == "kernel-table":
-        kernel_table(*sys.argv[2:7])
+        kernel_table(*sys.argv[2:8])
     elif sys.argv[1] == "step":
         step(*sys.argv[2:6])
     else:

@@ -371,6 +371,118 @@ void dwconv3x3_upcat_lds_kernel(const float* __restrict__ a, int h, int w, int C
     }
 }
 
+// Bilinear upsampling of [planes, h, w] float32 maps to [planes, H, W] with torch's upsample_bilinear2d arithmetic (source index,
+// weights and the order h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)), either corner convention.  DeepLabV3+'s
+// segmentation head ends in UpsamplingBilinear2d(x4) on the 19 logit planes (1.27 GB written per batch of 8 at 1024x2048):
+// 4 output pixels per lane, one 16-byte store, the <= 2 x 4 source values from L2 (the low-resolution maps are 64x smaller).
+__global__ __launch_bounds__(kThreads)
+void upsample_bilinear_kernel(const float* __restrict__ low, int h, int w, int H, int W, float sy, float sx, int align,
+                              float* __restrict__ out, int64_t planes)
+{
+    const int wq = (W + 3) / 4;
+    const int64_t total = planes * H * wq;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int xq = (int)(i % wq);
+        int64_t t = i / wq;
+        const int y = (int)(t % H);
+        const int64_t pl = t / H;
+        float fy = align ? sy * (float)y : sy * ((float)y + 0.5f) - 0.5f;
+        fy = fy < 0.f ? 0.f : fy;
+        const int y0 = (int)fy, y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+        const float* r0 = low + (pl * h + y0) * (int64_t)w;
+        const float* r1 = low + (pl * h + y1) * (int64_t)w;
+        float v[4];
+        if (sx * 3.0f < 1.0f) {
+            // upsampling by more than 3: the four pixels' source columns lie in [a, a + 2] — six loads instead of sixteen
+            // (the sixteen-load form is bound by the vector-memory pipe: 0.51 ms for 1.27 GB, torch's kernel the same)
+            int xa = xq * 4; xa = xa < W ? xa : W - 1;
+            float fa = align ? sx * (float)xa : sx * ((float)xa + 0.5f) - 0.5f;
+            fa = fa < 0.f ? 0.f : fa;
+            const int a = (int)fa;
+            const int c1 = a + 1 < w ? a + 1 : w - 1, c2 = a + 2 < w ? a + 2 : w - 1;
+            const float t0 = r0[a], t1 = r0[c1], t2 = r0[c2], b0 = r1[a], b1 = r1[c1], b2 = r1[c2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int x = xq * 4 + k; x = x < W ? x : W - 1;
+                float fx = align ? sx * (float)x : sx * ((float)x + 0.5f) - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const int x0 = (int)fx;
+                const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+                const bool first = x0 == a;                        // else x0 == a + 1; x1 = x0 + 1 clamped = the next staged column
+                const float v00 = first ? t0 : t1, v01 = first ? t1 : t2, v10 = first ? b0 : b1, v11 = first ? b1 : b2;
+                v[k] = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                int x = xq * 4 + k; x = x < W ? x : W - 1;
+                float fx = align ? sx * (float)x : sx * ((float)x + 0.5f) - 0.5f;
+                fx = fx < 0.f ? 0.f : fx;
+                const int x0 = (int)fx, x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const float lx1 = fx - (float)x0, lx0 = 1.0f - lx1;
+                v[k] = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+            }
+        }
+        float* o = out + (pl * H + y) * (int64_t)W + xq * 4;
+        if ((W & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int k = 0; k < 4 && xq * 4 + k < W; ++k) o[k] = v[k];
+    }
+}
+
+// Upsampling by more than 3 in both directions (W % 4 == 0): a lane owns a 4 x 4 block of output pixels, whose source values lie
+// in 3 x 3 cells — nine loads and four 16-byte stores per lane (the row-at-a-time kernel above runs one dependent
+// load -> blend -> store chain per 16 bytes and is latency-bound at 2.9 TB/s).  Same expressions: same values.
+__global__ __launch_bounds__(kThreads)
+void upsample_bilinear_4x4_kernel(const float* __restrict__ low, int h, int w, int H, int W, float sy, float sx, int align,
+                                  float* __restrict__ out, int64_t planes)
+{
+    const int wq = W / 4, hq = (H + 3) / 4;
+    const int64_t total = planes * hq * wq;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int xq = (int)(i % wq);
+        int64_t t = i / wq;
+        const int yq = (int)(t % hq);
+        const int64_t pl = t / hq;
+        auto src = [&](int d, float sc) { float f = align ? sc * (float)d : sc * ((float)d + 0.5f) - 0.5f; return f < 0.f ? 0.f : f; };
+        const int ya = (int)src(yq * 4, sy), xa = (int)src(xq * 4, sx);
+        float c[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yy = ya + r < h ? ya + r : h - 1;
+            const float* row = low + (pl * h + yy) * (int64_t)w;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) c[r][q] = row[xa + q < w ? xa + q : w - 1];
+        }
+        float lx0[4], lx1[4]; bool fx_first[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float fx = src(xq * 4 + k, sx);
+            const int x0 = (int)fx;
+            lx1[k] = fx - (float)x0; lx0[k] = 1.0f - lx1[k]; fx_first[k] = x0 == xa;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int y = yq * 4 + j;
+            if (y >= H) break;
+            const float fy = src(y, sy);
+            const int y0 = (int)fy;
+            const float ly1 = fy - (float)y0, ly0 = 1.0f - ly1;
+            const bool fy_first = y0 == ya;
+            float v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float t00 = fy_first ? (fx_first[k] ? c[0][0] : c[0][1]) : (fx_first[k] ? c[1][0] : c[1][1]);
+                const float t01 = fy_first ? (fx_first[k] ? c[0][1] : c[0][2]) : (fx_first[k] ? c[1][1] : c[1][2]);
+                const float t10 = fy_first ? (fx_first[k] ? c[1][0] : c[1][1]) : (fx_first[k] ? c[2][0] : c[2][1]);
+                const float t11 = fy_first ? (fx_first[k] ? c[1][1] : c[1][2]) : (fx_first[k] ? c[2][1] : c[2][2]);
+                v[k] = ly0 * (lx0[k] * t00 + lx1[k] * t01) + ly1 * (lx0[k] * t10 + lx1[k] * t11);
+            }
+            *reinterpret_cast<float4*>(out + (pl * H + y) * (int64_t)W + xq * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
 // Depth tail of EnsembleModel.forward (PKG/models/model.py:368-371 + :471-478): the DeepLab depth map is predicted at
 // stride 16, upsampled bilinearly (align_corners=False) to the input size and combined with the SegFormer map as
 // w0*d1 + w1*d2 (or their mean).  One pass: reads d1 and the 64x-smaller low-resolution map, writes both outputs.
@@ -637,6 +749,29 @@ AWSEG_API int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_wid
     const int64_t items = batch * height * ((width + SX - 1) / SX) * ((a_channels + hi_channels) / 4 - c4_lo);
     hipLaunchKernelGGL((dwconv3x3_upcat_strip_kernel<SX>), dim3(awseg_grid_1d(items, kThreads)), dim3(kThreads), 0, awseg_s(stream),
                        a, a_height, a_width, a_channels, hi, hi_channels, batch, height, width, ry, rx, w9, out, c4_lo);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_upsample_bilinear(const float* low, int64_t planes, int low_height, int low_width, int height, int width,
+                                      int align_corners, float* out, awseg_stream_t stream)
+{
+    if (planes == 0) return 0;
+    if (!low || !out || planes < 0 || low_height < 1 || low_width < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if ((width & 3) == 0 && ((uintptr_t)out & 15)) return AWSEG_EALIGN;
+    // torch area_pixel_compute_scale: align_corners ? (out > 1 ? (in - 1) / (out - 1) : 0) : in / out, in float
+    const float sy = align_corners ? (height > 1 ? (float)(low_height - 1) / (float)(height - 1) : 0.f) : (float)low_height / (float)height;
+    const float sx = align_corners ? (width > 1 ? (float)(low_width - 1) / (float)(width - 1) : 0.f) : (float)low_width / (float)width;
+    if ((width & 3) == 0 && sx * 3.0f < 1.0f && sy * 3.0f < 1.0f) {
+        const int64_t blocks4 = planes * ((height + 3) / 4) * (width / 4);
+        hipLaunchKernelGGL(upsample_bilinear_4x4_kernel, dim3(awseg_grid_1d(blocks4, kThreads)), dim3(kThreads), 0, awseg_s(stream), low,
+                           low_height, low_width, height, width, sy, sx, align_corners ? 1 : 0, out, planes);
+        AWSEG_LAUNCH_CHECK();
+        return 0;
+    }
+    const int64_t total = planes * height * ((width + 3) / 4);
+    hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), low,
+                       low_height, low_width, height, width, sy, sx, align_corners ? 1 : 0, out, planes);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -881,6 +881,13 @@ void aspp_dw3_sliced_kernel(const float* __restrict__ x, int64_t batch, int h, i
     }
 }
 
+// 16-byte store with the non-temporal hint: the three output planes (1.5 GB per launch) stream through the same L2 the
+// taps re-read their 2 MB unit from; without the hint they evict it (PMC: the 0.54 GB input came from HBM 2.6 times).
+__device__ __forceinline__ void st_stream(float* p, float4 v)
+{
+    typedef float vf4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(vf4{ v.x, v.y, v.z, v.w }, reinterpret_cast<vf4*>(p));
+}
 // Same units and XCD order; a lane owns (rate, row class j mod d, column, channel quad) and walks the rows j, j+d, j+2d, ...
 // of its class.  An input row s feeds the outputs s-d, s, s+d of the SAME class (tap rows 2, 1, 0), so the lane loads
 // each input row once — 3 loads (the three tap columns) per output instead of 9 — and carries two partial outputs:
@@ -941,11 +948,10 @@ void aspp_dw3_walk_kernel(const float* __restrict__ x, int64_t batch, int h, int
             if (s >= h) break;
             const float4 h0 = hsum(0, v[g]), h1 = hsum(1, v[g]), h2 = hsum(2, v[g]);
             if (s != j)
-                *reinterpret_cast<float4*>(ob + ((int64_t)(s - d) * w + xx) * C) =
-                    make_float4(accA.x + h2.x, accA.y + h2.y, accA.z + h2.z, accA.w + h2.w);
+                st_stream(ob + ((int64_t)(s - d) * w + xx) * C, make_float4(accA.x + h2.x, accA.y + h2.y, accA.z + h2.z, accA.w + h2.w));
             accA = make_float4(accB.x + h1.x, accB.y + h1.y, accB.z + h1.z, accB.w + h1.w);
             accB = h0;
-            if (s + d >= h) *reinterpret_cast<float4*>(ob + ((int64_t)s * w + xx) * C) = accA;
+            if (s + d >= h) st_stream(ob + ((int64_t)s * w + xx) * C, accA);
         }
     }
 }

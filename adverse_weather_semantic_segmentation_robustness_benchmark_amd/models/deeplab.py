@@ -299,5 +299,10 @@ class DeepLabV3Plus(nn.Module):
             low = y2.view(Bq, H4, W4, -1).permute(0, 3, 1, 2).contiguous()  # [B,C,H/4,W/4] NCHW (small)
         else:
             low = head(dec).contiguous()
-        out = self.segmentation_head[1](low)                                # x4 bilinear, align_corners=True -> NCHW
+        up = self.segmentation_head[1]
+        if isinstance(up, nn.UpsamplingBilinear2d) and low.is_cuda and low.dtype == torch.float32:
+            f = int(up.scale_factor)
+            out = ops.upsample_bilinear(low, (low.shape[2] * f, low.shape[3] * f), True)   # x4 bilinear, align_corners=True (HIP)
+        else:
+            out = up(low)
         return (out, feats[-1]) if return_features else out

@@ -767,6 +767,17 @@ def restore_split(state: dict) -> None:
     HEAD_SPLIT = bool(state.get("segformer_head", HEAD_SPLIT))
 
 
+def upsample_bilinear(x: torch.Tensor, size, align_corners: bool) -> torch.Tensor:
+    """F.interpolate(x, size, mode="bilinear", align_corners=...) / nn.UpsamplingBilinear2d on an NCHW float32 tensor, torch's
+    arithmetic (bit-identical), 4 output pixels per lane."""
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    H, W = int(size[0]), int(size[1])
+    out = torch.empty(b, c, H, W, dtype=torch.float32, device=x.device)
+    N.call("awseg_upsample_bilinear", N.ptr(x), b * c, h, w, H, W, int(bool(align_corners)), N.ptr(out), N.stream())
+    return out
+
+
 def depth_upsample_combine(d1: torch.Tensor, d2_low: torch.Tensor, weights: Optional[torch.Tensor]):
     """(d2_full, d) with d2_full = bilinear(align_corners=False) upsample of d2_low [B,1,h,w] to d1's size [B,1,H,W] and
     d = weights[0]*d1 + weights[1]*d2_full (mean when weights is None) — PKG/models/model.py:368-371, 471-478."""

@@ -566,6 +566,13 @@ int awseg_attention_d32(const float* q, const float* k, const float* v, float* o
 int awseg_attention_d32_split(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                               int n_queries, int n_keys, float scale, awseg_stream_t stream);
 
+/* Bilinear upsampling of [planes, low_height, low_width] float32 maps to [planes, height, width] with torch's
+ * upsample_bilinear2d arithmetic (source index, weights, order of the four products), align_corners 0 or 1.  Replaces
+ * the nn.UpsamplingBilinear2d(scale_factor=4) at the end of DeepLabV3+'s segmentation head (the smp model the reference
+ * builds at PKG/models/model.py:262-268) and F.interpolate(..., mode="bilinear") calls on logit / depth planes. */
+int awseg_upsample_bilinear(const float* low, int64_t planes, int low_height, int low_width,
+                            int height, int width, int align_corners, float* out, awseg_stream_t stream);
+
 /* awseg_depth_upsample_combine: the depth tail of the ensemble in one pass — d2_full = bilinear upsample
  * (align_corners=False) of the stride-16 DeepLab depth map d2_low [B,h,w] to [B,H,W] (PKG/models/model.py:368-371) and
  * d_out = weights[0]*d1 + weights[1]*d2_full, or (d1 + d2_full)/2 when weights is NULL (model.py:471-478).

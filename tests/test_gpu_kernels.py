@@ -865,6 +865,19 @@ def test_gemm_tune_keeps_results(ops, native):
     assert (ops.gemm_bias_act(x, w, b, 1).double() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("cfg", [(2, 19, 16, 32, 64, 128, True), (1, 3, 7, 5, 28, 20, True), (2, 1, 4, 8, 64, 128, False),
+                                 (1, 2, 5, 9, 33, 70, False), (1, 19, 256, 512, 1024, 2048, True)])
+def test_upsample_bilinear_matches_torch(ops, cfg):
+    """awseg_upsample_bilinear against F.interpolate (both corner conventions, non-multiple-of-4 widths, the full DeepLab size)."""
+    B, C, h, w, H, W, align = cfg
+    g = torch.Generator(device="cuda").manual_seed(h * w)
+    x = torch.randn(B, C, h, w, device="cuda", generator=g)
+    ref = torch.nn.functional.interpolate(x, size=(H, W), mode="bilinear", align_corners=align)
+    got = ops.upsample_bilinear(x, (H, W), align)
+    err = (got - ref).abs().max().item()
+    assert err < 1e-6 * max(1.0, ref.abs().max().item()), err      # same expression; torch's build may contract a*b+c into FMAs
+
+
 @pytest.mark.parametrize("shape", [(2, 5, 7, 8, 4), (1, 16, 32, 256, 48), (1, 3, 3, 4, 4), (2, 9, 13, 256, 8), (1, 4, 21, 512, 48)])
 def test_dwconv3x3_upcat_matches_torch(ops, shape):
     """Decoder fusion: depthwise3x3(cat(UpsamplingBilinear2d(x4)(a), hi)) against the torch ops it replaces (1e-5)."""

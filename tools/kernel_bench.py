@@ -125,6 +125,8 @@ def main():
     hist = torch.zeros(2, 8192, dtype=torch.int64, device=dev)
     cases["ensemble eval stats (ECE + disagreement hist)"] = (
         lambda: ops.ensemble_eval_stats(s1, s2, 0, wts, T, labels, cond, edges, bins, hist, 0.0, 3.0), "hbm", (2 * C * 4 + 1) * px * B)
+    lowl = torch.randn(B, C, H // 4, W // 4, device=dev)
+    cases["upsample_bilinear x4 19 planes (deeplab logits)"] = (lambda: ops.upsample_bilinear(lowl, (H, W), True), "hbm", C * 4 * px * B * (1 + 1 / 16))
     xl = torch.randn(B * (H // 4) * (W // 4), 32, device=dev); lw = torch.randn(32, device=dev); lb = torch.randn(32, device=dev)
     cases["layernorm_rows C=32 @1/4"] = (lambda: ops.layernorm_rows(xl, lw, lb, 1e-6), "hbm", 2 * 32 * 4 * xl.shape[0])
 

@@ -10,7 +10,7 @@ int main()
 {
     const int64_t M = 65536; const int N = 512, K = 2048;
     float *x, *w, *o; uint16_t* ws;
-    hipMalloc(&x, M * K * 4); hipMalloc(&w, (size_t)N * K * 4); hipMalloc(&o, M * N * 4); hipMalloc(&ws, (size_t)2 * N * K * 2);
+    hipMalloc(&x, M * K * 4); hipMalloc(&w, (size_t)N * K * 4); hipMalloc(&o, M * N * 4); hipMalloc(&ws, (size_t)2 * N * K * 2 + 16);   // [2][N][K] halves + the 16-byte trailer {max|w| bits, exponent}
     std::vector<float> hx(M * K), hw((size_t)N * K);
     for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = ((float)((i * 40503u) % 2001) / 1000.f - 1.f) * 0.05f;

@@ -53,6 +53,17 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 
+// Unscaled form: hi = f16(x) (round toward zero), lo = f16(x - hi) — three instructions per pair (v_cvt_pkrtz + two v_fma_mix).
+// The low part keeps its 11 bits while |lo| >= 2^-14, i.e. |x| >= 2^-3; the single-accumulator kernel stages x * 2^4, which
+// moves that bound to 2^-7 (below it the absolute error is 2^-29 of a unit: far inside float32 grade for O(1) tensors).
+__device__ __forceinline__ void split_pair_unscaled(float a, float b, unsigned& hi, unsigned& lo)
+{
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
+        : "=&v"(lo) : "v"(a), "v"(b), "v"(hi));
+}
+
 // power-of-two scale that brings a maximum magnitude with float bits `maxbits` into [2^13, 2^14): returns e with
 // scaled = v * 2^-e.  Zero / subnormal maxima (and Inf / NaN) leave the tensor unscaled.
 __device__ __forceinline__ int norm_exponent(unsigned maxbits)
@@ -128,10 +139,17 @@ __device__ __forceinline__ unsigned pack_bf16(float a, float b)
 // path): activations are rounded to bf16 when they are staged, weights come as one bf16 plane (awseg_gemm_bf16_weights
 // writes it where the split form keeps its high parts), float32 accumulation and epilogue.  bf16 has float32's exponent
 // range: no range guard, no second pass.
-template <int MT, int NT, int WM, int WN, bool KTAIL, bool BF16>
+// ONE = true: ONE accumulator per product tile.  The weights' low plane is brought back to its unscaled value when it is staged
+// (x 2^-11, exact: v_pk_mul_f16), the activations are split into unscaled parts, and the three products of a tile add into the
+// same registers — half the accumulator registers, which is what lets a wave own 128 x 64 (MT 4, NT 2: 12 KB of LDS fragment
+// reads per 24 MFMAs instead of 8 KB per 12) in a 256 x 256 block tile.
+template <int MT, int NT, int WM, int WN, bool KTAIL, bool BF16, bool ONE = false>
 __global__ __launch_bounds__(GT, (MT * NT <= 2 ? 4 : 2))
 void gemm_split_kernel(gemm_args a)
 {
+    static_assert(!(ONE && BF16), "single-accumulator form is for split operands");
+    constexpr float kSx0 = ONE ? 16.0f : 1.0f;                   // optimistic-pass activation scale (ONE: see split_pair_unscaled)
+    constexpr int kXe0 = ONE ? -4 : 0;
     static_assert(WM * WN == 8, "eight waves");
     constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN;
     constexpr int NA = BM / 64;                                  // float4 of x per thread per K tile
@@ -178,8 +196,8 @@ void gemm_split_kernel(gemm_args a)
     float4 areg[NA]; u32x4 breg[NB];
     float amax = 0.f;                                            // max|x| this thread staged in the current pass
     bool scaled = false;                                         // second pass over a tile whose activations left the split range
-    float sx = 1.0f;                                             // activation scale of that pass (2^-e)
-    int xe = 0;
+    float sx = kSx0;                                             // activation scale of the pass (2^-e)
+    int xe = kXe0;
     auto fetch = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -204,17 +222,28 @@ void gemm_split_kernel(gemm_args a)
                 *reinterpret_cast<u32x2*>(d) = H;
                 continue;
             }
-            if (scaled) { v.x *= sx; v.y *= sx; v.z *= sx; v.w *= sx; }       // block-uniform branch
+            if (ONE || scaled) { v.x *= sx; v.y *= sx; v.z *= sx; v.w *= sx; }       // block-uniform branch
             amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));   // v_max3_f32 with |.| modifiers
             amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.z)), __builtin_fabsf(v.w));
-            split_pair(v.x, v.y, hh, ll); H[0] = hh; L[0] = ll;
-            split_pair(v.z, v.w, hh, ll); H[1] = hh; L[1] = ll;
+            if (ONE) {
+                split_pair_unscaled(v.x, v.y, hh, ll); H[0] = hh; L[0] = ll;
+                split_pair_unscaled(v.z, v.w, hh, ll); H[1] = hh; L[1] = ll;
+            } else {
+                split_pair(v.x, v.y, hh, ll); H[0] = hh; L[0] = ll;
+                split_pair(v.z, v.w, hh, ll); H[1] = hh; L[1] = ll;
+            }
             *reinterpret_cast<u32x2*>(d) = H;
             *reinterpret_cast<u32x2*>(d + 32) = L;
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (BF16 && (i & 1)) continue;
+            if (ONE && (i & 1)) {                                // low plane: stored as (w - hi) * 2^11 -> back to w - hi
+                // one vector multiply (element-wise writes through breg[i][q] in a loop were compiled into a chain reading the
+                // element just written: hipcc / clang-22, checked in the ISA)
+                const h8 lo8 = __builtin_bit_cast(h8, breg[i]) * (_Float16)0.00048828125f;
+                breg[i] = __builtin_bit_cast(u32x4, lo8);
+            }
             *reinterpret_cast<u32x4*>(&sB[buf][bdst0 + (i >> 1) * 128 * GROW + 32 * (i & 1)]) = breg[i];
         }
     };
@@ -312,6 +341,11 @@ void gemm_split_kernel(gemm_args a)
                             continue;
                         }
                         am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bh[j], am[i][j], 0, 0, 0);
+                        if (ONE) {
+                            am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bl[j], am[i][j], 0, 0, 0);
+                            am[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i], Bh[j], am[i][j], 0, 0, 0);
+                            continue;
+                        }
                         ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[i], Bl[j], ac2[i][j], 0, 0, 0);
                         ac2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[i], Bh[j], ac2[i][j], 0, 0, 0);
                     }
@@ -339,7 +373,7 @@ void gemm_split_kernel(gemm_args a)
             if (mx != 0u && !scaled) {
                 const int ex = (int)(mx >> 23) & 0xff;
                 if (ex != 0xff) {                                // Inf / NaN: nothing to rescue, let them propagate
-                    xe = ex - 127 - 13;                          // max|x| * 2^-xe in [2^13, 2^14)
+                    xe = ex - 127 - 13 + kXe0;                   // max|x| * 2^-xe in [2^13, 2^14) (the maximum was taken after the x 2^-kXe0 staging scale)
                     sx = pow2f(-xe);                             // xe in [2, 114]: one factor is enough
                     scaled = true;
                     point(m0, n0);                               // the registers hold the NEXT tile's first K tile: fetch this one again
@@ -350,7 +384,7 @@ void gemm_split_kernel(gemm_args a)
         }
         // result scale: 2^(we + xe), applied as two factors (each a normal float; their product may legitimately overflow
         // to Inf exactly where the float32 GEMM would)
-        const int oe = we + (scaled ? xe : 0);
+        const int oe = we + xe;                                  // xe = kXe0 on the optimistic pass
         const int oe1 = oe / 2, oe2 = oe - oe1;
         const float os1 = pow2f(oe1 < -126 ? -126 : (oe1 > 127 ? 127 : oe1)), os2 = pow2f(oe2 < -126 ? -126 : (oe2 > 127 ? 127 : oe2));
         const bool rescale = oe != 0;
@@ -394,7 +428,7 @@ void gemm_split_kernel(gemm_args a)
 #pragma unroll
                         for (int r8 = 0; r8 < 8; ++r8) {
                             const int r = 8 * half + r8;
-                            float vv = fmaf(ac2[i][j][r], kLoInv, am[i][j][r]);
+                            float vv = ONE ? am[i][j][r] : fmaf(ac2[i][j][r], kLoInv, am[i][j][r]);
                             if (rescale) vv = vv * os1 * os2;                                  // block-uniform branch
                             vv = vv + bv + rv[r8];
                             if (a.act == 1) vv = fmaxf(vv, 0.f);
@@ -406,7 +440,7 @@ void gemm_split_kernel(gemm_args a)
         }
         if (!has_next) break;
         slot = nslot; m0 = nm0; n0 = nn0;
-        scaled = false;
+        scaled = false; sx = kSx0; xe = kXe0;
     }
 }
 
@@ -448,18 +482,23 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
         cus = n_cu;
     }
-    static int tile_mode = -1;                                   // AWSEG_GEMM_SPLIT_TILE = 128 / 256 forces the block-tile width (measurements)
-    if (tile_mode < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_TILE"); tile_mode = !e ? 0 : (atoi(e) == 256 ? 2 : (atoi(e) == 128 ? 1 : 0)); }
-    // the 128 x 256 tile when N fills it and there are enough tiles for every CU
-    const bool wide = tile_mode == 2 || (tile_mode == 0 && n % 256 == 0 && ((m + 127) / 128) * (int64_t)(n / 256) >= cus);
-    const int bn = wide ? 256 : 128;
-    const int64_t ntm = (m + 127) / 128;
+    static int tile_mode = -1;                                   // AWSEG_GEMM_SPLIT_TILE = 128 / 256 / 512 forces the block tile (measurements; 512 = 256 x 256)
+    if (tile_mode < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_TILE"); tile_mode = !e ? 0 : (atoi(e) == 512 ? 3 : (atoi(e) == 256 ? 2 : (atoi(e) == 128 ? 1 : 0))); }
+    // 256 x 256 (single accumulator) when N fills it and there is at least one tile per CU (AWSEG_GEMM_SPLIT_HUGE_MIN_TILES per CU); else the 128 x 256 tile when N
+    // fills it and there are enough tiles for every CU; else 128 x 128
+    static int huge_min = -1;
+    if (huge_min < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_HUGE_MIN_TILES"); huge_min = e ? atoi(e) : 1; }
+    const bool huge = !bf16 && (tile_mode == 3 || (tile_mode == 0 && n % 256 == 0 && ((m + 255) / 256) * (int64_t)(n / 256) >= (int64_t)huge_min * cus));
+    const bool wide = !huge && (tile_mode == 2 || (tile_mode == 0 && n % 256 == 0 && ((m + 127) / 128) * (int64_t)(n / 256) >= cus));
+    const int bn = (wide || huge) ? 256 : 128;
+    const int bm = huge ? 256 : 128;
+    const int64_t ntm = (m + bm - 1) / bm;
     a.ntn = (n + bn - 1) / bn;
     const int64_t ntm8 = (ntm + 7) / 8 * 8;                      // 8 m-tiles (one per XCD) x all n-tiles per group
-    if (ntm8 * a.ntn > 0x7fffffff || (int64_t)128 * n > 0x7fffffff) return AWSEG_ERANGE;
+    if (ntm8 * a.ntn > 0x7fffffff || (int64_t)bm * n > 0x7fffffff) return AWSEG_ERANGE;
     a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
     const int64_t slots = ntm8 * a.ntn;
-    int64_t blocks = (int64_t)cus * (wide ? 1 : 2) / 8 * 8;      // persistent: one (128 x 256) or two (128 x 128) blocks per CU
+    int64_t blocks = (int64_t)cus * ((wide || huge) ? 1 : 2) / 8 * 8;      // persistent: one (128 x 256 / 256 x 256) or two (128 x 128) blocks per CU
     if (blocks < 8) blocks = 8;
     if (blocks > slots) blocks = slots;                          // slots is a multiple of 8
     const dim3 grid((unsigned)blocks), block(GT);
@@ -473,7 +512,11 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
             else hipLaunchKernelGGL((gemm_split_kernel<MT_, NT_, WM_, WN_, false, false>), grid, block, 0, awseg_s(stream), a);        \
         }                                                                                                             \
     } while (0)
-    if (wide) GEMM_GO(2, 2, 2, 4); else GEMM_GO(1, 2, 4, 2);
+    if (huge) {
+        if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<4, 2, 2, 4, true, false, true>), grid, block, 0, awseg_s(stream), a);
+        else hipLaunchKernelGGL((gemm_split_kernel<4, 2, 2, 4, false, false, true>), grid, block, 0, awseg_s(stream), a);
+    }
+    else if (wide) GEMM_GO(2, 2, 2, 4); else GEMM_GO(1, 2, 4, 2);
 #undef GEMM_GO
     AWSEG_LAUNCH_CHECK();
     return 0;

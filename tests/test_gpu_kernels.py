@@ -964,12 +964,14 @@ def test_attention_d32_split_flat_softmax(ops):
     assert (got.double() - ref).abs().max().item() < 2e-5
 
 
-@pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72), (200, 160, 264), (1100, 384, 1024), (38400, 256, 128), (38500, 512, 104)])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72), (200, 160, 264), (1100, 384, 1024), (38400, 256, 128), (38500, 512, 104),
+                                   (131100, 256, 128), (65600, 512, 104)])
 @pytest.mark.parametrize("res_act", [(False, 0), (True, 1)])
 def test_gemm_split_float32_grade(ops, shape, res_act):
     """Split-operand f16-MFMA GEMM against float64, next to the hipBLASLt float32 GEMM on the same inputs: ragged M and
     N, K not a multiple of the 32-wide K tile, bias / residual / ReLU epilogue, residual aliasing the output; the last
-    two shapes have enough tiles for the 128 x 256 block-tile configuration (N % 256 == 0, >= one tile per CU)."""
+    two shapes before the end have enough tiles for the 128 x 256 block-tile configuration (N % 256 == 0, >= one tile per CU),
+    the last two for the 256 x 256 single-accumulator one (>= two tiles per CU; ragged M, K tail)."""
     M, Nn, K = shape
     has_res, act = res_act
     g = torch.Generator(device="cuda").manual_seed(M + Nn + K)
@@ -995,7 +997,7 @@ def test_gemm_split_float32_grade(ops, shape, res_act):
     assert e_split < 4 * e_lib + 1e-6
 
 
-@pytest.mark.parametrize("shape", [(300, 256, 128), (38400, 256, 128), (4100, 320, 72)])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (38400, 256, 128), (4100, 320, 72), (131100, 256, 128)])
 @pytest.mark.parametrize("xscale,wscale", [(1e5, 0.05), (3e4, 1e-9), (1e30, 1e-28), (2.0, 1e6), (1e-30, 1e4)])
 def test_gemm_split_large_operands(ops, shape, xscale, wscale):
     """operands outside the f16 range must not give silently wrong products.  Activations at 1e5 / 1e30

@@ -488,7 +488,7 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     // fills it and there are enough tiles for every CU; else 128 x 128
     static int huge_min = -1;
     if (huge_min < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_HUGE_MIN_TILES"); huge_min = e ? atoi(e) : 1; }
-    const bool huge = !bf16 && (tile_mode == 3 || (tile_mode == 0 && n % 256 == 0 && ((m + 255) / 256) * (int64_t)(n / 256) >= (int64_t)huge_min * cus));
+    const bool huge = !bf16 && (tile_mode == 3 || (tile_mode == 0 && n % 256 == 0 && k >= 128 && ((m + 255) / 256) * (int64_t)(n / 256) >= (int64_t)huge_min * cus));   // K = 64: two K tiles per 256 x 256 epilogue, measured 6 % slower
     const bool wide = !huge && (tile_mode == 2 || (tile_mode == 0 && n % 256 == 0 && ((m + 127) / 128) * (int64_t)(n / 256) >= cus));
     const int bn = (wide || huge) ? 256 : 128;
     const int bm = huge ? 256 : 128;

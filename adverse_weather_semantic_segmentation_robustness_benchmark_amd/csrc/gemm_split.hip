@@ -115,6 +115,10 @@ struct gemm_args {
     const float* x; const _Float16* wh; const _Float16* wl; const float* bias; const float* residual; float* out;
     const unsigned* trailer;                                     // {max|w| bits, weight exponent ew} (awseg_gemm_split_weights)
     int64_t M; int N, K, act, ntm, ntm8, ntn;
+    // conv = 1: x is an NHWC image batch [B, cH, cW, cC] and row m = (b, oy, ox) of the A operand is gathered from it —
+    // column k = (ky * ckw + kx) * cC + c is x[b, oy * cs - cp + ky * cd, ox * cs - cp + kx * cd, c], zero outside (the im2col
+    // matrix of awseg_im2col_nhwc, never materialised).  cC % 32 == 0: a 32-wide K tile lies inside one tap.
+    int conv, cH, cW, cC, cHo, cWo, ckw, cs, cp, cd;
 };
 
 constexpr float kSplitLimit = 32768.0f;                          // |x| below this splits without loss (hi < 65504, lo * 2048 < 65504)
@@ -178,6 +182,7 @@ void gemm_split_kernel(gemm_args a)
     // operand addresses of the tile being fetched: block-uniform bases (scalar registers) + 32-bit lane offsets
     const float* xb = nullptr; const _Float16* whb = nullptr; const _Float16* wlb = nullptr;
     int aoff[NA], boff[NB / 2];
+    int cby[NA], cy0[NA], cx0[NA];                               // conv: image row base b * cH, first tap's input row / column of the A rows
     auto point = [&](int64_t m0, int n0) {
         xb = a.x + m0 * K; whb = a.wh + (int64_t)n0 * K; wlb = a.wl + (int64_t)n0 * K;
         const int64_t mleft = a.M - m0;                          // clamped rows are computed and never stored
@@ -186,6 +191,13 @@ void gemm_split_kernel(gemm_args a)
         for (int i = 0; i < NA; ++i) {
             const int row = ar + 64 * i;
             aoff[i] = (int)(row < mleft ? row : mleft - 1) * K + 4 * ac;
+            if (a.conv) {                                        // block-uniform
+                const int64_t m = m0 + (row < mleft ? row : mleft - 1);
+                const int b = (int)(m / ((int64_t)a.cHo * a.cWo));
+                const int rem = (int)(m - (int64_t)b * a.cHo * a.cWo);
+                const int oy = rem / a.cWo, ox = rem - oy * a.cWo;
+                cby[i] = b * a.cH; cy0[i] = oy * a.cs - a.cp; cx0[i] = ox * a.cs - a.cp;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB / 2; ++i) {
@@ -199,10 +211,22 @@ void gemm_split_kernel(gemm_args a)
     float sx = kSx0;                                             // activation scale of the pass (2^-e)
     int xe = kXe0;
     auto fetch = [&](int k0) {
+        if (a.conv) {                                            // block-uniform: the K tile's tap and its channel offset
+            const int tap = k0 / a.cC, c0 = k0 - tap * a.cC + 4 * ac;
+            const int ky = tap / a.ckw, kx = tap - ky * a.ckw;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int iy = cy0[i] + ky * a.cd, ix = cx0[i] + kx * a.cd;
+                const bool ok = (unsigned)iy < (unsigned)a.cH && (unsigned)ix < (unsigned)a.cW;
+                areg[i] = ok ? *reinterpret_cast<const float4*>(a.x + ((int64_t)(cby[i] + iy) * a.cW + ix) * a.cC + c0)
+                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             if (KTAIL && k0 + 4 * ac >= K) areg[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             else areg[i] = *reinterpret_cast<const float4*>(xb + aoff[i] + k0);
+        }
         }
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
@@ -465,8 +489,10 @@ AWSEG_API int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w
 }
 
 namespace {
+struct conv_desc { int H, W, C, Ho, Wo, kw, stride, pad, dil; };
+
 int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float* bias, const float* residual,
-                int act, float* out, int64_t m, int n, int k, awseg_stream_t stream)
+                int act, float* out, int64_t m, int n, int k, awseg_stream_t stream, const conv_desc* cv = nullptr)
 {
     if (m == 0 || n == 0) return 0;
     if (!x || !w_split || !out || m < 0 || n < 0 || k < 8 || act < 0 || act > 1) return AWSEG_EINVAL;
@@ -476,6 +502,9 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     a.x = x; a.wh = reinterpret_cast<const _Float16*>(w_split); a.wl = a.wh + (int64_t)n * k;
     a.trailer = reinterpret_cast<const unsigned*>(w_split + 2 * (int64_t)n * k);
     a.bias = bias; a.residual = residual; a.out = out; a.M = m; a.N = n; a.K = k; a.act = act;
+    a.conv = cv ? 1 : 0;
+    if (cv) { a.cH = cv->H; a.cW = cv->W; a.cC = cv->C; a.cHo = cv->Ho; a.cWo = cv->Wo; a.ckw = cv->kw; a.cs = cv->stride; a.cp = cv->pad; a.cd = cv->dil; }
+    else { a.cH = a.cW = a.cC = a.cHo = a.cWo = a.ckw = a.cs = 1; a.cp = 0; a.cd = 1; }
     static int cus = 0;                                          // CU count of the (single, per-process) device, read once
     if (cus == 0) {
         int dev = 0, n_cu = 0;
@@ -538,6 +567,23 @@ AWSEG_API int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split,
                                         int act, float* out, int64_t m, int n, int k, awseg_stream_t stream)
 {
     return gemm_launch(false, x, w_split, bias, residual, act, out, m, n, k, stream);
+}
+
+AWSEG_API int awseg_conv_gemm_split_bias_act(const float* x, int64_t batch, int height, int width, int channels, int kernel_h,
+                                             int kernel_w, int stride, int pad, int dilation, const uint16_t* w_split,
+                                             const float* bias, const float* residual, int act, float* out, int n,
+                                             awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (batch < 0 || height < 1 || width < 1 || channels < 32 || kernel_h < 1 || kernel_w < 1 || stride < 1 || pad < 0 || dilation < 1) return AWSEG_EINVAL;
+    if (channels % 32) return AWSEG_ERANGE;                      // a 32-wide K tile must lie inside one tap
+    const int ho = (height + 2 * pad - dilation * (kernel_h - 1) - 1) / stride + 1;
+    const int wo = (width + 2 * pad - dilation * (kernel_w - 1) - 1) / stride + 1;
+    if (ho < 1 || wo < 1) return AWSEG_ERANGE;
+    const int64_t k = (int64_t)kernel_h * kernel_w * channels;
+    if (k > 0x7fffffff || batch * height > 0x7fffffff) return AWSEG_ERANGE;
+    const conv_desc cv = { height, width, channels, ho, wo, kernel_w, stride, pad, dilation };
+    return gemm_launch(false, x, w_split, bias, residual, act, out, batch * ho * wo, n, (int)k, stream, &cv);
 }
 
 AWSEG_API int awseg_gemm_bf16_weights(const float* w, int n, int k, uint16_t* w_bf16, awseg_stream_t stream)

@@ -639,6 +639,30 @@ def gemm_split_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[t
     return out
 
 
+# strided / patch convolutions: gather the A operand inside the split GEMM (default) or write the im2col matrix first (AWSEG_CONV_GATHER=0)
+CONV_GATHER = os.environ.get("AWSEG_CONV_GATHER", "1") != "0"
+
+
+def conv_gemm_split(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], act: int, kh: int, kw: int, stride: int,
+                    pad: int, dilation: int = 1, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv2d on a float32 NHWC tensor [B,H,W,C] (C % 32 == 0) as one split-operand GEMM whose A operand is gathered from x
+    while it is staged — the im2col matrix of `im2col_nhwc` is never written.  w_split = gemm_split_weights(w2) with
+    w2 [N, kh*kw*C] in (ky, kx, c) column order.  Returns [B,Ho,Wo,N]; bit-identical to im2col_nhwc + gemm_split_bias_act."""
+    x = x.contiguous()
+    b, h, w, c = x.shape
+    n, k = w_split.shape[1], w_split.shape[2]
+    if k != kh * kw * c:
+        raise N.AwsegError(f"conv_gemm_split: weights have K = {k}, the convolution needs {kh * kw * c}")
+    if w_split.untyped_storage().nbytes() - w_split.storage_offset() * 2 < (2 * n * k + 8) * 2:
+        raise N.AwsegError("w_split lost its 16-byte trailer (weight exponent): pass the tensor gemm_split_weights returned, not a copy")
+    ho = (h + 2 * pad - dilation * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dilation * (kw - 1) - 1) // stride + 1
+    out = torch.empty(b, ho, wo, n, dtype=torch.float32, device=x.device)
+    N.call("awseg_conv_gemm_split_bias_act", N.ptr(x), b, h, w, c, kh, kw, stride, pad, dilation, N.ptr(w_split), N.ptr(bias),
+           N.ptr(residual), act, N.ptr(out), n, N.stream())
+    return out
+
+
 def im2col_nhwc(x: torch.Tensor, kh: int, kw: int, stride: int, pad: int, dilation: int = 1, k_padded: Optional[int] = None):
     """x float32 [B,H,W,C] -> (cols [B*Ho*Wo, k_padded], Ho, Wo): column (ky*kw + kx)*C + c, zero padded (awseg.h)."""
     x = x.contiguous()

@@ -496,6 +496,18 @@ int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int
                                       const uint16_t* u_split, const float* shift, const float* residual, int act,
                                       const float* w2, const float* b2, float* out, awseg_stream_t stream);
 
+/* A convolution as ONE split-operand GEMM without the im2col matrix: x float32 NHWC [batch, height, width, channels]
+ * (channels % 32 == 0), weights in im2col column order (ky, kx, c) split by awseg_gemm_split_weights
+ * ([n, kernel_h * kernel_w * channels]); row (b, oy, ox) of the A operand is gathered from x while the K tiles are staged
+ * (zero outside the image).  out float32 [batch * Ho * Wo, n] = NHWC; bias / residual / act as awseg_gemm_split_bias_act.
+ * Same tiles, same summation order as awseg_im2col_nhwc + awseg_gemm_split_bias_act: bit-identical results.  Used for the
+ * stride-2 3x3 / patch convolutions and the stride-2 1x1 downsample branches (reference: the smp ResNet encoder and the
+ * HF SegFormer patch embeddings / sequence reductions built at PKG/models/model.py:262-268, :160-166). */
+int awseg_conv_gemm_split_bias_act(const float* x, int64_t batch, int height, int width, int channels,
+                                   int kernel_h, int kernel_w, int stride, int pad, int dilation,
+                                   const uint16_t* w_split, const float* bias, const float* residual, int act,
+                                   float* out, int n, awseg_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  *  BASELINE config 5: the bf16 MFMA path (SegFormer-B5 + DeepLabV3+-R101)
  * ------------------------------------------------------------------------- *

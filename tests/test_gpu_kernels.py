@@ -997,6 +997,28 @@ def test_gemm_split_float32_grade(ops, shape, res_act):
     assert e_split < 4 * e_lib + 1e-6
 
 
+@pytest.mark.parametrize("cfg", [(2, 37, 53, 64, 128, 3, 3, 2, 1), (1, 64, 96, 32, 160, 2, 2, 2, 0), (3, 40, 40, 128, 256, 1, 1, 2, 0),
+                                 (8, 128, 256, 128, 128, 3, 3, 2, 1), (2, 128, 256, 256, 512, 1, 1, 2, 0), (4, 256, 512, 64, 256, 3, 3, 2, 1)])
+def test_conv_gemm_split_equals_im2col_plus_gemm(ops, cfg):
+    """awseg_conv_gemm_split_bias_act (A operand gathered from the NHWC image while the K tiles are staged) against the
+    im2col matrix + the same GEMM — bit-identical — and against torch's convolution in float64: stride-2 3x3 with padding,
+    kernel == stride patches, stride-2 1x1 downsample; ragged tile edges, tiles spanning two images, every block-tile shape."""
+    B, H, W, C, Nn, kh, kw, st, pd = cfg
+    g = torch.Generator(device="cuda").manual_seed(sum(cfg))
+    x = torch.randn(B, H, W, C, device="cuda", generator=g)
+    wt = torch.randn(Nn, C, kh, kw, device="cuda", generator=g) * 0.05
+    bias = torch.randn(Nn, device="cuda", generator=g)
+    w2 = wt.permute(0, 2, 3, 1).reshape(Nn, kh * kw * C).contiguous()
+    ws = ops.gemm_split_weights(w2)
+    got = ops.conv_gemm_split(x, ws, bias, 1, kh, kw, st, pd)
+    cols, ho, wo = ops.im2col_nhwc(x, kh, kw, st, pd, 1, kh * kw * C)
+    ref_same = ops.gemm_split_bias_act(cols, ws, bias, 1).view(B, ho, wo, Nn)
+    assert got.shape == ref_same.shape and torch.equal(got, ref_same)
+    ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=st, padding=pd))
+    err = (got.permute(0, 3, 1, 2).double() - ref).abs().max().item()
+    assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+
+
 @pytest.mark.parametrize("shape", [(300, 256, 128), (38400, 256, 128), (4100, 320, 72), (131100, 256, 128)])
 @pytest.mark.parametrize("xscale,wscale", [(1e5, 0.05), (3e4, 1e-9), (1e30, 1e-28), (2.0, 1e6), (1e-30, 1e4)])
 def test_gemm_split_large_operands(ops, shape, xscale, wscale):

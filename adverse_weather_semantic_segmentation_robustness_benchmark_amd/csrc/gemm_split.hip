@@ -517,7 +517,7 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     // fills it and there are enough tiles for every CU; else 128 x 128
     static int huge_min = -1;
     if (huge_min < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_HUGE_MIN_TILES"); huge_min = e ? atoi(e) : 1; }
-    const bool huge = !bf16 && (tile_mode == 3 || (tile_mode == 0 && n % 256 == 0 && k >= 128 && ((m + 255) / 256) * (int64_t)(n / 256) >= (int64_t)huge_min * cus));   // K = 64: two K tiles per 256 x 256 epilogue, measured 6 % slower
+    const bool huge = (tile_mode == 3 || (tile_mode == 0 && n % 256 == 0 && k >= 128 && ((m + 255) / 256) * (int64_t)(n / 256) >= (int64_t)huge_min * cus));   // K = 64: two K tiles per 256 x 256 epilogue, measured 6 % slower
     const bool wide = !huge && (tile_mode == 2 || (tile_mode == 0 && n % 256 == 0 && ((m + 127) / 128) * (int64_t)(n / 256) >= cus));
     const int bn = (wide || huge) ? 256 : 128;
     const int bm = huge ? 256 : 128;
@@ -541,7 +541,11 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
             else hipLaunchKernelGGL((gemm_split_kernel<MT_, NT_, WM_, WN_, false, false>), grid, block, 0, awseg_s(stream), a);        \
         }                                                                                                             \
     } while (0)
-    if (huge) {
+    if (huge && bf16) {                                          // one product per tile anyway: the same 128 x 64 wave tiles
+        if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<4, 2, 2, 4, true, true, false>), grid, block, 0, awseg_s(stream), a);
+        else hipLaunchKernelGGL((gemm_split_kernel<4, 2, 2, 4, false, true, false>), grid, block, 0, awseg_s(stream), a);
+    }
+    else if (huge) {
         if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<4, 2, 2, 4, true, false, true>), grid, block, 0, awseg_s(stream), a);
         else hipLaunchKernelGGL((gemm_split_kernel<4, 2, 2, 4, false, false, true>), grid, block, 0, awseg_s(stream), a);
     }

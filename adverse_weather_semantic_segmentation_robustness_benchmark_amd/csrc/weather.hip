@@ -1553,7 +1553,10 @@ static int fog_common(int mode, const uint8_t* imgs, int H, int W, const awseg_f
                 // two 256-thread blocks fit a CU (70 KB LDS ring each): the strip height that makes the grid ONE round of them
                 const int64_t per_round = (int64_t)AWSEG_CUS * 2 / (((W >> 2) + kFogStripQuads - 1) / kFogStripQuads) / cnt;   // y-blocks (4 strips each) available
                 strip_rows = per_round >= 1 ? (int)((H + 4 * per_round - 1) / (4 * per_round)) : H;
-                if (strip_rows < 24) strip_rows = 24;                     // below that the 16 halo rows dominate: take more rounds instead
+                // few frames per launch (the in-step case: 1-2 frames of a kind): short strips — the halo rows triple the noise work,
+                // but the chip is otherwise idle and a wave's serial row walk is the launch's duration; many frames: >= 24 rows per strip
+                const int min_rows = cnt <= 2 ? 8 : 24;
+                if (strip_rows < min_rows) strip_rows = min_rows;
             }
             const bool strip_ok = strip_rows >= 1 && (W & 3) == 0 && W >= 16 && (((uintptr_t)imgs & 3) == 0) &&
                                   (!out || ((uintptr_t)out & 3) == 0) && (!norm_out || ((uintptr_t)norm_out & 15) == 0);

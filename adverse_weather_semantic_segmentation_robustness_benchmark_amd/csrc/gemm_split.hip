@@ -519,15 +519,21 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     if (huge_min < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_HUGE_MIN_TILES"); huge_min = e ? atoi(e) : 1; }
     const bool huge = (tile_mode == 3 || (tile_mode == 0 && n % 256 == 0 && k >= 128 && ((m + 255) / 256) * (int64_t)(n / 256) >= (int64_t)huge_min * cus));   // K = 64: two K tiles per 256 x 256 epilogue, measured 6 % slower
     const bool wide = !huge && (tile_mode == 2 || (tile_mode == 0 && n % 256 == 0 && ((m + 127) / 128) * (int64_t)(n / 256) >= cus));
+    // 256 x 128 (single accumulator, 64 x 64 wave tiles: 8 KB of LDS fragment reads per 12 MFMAs where the 128 x 128 tile's 32 x 64
+    // wave tiles read 6 KB per 6) for the N % 128 == 0 shapes that cannot fill 256-wide tiles; AWSEG_GEMM_SPLIT_TALL=0 turns it off
+    static int tall_on = -1;
+    if (tall_on < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_TALL"); tall_on = e ? atoi(e) : 1; }
+    const bool tall = !huge && !wide && !bf16 && tile_mode == 0 && tall_on && n % 128 == 0 && k >= 128 &&
+                      ((m + 255) / 256) * (int64_t)(n / 128) >= cus;
     const int bn = (wide || huge) ? 256 : 128;
-    const int bm = huge ? 256 : 128;
+    const int bm = (huge || tall) ? 256 : 128;
     const int64_t ntm = (m + bm - 1) / bm;
     a.ntn = (n + bn - 1) / bn;
     const int64_t ntm8 = (ntm + 7) / 8 * 8;                      // 8 m-tiles (one per XCD) x all n-tiles per group
     if (ntm8 * a.ntn > 0x7fffffff || (int64_t)bm * n > 0x7fffffff) return AWSEG_ERANGE;
     a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
     const int64_t slots = ntm8 * a.ntn;
-    int64_t blocks = (int64_t)cus * ((wide || huge) ? 1 : 2) / 8 * 8;      // persistent: one (128 x 256 / 256 x 256) or two (128 x 128) blocks per CU
+    int64_t blocks = (int64_t)cus * ((wide || huge || tall) ? 1 : 2) / 8 * 8;      // persistent: one (128 x 256 / 256 x 256 / 256 x 128) or two (128 x 128) blocks per CU
     if (blocks < 8) blocks = 8;
     if (blocks > slots) blocks = slots;                          // slots is a multiple of 8
     const dim3 grid((unsigned)blocks), block(GT);
@@ -548,6 +554,10 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     else if (huge) {
         if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<4, 2, 2, 4, true, false, true>), grid, block, 0, awseg_s(stream), a);
         else hipLaunchKernelGGL((gemm_split_kernel<4, 2, 2, 4, false, false, true>), grid, block, 0, awseg_s(stream), a);
+    }
+    else if (tall) {
+        if (k % GKT) hipLaunchKernelGGL((gemm_split_kernel<2, 2, 4, 2, true, false, true>), grid, block, 0, awseg_s(stream), a);
+        else hipLaunchKernelGGL((gemm_split_kernel<2, 2, 4, 2, false, false, true>), grid, block, 0, awseg_s(stream), a);
     }
     else if (wide) GEMM_GO(2, 2, 2, 4); else GEMM_GO(1, 2, 4, 2);
 #undef GEMM_GO

@@ -965,13 +965,13 @@ def test_attention_d32_split_flat_softmax(ops):
 
 
 @pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72), (200, 160, 264), (1100, 384, 1024), (38400, 256, 128), (38500, 512, 104),
-                                   (131100, 256, 128), (65600, 512, 104)])
+                                   (131100, 256, 128), (65600, 512, 104), (65700, 128, 512), (70000, 384, 136)])
 @pytest.mark.parametrize("res_act", [(False, 0), (True, 1)])
 def test_gemm_split_float32_grade(ops, shape, res_act):
     """Split-operand f16-MFMA GEMM against float64, next to the hipBLASLt float32 GEMM on the same inputs: ragged M and
     N, K not a multiple of the 32-wide K tile, bias / residual / ReLU epilogue, residual aliasing the output; the last
     two shapes before the end have enough tiles for the 128 x 256 block-tile configuration (N % 256 == 0, >= one tile per CU),
-    the last two for the 256 x 256 single-accumulator one (>= two tiles per CU; ragged M, K tail)."""
+    the next two for the 256 x 256 single-accumulator one (ragged M, K tail), the last two for the 256 x 128 one (N % 128 == 0)."""
     M, Nn, K = shape
     has_res, act = res_act
     g = torch.Generator(device="cuda").manual_seed(M + Nn + K)

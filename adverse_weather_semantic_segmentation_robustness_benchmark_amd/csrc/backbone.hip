@@ -371,6 +371,48 @@ void dwconv3x3_upcat_lds_kernel(const float* __restrict__ a, int h, int w, int C
     }
 }
 
+// nn.MaxPool2d(3, stride 2, padding 1) on an NHWC float32 tensor (the ResNet stem; torch's max_pool2d_with_indices also writes
+// an int64 index per output — 537 MB per batch of 8 at 1024 x 2048 — that nobody reads).  A lane owns 2 adjacent output pixels
+// of one channel quad: 5 columns x 3 rows = 15 loads for 2 outputs.  Out-of-image taps do not take part (-inf padding).
+__global__ __launch_bounds__(kThreads)
+void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, int64_t batch, int H, int W, int C, int Ho, int Wo, float* __restrict__ out)
+{
+    const int c4n = C / 4, wp = (Wo + 1) / 2;
+    const int64_t total = batch * Ho * wp * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * kThreads + threadIdx.x; i < total; i += (int64_t)gridDim.x * kThreads) {
+        const int c4 = (int)(i % c4n);
+        int64_t t = i / c4n;
+        const int xp = (int)(t % wp); t /= wp;
+        const int oy = (int)(t % Ho);
+        const int64_t b = t / Ho;
+        const float* xb = x + b * (int64_t)H * W * C + c4 * 4;
+        const float ninf = -__builtin_inff();
+        float4 col[5];
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int ix = xp * 4 - 1 + q;                         // input columns 2 ox - 1 .. 2 ox + 1 of ox = 2 xp, 2 xp + 1
+            float4 m = make_float4(ninf, ninf, ninf, ninf);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int iy = oy * 2 - 1 + r;
+                if (ix >= 0 && ix < W && iy >= 0 && iy < H) {
+                    const float4 v = *reinterpret_cast<const float4*>(xb + ((int64_t)iy * W + ix) * C);
+                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                }
+            }
+            col[q] = m;
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const int ox = xp * 2 + o;
+            if (ox >= Wo) break;
+            const float4 a = col[2 * o], bq = col[2 * o + 1], c = col[2 * o + 2];
+            const float4 r = make_float4(fmaxf(fmaxf(a.x, bq.x), c.x), fmaxf(fmaxf(a.y, bq.y), c.y), fmaxf(fmaxf(a.z, bq.z), c.z), fmaxf(fmaxf(a.w, bq.w), c.w));
+            *reinterpret_cast<float4*>(out + ((b * Ho + oy) * (int64_t)Wo + ox) * C + c4 * 4) = r;
+        }
+    }
+}
+
 // Bilinear upsampling of [planes, h, w] float32 maps to [planes, H, W] with torch's upsample_bilinear2d arithmetic (source index,
 // weights and the order h0 * (w0 * v00 + w1 * v01) + h1 * (w0 * v10 + w1 * v11)), either corner convention.  DeepLabV3+'s
 // segmentation head ends in UpsamplingBilinear2d(x4) on the 19 logit planes (1.27 GB written per batch of 8 at 1024x2048):
@@ -749,6 +791,20 @@ AWSEG_API int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_wid
     const int64_t items = batch * height * ((width + SX - 1) / SX) * ((a_channels + hi_channels) / 4 - c4_lo);
     hipLaunchKernelGGL((dwconv3x3_upcat_strip_kernel<SX>), dim3(awseg_grid_1d(items, kThreads)), dim3(kThreads), 0, awseg_s(stream),
                        a, a_height, a_width, a_channels, hi, hi_channels, batch, height, width, ry, rx, w9, out, c4_lo);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_maxpool3x3s2_nhwc(const float* x, int64_t batch, int height, int width, int channels, float* out,
+                                      awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!x || !out || batch < 0 || height < 1 || width < 1 || channels < 4 || (channels & 3)) return AWSEG_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return AWSEG_EALIGN;
+    const int ho = (height - 1) / 2 + 1, wo = (width - 1) / 2 + 1;     // floor((n + 2 - 3) / 2) + 1
+    const int64_t total = batch * ho * ((wo + 1) / 2) * (channels / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, batch,
+                       height, width, channels, ho, wo, out);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -26,6 +26,10 @@ from .. import ops
 CL = torch.channels_last
 
 
+def _pair(v):
+    return (v, v) if isinstance(v, int) else tuple(v)
+
+
 # --------------------------------------------------------------------------- parameter caches
 def _versions(*tensors):
     return tuple((t.data_ptr(), t._version) for t in tensors if t is not None)
@@ -258,7 +262,14 @@ def resnet_features(enc, x: torch.Tensor, stem_feature: bool = False) -> List[to
         y = enc.maxpool(y)
     else:
         w, shift = folded_conv_bn(enc.conv1, enc.bn1)
-        y = enc.maxpool(F.conv2d(x, w, None, enc.conv1.stride, enc.conv1.padding))
+        y = F.conv2d(x, w, None, enc.conv1.stride, enc.conv1.padding)
+        mp = enc.maxpool
+        if (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous(memory_format=CL) and y.shape[1] % 4 == 0
+                and _pair(mp.kernel_size) == (3, 3) and _pair(mp.stride) == (2, 2) and _pair(mp.padding) == (1, 1)
+                and _pair(mp.dilation) == (1, 1) and not mp.ceil_mode):
+            y = ops.maxpool3x3s2_nhwc(nhwc_view(y)).permute(0, 3, 1, 2)          # HIP: no int64 index tensor (torch writes 537 MB of them)
+        else:
+            y = mp(y)
         if not y.is_contiguous(memory_format=CL):
             y = y.contiguous(memory_format=CL)
         ops.bias_act_nhwc_(y.permute(0, 2, 3, 1), shift, None, N.ACT_RELU)

@@ -321,6 +321,8 @@ class EnsembleModel(nn.Module):
                      oob: Optional[torch.Tensor] = None, cond: Optional[torch.Tensor] = None, want_logits: bool = True,
                      want_pred: bool = True, pred_dtype=torch.int64) -> Dict[str, torch.Tensor]:
         """members -> ONE pass: combine, /temperature, argmax, confusion (slots: overall + condition)."""
+        if x.is_cuda and x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
+            x = x.contiguous(memory_format=torch.channels_last)    # both members start from NHWC memory: convert once, not once each
         o1 = self.segformer(x)
         self.deeplabv3plus._defer_depth_upsample = self.include_depth
         try:

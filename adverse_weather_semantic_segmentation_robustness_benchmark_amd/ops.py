@@ -791,6 +791,15 @@ def restore_split(state: dict) -> None:
     HEAD_SPLIT = bool(state.get("segformer_head", HEAD_SPLIT))
 
 
+def maxpool3x3s2_nhwc(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """nn.MaxPool2d(3, stride=2, padding=1) on a contiguous float32 [B,H,W,C] tensor -> [B,Ho,Wo,C] (no index tensor)."""
+    x = x_nhwc.contiguous()
+    b, h, w, c = x.shape
+    out = torch.empty(b, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c, dtype=torch.float32, device=x.device)
+    N.call("awseg_maxpool3x3s2_nhwc", N.ptr(x), b, h, w, c, N.ptr(out), N.stream())
+    return out
+
+
 def upsample_bilinear(x: torch.Tensor, size, align_corners: bool) -> torch.Tensor:
     """F.interpolate(x, size, mode="bilinear", align_corners=...) / nn.UpsamplingBilinear2d on an NCHW float32 tensor, torch's
     arithmetic (bit-identical), 4 output pixels per lane."""

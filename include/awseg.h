@@ -578,6 +578,12 @@ int awseg_attention_d32(const float* q, const float* k, const float* v, float* o
 int awseg_attention_d32_split(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                               int n_queries, int n_keys, float scale, awseg_stream_t stream);
 
+/* nn.MaxPool2d(kernel 3, stride 2, padding 1) on a float32 NHWC tensor [batch, height, width, channels] (channels % 4 == 0)
+ * -> [batch, (height - 1) / 2 + 1, (width - 1) / 2 + 1, channels]; padding does not take part in the maximum.  The ResNet stem
+ * of the smp encoder the reference builds (PKG/models/model.py:262-268); no index tensor is produced. */
+int awseg_maxpool3x3s2_nhwc(const float* x, int64_t batch, int height, int width, int channels, float* out,
+                            awseg_stream_t stream);
+
 /* Bilinear upsampling of [planes, low_height, low_width] float32 maps to [planes, height, width] with torch's
  * upsample_bilinear2d arithmetic (source index, weights, order of the four products), align_corners 0 or 1.  Replaces
  * the nn.UpsamplingBilinear2d(scale_factor=4) at the end of DeepLabV3+'s segmentation head (the smp model the reference

@@ -865,6 +865,15 @@ def test_gemm_tune_keeps_results(ops, native):
     assert (ops.gemm_bias_act(x, w, b, 1).double() - ref).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("shape", [(2, 17, 23, 8), (1, 64, 128, 64), (3, 9, 10, 4), (1, 1, 7, 12)])
+def test_maxpool3x3s2_nhwc_equals_torch(ops, shape):
+    B, H, W, C = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape))
+    x = torch.randn(B, H, W, C, device="cuda", generator=g)
+    ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(ops.maxpool3x3s2_nhwc(x), ref)
+
+
 @pytest.mark.parametrize("cfg", [(2, 19, 16, 32, 64, 128, True), (1, 3, 7, 5, 28, 20, True), (2, 1, 4, 8, 64, 128, False),
                                  (1, 2, 5, 9, 33, 70, False), (1, 19, 256, 512, 1024, 2048, True)])
 def test_upsample_bilinear_matches_torch(ops, cfg):

@@ -125,6 +125,8 @@ def main():
     hist = torch.zeros(2, 8192, dtype=torch.int64, device=dev)
     cases["ensemble eval stats (ECE + disagreement hist)"] = (
         lambda: ops.ensemble_eval_stats(s1, s2, 0, wts, T, labels, cond, edges, bins, hist, 0.0, 3.0), "hbm", (2 * C * 4 + 1) * px * B)
+    xmp = torch.randn(B, H // 2, W // 2, 64, device=dev)
+    cases["maxpool3x3s2 nhwc 64ch (resnet stem)"] = (lambda: ops.maxpool3x3s2_nhwc(xmp), "hbm", 64 * 4 * (H // 2) * (W // 2) * B * (1 + 1 / 4))
     lowl = torch.randn(B, C, H // 4, W // 4, device=dev)
     cases["upsample_bilinear x4 19 planes (deeplab logits)"] = (lambda: ops.upsample_bilinear(lowl, (H, W), True), "hbm", C * 4 * px * B * (1 + 1 / 16))
     xl = torch.randn(B * (H // 4) * (W // 4), 32, device=dev); lw = torch.randn(32, device=dev); lb = torch.randn(32, device=dev)

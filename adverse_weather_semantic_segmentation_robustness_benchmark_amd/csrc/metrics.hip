@@ -405,15 +405,22 @@ __global__ void ece_fold_kernel(const ece_cell* __restrict__ partial, int blocks
 //              then a rank statistic of the two histograms, additive over batches and ranks.
 // C = 19 only (2 x 19 x 4 logits live in registers); 4 pixels per lane.
 // ---------------------------------------------------------------------------------------
-template <int MODE, int LDT>
+// CONF = true: the same pass ALSO counts the 19 x 19 confusion matrix of argmax(r) against the labels, with the combine kernel's
+// rules (torch's argmax update, ignore_index, the reference's uint8 index wrap, out-of-range count) into per-block partials that
+// fold_partials_kernel folds — the separate awseg_combine_argmax_confusion pass over the two logit maps (2.55 GB per batch of 8
+// at 1024 x 2048) is not needed when neither the ensemble logits nor the prediction map are asked for.
+template <int MODE, int LDT, bool CONF>
 __global__ __launch_bounds__(kThreads)
 void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restrict__ seg2, int64_t hw,
                            const float* __restrict__ weights, const float* __restrict__ temperature,
                            const void* __restrict__ label, const float* __restrict__ edges, int n_bins,
                            ece_cell* __restrict__ partial, unsigned long long* __restrict__ hist, int n_hist,
-                           float h_lo, float h_scale)
+                           float h_lo, float h_scale, int ignore_index, int wrap, uint32_t* __restrict__ conf_partial,
+                           int64_t* __restrict__ oob)
 {
     constexpr int C = 19;
+    __shared__ uint32_t s_conf[CONF ? C * C : 1];
+    if (CONF) { for (int i = threadIdx.x; i < C * C; i += kThreads) s_conf[i] = 0u; }
     __shared__ uint32_t s_cnt[64], s_cor[64];
     __shared__ unsigned long long s_sum[64];
     __shared__ float s_edges[65];
@@ -446,7 +453,7 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int64_t t = awseg_ld_label<LDT>(label, img * hw + p + k);
-            if (t == 255) continue;                               // metrics.py:170, :426
+            if (!CONF && t == 255) continue;                      // metrics.py:170, :426
             // ensemble logits r, their max / argmax / sum-exp for the calibration part
             float rmax = -INFINITY, rsum = 0.f; int rarg = 0;
             float r[C];
@@ -458,8 +465,13 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
                 else { float u = x[c][k] + y[c][k]; rv = u / 2.f; }
                 if (has_t) rv = rv / T;
                 r[c] = rv;
-                if (c == 0 || rv > rmax) { rmax = rv; rarg = c; }
+                if (CONF) { if (c == 0) { rmax = rv; rarg = 0; } else amax_step(rv, c, rmax, rarg); }   // torch's argmax rule, as the combine kernel
+                else if (c == 0 || rv > rmax) { rmax = rv; rarg = c; }
                 m1 = fmaxf(m1, x[c][k]); m2 = fmaxf(m2, y[c][k]);
+            }
+            if (CONF) {
+                hist_add<LDT>(s_conf, label, img * hw + p + k, rarg, C, ignore_index, wrap, oob);
+                if (t == 255) continue;                           // the calibration / disagreement statistics skip 255 (metrics.py:170, :426)
             }
 #pragma unroll
             for (int c = 0; c < C; ++c) rsum += __expf(r[c] - rmax);
@@ -506,6 +518,10 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
     for (int i = threadIdx.x; i < 2 * n_hist; i += kThreads) {
         const uint32_t v = s_hist[i];
         if (v) atomicAdd(&hist[i], (unsigned long long)v);
+    }
+    if (CONF) {
+        uint32_t* cd = conf_partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (C * C);
+        for (int i = threadIdx.x; i < C * C; i += kThreads) cd[i] = s_conf[i];
     }
 }
 
@@ -555,8 +571,8 @@ AWSEG_API int64_t awseg_metrics_workspace(int64_t batch, int num_classes, int64_
 {
     // uint32 partials: one C*C histogram per block; also covers the ECE partials (24 B x 64 bins)
     int64_t bpi = blocks_per_image(hw, batch < 1 ? 1 : batch, 1);
-    int64_t per_block = (int64_t)num_classes * num_classes * 4;
-    if (per_block < 64 * 24) per_block = 64 * 24;
+    // + the ECE partials BEHIND the histogram partials when one launch produces both (awseg_combine_confusion_stats)
+    int64_t per_block = (int64_t)num_classes * num_classes * 4 + 64 * 24;
     return bpi * (batch < 1 ? 1 : batch) * per_block;
 }
 
@@ -687,13 +703,15 @@ AWSEG_API int awseg_ece_accumulate(const float* logits, int64_t batch, int num_c
     return 0;
 }
 
-AWSEG_API int awseg_ensemble_eval_stats(const float* seg1, const float* seg2, int64_t batch, int num_classes, int64_t hw,
-                                        int mode, const float* weights, const float* temperature, const void* label,
-                                        int label_dtype, const int32_t* cond, const float* edges, int n_bins, void* ece_bins,
-                                        int n_slots, int64_t* auroc_hist, int n_hist, float hist_lo, float hist_hi,
-                                        void* workspace, awseg_stream_t stream)
+static int stats_impl(const float* seg1, const float* seg2, int64_t batch, int num_classes, int64_t hw,
+                      int mode, const float* weights, const float* temperature, const void* label,
+                      int label_dtype, const int32_t* cond, const float* edges, int n_bins, void* ece_bins,
+                      int n_slots, int64_t* auroc_hist, int n_hist, float hist_lo, float hist_hi,
+                      void* workspace, awseg_stream_t stream,
+                      bool conf, int ignore_index, int wrap, int64_t* counts, int count_slots, int64_t* oob)
 {
     if (!seg1 || !seg2 || !label || !edges || !ece_bins || !auroc_hist || !workspace) return AWSEG_EINVAL;
+    if (conf && (!counts || !oob || count_slots < 1)) return AWSEG_EINVAL;
     if (num_classes != 19) return AWSEG_ERANGE;                  // register-resident 2 x 19 x 4 logits
     if (mode != AWSEG_COMBINE_WEIGHTED && mode != AWSEG_COMBINE_MEAN) return AWSEG_ERANGE;
     if (mode == AWSEG_COMBINE_WEIGHTED && !weights) return AWSEG_EINVAL;
@@ -707,16 +725,47 @@ AWSEG_API int awseg_ensemble_eval_stats(const float* seg1, const float* seg2, in
     const float scale = (float)n_hist / (hist_hi - hist_lo);
     const size_t lds = (size_t)2 * n_hist * sizeof(uint32_t);
     unsigned long long* hist = (unsigned long long*)auroc_hist;
-#define AWSEG_ES(M, L) { \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ensemble_stats_kernel<M, L>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AWSEG_EINVAL; \
-        hipLaunchKernelGGL((ensemble_stats_kernel<M, L>), grid, block, lds, s, seg1, seg2, hw, weights, temperature, label, \
-                           edges, n_bins, (ece_cell*)workspace, hist, n_hist, hist_lo, scale); }
-    if (mode == AWSEG_COMBINE_WEIGHTED) { if (label_dtype == AWSEG_U8) AWSEG_ES(0, AWSEG_U8) else if (label_dtype == AWSEG_I64) AWSEG_ES(0, AWSEG_I64) else return AWSEG_EINVAL; }
-    else { if (label_dtype == AWSEG_U8) AWSEG_ES(2, AWSEG_U8) else if (label_dtype == AWSEG_I64) AWSEG_ES(2, AWSEG_I64) else return AWSEG_EINVAL; }
+    // workspace: [batch][bpi][n_bins] ECE cells, then (conf) [batch][bpi][19 x 19] uint32 histogram partials
+    uint32_t* conf_partial = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + (size_t)batch * bpi * 64 * sizeof(ece_cell));
+#define AWSEG_ES(M, L, CF) { \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ensemble_stats_kernel<M, L, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AWSEG_EINVAL; \
+        hipLaunchKernelGGL((ensemble_stats_kernel<M, L, CF>), grid, block, lds, s, seg1, seg2, hw, weights, temperature, label, \
+                           edges, n_bins, (ece_cell*)workspace, hist, n_hist, hist_lo, scale, ignore_index, wrap, conf_partial, oob); }
+#define AWSEG_ES2(M, L) { if (conf) AWSEG_ES(M, L, true) else AWSEG_ES(M, L, false) }
+    if (mode == AWSEG_COMBINE_WEIGHTED) { if (label_dtype == AWSEG_U8) AWSEG_ES2(0, AWSEG_U8) else if (label_dtype == AWSEG_I64) AWSEG_ES2(0, AWSEG_I64) else return AWSEG_EINVAL; }
+    else { if (label_dtype == AWSEG_U8) AWSEG_ES2(2, AWSEG_U8) else if (label_dtype == AWSEG_I64) AWSEG_ES2(2, AWSEG_I64) else return AWSEG_EINVAL; }
+#undef AWSEG_ES2
 #undef AWSEG_ES
     AWSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(ece_fold_kernel, dim3((unsigned)batch), dim3(64), 0, s, (const ece_cell*)workspace, bpi, n_bins, cond,
                        n_slots, (ece_out*)ece_bins);
     AWSEG_LAUNCH_CHECK();
+    if (conf) {
+        hipLaunchKernelGGL(fold_partials_kernel, dim3((unsigned)batch, (19 * 19 + 63) / 64), dim3(kFoldSlices * 64), 0, s, conf_partial, bpi,
+                           19 * 19, cond, count_slots, counts);
+        AWSEG_LAUNCH_CHECK();
+    }
     return 0;
+}
+
+AWSEG_API int awseg_ensemble_eval_stats(const float* seg1, const float* seg2, int64_t batch, int num_classes, int64_t hw,
+                                        int mode, const float* weights, const float* temperature, const void* label,
+                                        int label_dtype, const int32_t* cond, const float* edges, int n_bins, void* ece_bins,
+                                        int n_slots, int64_t* auroc_hist, int n_hist, float hist_lo, float hist_hi,
+                                        void* workspace, awseg_stream_t stream)
+{
+    return stats_impl(seg1, seg2, batch, num_classes, hw, mode, weights, temperature, label, label_dtype, cond, edges, n_bins,
+                      ece_bins, n_slots, auroc_hist, n_hist, hist_lo, hist_hi, workspace, stream, false, 255, 0, nullptr, 0, nullptr);
+}
+
+AWSEG_API int awseg_combine_confusion_stats(const float* seg1, const float* seg2, int64_t batch, int num_classes, int64_t hw,
+                                            int mode, const float* weights, const float* temperature, const void* label,
+                                            int label_dtype, int ignore_index, int label_wrap_u8, const int32_t* cond,
+                                            int64_t* counts, int count_slots, int64_t* oob, const float* edges, int n_bins,
+                                            void* ece_bins, int ece_slots, int64_t* auroc_hist, int n_hist, float hist_lo,
+                                            float hist_hi, void* workspace, awseg_stream_t stream)
+{
+    return stats_impl(seg1, seg2, batch, num_classes, hw, mode, weights, temperature, label, label_dtype, cond, edges, n_bins,
+                      ece_bins, ece_slots, auroc_hist, n_hist, hist_lo, hist_hi, workspace, stream, true, ignore_index,
+                      label_wrap_u8, counts, count_slots, oob);
 }

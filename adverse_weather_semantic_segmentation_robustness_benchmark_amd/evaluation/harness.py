@@ -20,6 +20,8 @@ import logging
 from typing import Any, Dict
 
 import numpy as np
+import os
+
 import torch
 import torch.nn.functional as F
 
@@ -86,6 +88,10 @@ class EvalState:
         return float((pos * (below + 0.5 * neg)).sum().item() / (P * Nn))
 
 
+# confusion + calibration + disagreement statistics in one pass over the member logits (AWSEG_STATS_ONE_PASS=0: two passes)
+STATS_ONE_PASS = os.environ.get("AWSEG_STATS_ONE_PASS", "1") != "0"
+
+
 @torch.no_grad()
 def eval_batch(model, st: EvalState, images: torch.Tensor, labels: torch.Tensor, conds, metrics: RobustnessMetrics,
                with_stats: bool = True) -> None:
@@ -99,8 +105,11 @@ def eval_batch(model, st: EvalState, images: torch.Tensor, labels: torch.Tensor,
         strategy = getattr(model, "ensemble_strategy", "weighted_average")
         fused_stats = metrics.num_classes == 19 and strategy != "max_confidence" and images[0, 0].numel() % 4 == 0
         need_logits = with_stats and not fused_stats
-        res = model.forward_eval(images, labels, st.acc.counts, st.acc.oob, cond, want_logits=need_logits, want_pred=False)
-        if with_stats and fused_stats:
+        one_pass = (st.edges, st.ece, st.auroc, AUROC_LO, AUROC_HI) if (with_stats and fused_stats and STATS_ONE_PASS) else None
+        res = model.forward_eval(images, labels, st.acc.counts, st.acc.oob, cond, want_logits=need_logits, want_pred=False, stats=one_pass)
+        if one_pass is not None and getattr(model, "_stats_fused", False):
+            pass                                                  # confusion, ECE bins and the disagreement histogram came out of ONE pass
+        elif with_stats and fused_stats:
             # ECE of the combined logits + disagreement histogram in ONE pass over the member logits:
             # the ensemble logits are never materialised
             mode = N.COMBINE_WEIGHTED if strategy == "weighted_average" else N.COMBINE_MEAN

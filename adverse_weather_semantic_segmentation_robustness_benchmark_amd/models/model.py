@@ -319,8 +319,10 @@ class EnsembleModel(nn.Module):
     @torch.no_grad()
     def forward_eval(self, x: torch.Tensor, labels: Optional[torch.Tensor] = None, counts: Optional[torch.Tensor] = None,
                      oob: Optional[torch.Tensor] = None, cond: Optional[torch.Tensor] = None, want_logits: bool = True,
-                     want_pred: bool = True, pred_dtype=torch.int64) -> Dict[str, torch.Tensor]:
-        """members -> ONE pass: combine, /temperature, argmax, confusion (slots: overall + condition)."""
+                     want_pred: bool = True, pred_dtype=torch.int64, stats=None) -> Dict[str, torch.Tensor]:
+        """members -> ONE pass: combine, /temperature, argmax, confusion (slots: overall + condition).
+        stats = (edges, ece_bins, auroc_hist, lo, hi): also accumulate the calibration / disagreement statistics in that pass
+        when nothing per-pixel is asked for (`self._stats_fused` tells the caller whether it happened)."""
         if x.is_cuda and x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)    # both members start from NHWC memory: convert once, not once each
         o1 = self.segformer(x)
@@ -332,9 +334,18 @@ class EnsembleModel(nn.Module):
         mode = _STRATEGY.get(self.ensemble_strategy, N.COMBINE_MEAN)
         w = F.softmax(self.ensemble_weights, dim=0) if mode == N.COMBINE_WEIGHTED else None
         T = self.temperature if self.temperature_scaling else None
-        logits, pred = ops.combine_argmax_confusion(o1["segmentation"], o2["segmentation"], mode, w, T,
-                                                    want_logits=want_logits, want_pred=want_pred, pred_dtype=pred_dtype,
-                                                    label=labels, counts=counts, oob=oob, cond=cond)
+        if (stats is not None and not want_logits and not want_pred and labels is not None and counts is not None
+                and mode in (N.COMBINE_WEIGHTED, N.COMBINE_MEAN) and o1["segmentation"].shape[1] == 19
+                and o1["segmentation"][0, 0].numel() % 4 == 0):
+            # confusion + ECE bins + disagreement histogram in ONE pass over the member logits (stats = (edges, ece, auroc, lo, hi))
+            ops.combine_confusion_stats(o1["segmentation"], o2["segmentation"], mode, w, T, labels, cond, counts, oob, *stats)
+            logits, pred = None, None
+            self._stats_fused = True
+        else:
+            self._stats_fused = False
+            logits, pred = ops.combine_argmax_confusion(o1["segmentation"], o2["segmentation"], mode, w, T,
+                                                        want_logits=want_logits, want_pred=want_pred, pred_dtype=pred_dtype,
+                                                        label=labels, counts=counts, oob=oob, cond=cond)
         res = {"segformer_seg": o1["segmentation"], "deeplabv3plus_seg": o2["segmentation"]}
         if logits is not None:
             res["segmentation"] = logits

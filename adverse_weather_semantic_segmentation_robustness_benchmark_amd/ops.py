@@ -136,6 +136,22 @@ def ensemble_eval_stats(seg1: torch.Tensor, seg2: torch.Tensor, mode: int, weigh
            N.ptr(auroc_hist), auroc_hist.shape[1], float(lo), float(hi), N.ptr(ws), N.stream())
 
 
+def combine_confusion_stats(seg1: torch.Tensor, seg2: torch.Tensor, mode: int, weights, temperature, label: torch.Tensor, cond,
+                            counts: torch.Tensor, oob: torch.Tensor, edges: torch.Tensor, ece_bins: torch.Tensor,
+                            auroc_hist: torch.Tensor, lo: float, hi: float, ignore_index: int = 255, wrap_u8: Optional[bool] = None) -> None:
+    """combine_argmax_confusion (confusion counters only) + ensemble_eval_stats in one pass over the member logits."""
+    seg1, seg2, label = seg1.contiguous(), seg2.contiguous(), label.contiguous()
+    b, c = seg1.shape[0], seg1.shape[1]
+    hw = seg1[0, 0].numel()
+    if wrap_u8 is None:
+        wrap_u8 = label.dtype == torch.uint8
+    ws = N.workspace.get(seg1.device, N.lib().awseg_metrics_workspace(b, c, hw))
+    N.call("awseg_combine_confusion_stats", N.ptr(seg1), N.ptr(seg2), b, c, hw, mode, N.ptr(weights), N.ptr(temperature), N.ptr(label),
+           N.label_dtype(label), int(ignore_index), int(bool(wrap_u8)), N.ptr(cond), N.ptr(counts), counts.shape[0], N.ptr(oob),
+           N.ptr(edges), ece_bins.shape[1], N.ptr(ece_bins), ece_bins.shape[0], N.ptr(auroc_hist), auroc_hist.shape[1], float(lo),
+           float(hi), N.ptr(ws), N.stream())
+
+
 ECE_CONF_UNIT = 2.0 ** -30     # the device keeps the confidence sums in fixed point (int64, units of 2^-30): exact, order-independent
 
 

@@ -142,6 +142,8 @@ def algorithmic_work(name, B, H, W, C, info):
         return "hbm", (3 + 12) * px * n
     if name == "awseg_combine_argmax_confusion":
         return "hbm", (2 * C * 4 + 1) * px * B         # two member logit maps + labels in; counters only out
+    if name == "awseg_combine_confusion_stats":
+        return "hbm", (2 * C * 4 + 1) * px * B         # ONE pass over the two member logit maps + labels: confusion, ECE bins, disagreement histogram
     if name == "awseg_ensemble_eval_stats":
         return "hbm", (2 * C * 4 + 1) * px * B         # the same two member logit maps + labels again; bins / histogram out
     if name == "awseg_depth_upsample_combine":
@@ -162,7 +164,7 @@ def algorithmic_work(name, B, H, W, C, info):
 DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>", "awseg_conv3x3_winograd_split_nhwc": ("wino_split_kernel<0, false>", "wino_split_kernel<1, false>"), "awseg_conv3x3_winograd_bf16_nhwc": ("wino_split_kernel<0, true>", "wino_split_kernel<1, true>"), "awseg_gemm_split_bias_act": ("gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false"),
                  "awseg_gemm_bf16_bias_act": ("gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
                  "awseg_attention_d32_split": "attention_d32_split_kernel",
-                 "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0",
+                 "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0", "awseg_combine_confusion_stats": "ensemble_stats_kernel<",
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_walk_kernel"}
 
 

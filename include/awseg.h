@@ -645,6 +645,18 @@ int awseg_ensemble_eval_stats(const float* seg1, const float* seg2, int64_t batc
                               int64_t* auroc_hist, int n_hist, float hist_lo, float hist_hi,
                               void* workspace, awseg_stream_t stream);
 
+/* awseg_combine_argmax_confusion (no logits / prediction output) and awseg_ensemble_eval_stats in ONE pass over the two member
+ * logit maps: the 19 x 19 confusion counts of argmax(combine(s1, s2) / T) against the labels (slots: overall + 1 + cond[b], the
+ * combine kernel's argmax / ignore_index / uint8-wrap / out-of-range rules) together with the ECE bins and the disagreement
+ * histogram.  Same results as the two calls; the second 2 x 19 x 4 B/px read is gone.  C = 19, hw % 4 == 0; workspace of
+ * awseg_metrics_workspace(batch, 19, hw) bytes.  Replaces REF/scripts/evaluate.py:179-200 + :230-255 per batch. */
+int awseg_combine_confusion_stats(const float* seg1, const float* seg2, int64_t batch, int num_classes, int64_t hw,
+                                  int mode, const float* weights, const float* temperature, const void* label,
+                                  int label_dtype, int ignore_index, int label_wrap_u8, const int32_t* cond,
+                                  int64_t* counts, int count_slots, int64_t* oob, const float* edges, int n_bins,
+                                  void* ece_bins, int ece_slots, int64_t* auroc_hist, int n_hist, float hist_lo,
+                                  float hist_hi, void* workspace, awseg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

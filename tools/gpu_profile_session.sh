@@ -17,3 +17,12 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_kb_fetch -o kb -- python3 $K > $O/${R}_prof_kb_fetch.log 2>&1; echo "kb fetch exit $?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_kb_write -o kb -- python3 $K > $O/${R}_prof_kb_write.log 2>&1; echo "kb write exit $?"
 du -sh $O/${R}_prof_* | tail -8
+# Afterwards, in the repo (CPU is enough):
+#   python tools/make_profiles.py step gpurun_out/r02_prof_step ensemble_stats_kernel profiles/r02_bench_step_kernels.csv "<header>"
+#        (marker = a kernel that runs once per step: the one-pass confusion + statistics kernel)
+#   python tools/make_profiles.py kernel-table gpurun_out/r02_prof_step gpurun_out/r02_prof_step_fetch gpurun_out/r02_prof_step_write \
+#        profiles/r02_bench_step_stats_and_traffic.csv "<header>" mean
+#   python tools/make_profiles.py kernel-table gpurun_out/r02_prof_kb_trace gpurun_out/r02_prof_kb_fetch gpurun_out/r02_prof_kb_write \
+#        profiles/r02_kernel_bench_stats_and_traffic.csv "<header>"
+#   cp gpurun_out/r02_kernel_bench_hip_events.log gpurun_out/r02_bench_line_default.json gpurun_out/r02_bench_line_b5_r101_bf16.json profiles/
+#   python tools/make_profiles.py check-log profiles/r02_kernel_bench_hip_events.log

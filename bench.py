@@ -402,9 +402,10 @@ def train_main(args):
                        "dataset": ["synthetic"] * B}
 
     t_start = time.perf_counter()
-    # MIOpen's immediate-mode fall-back picks im2col + GEMM solvers for the backward 3x3 convolutions at these sizes (a
-    # bs-2 step did not finish in 300 s, gpurun_out/r02_train_bs2.err): let it time its solvers once per shape instead
-    torch.backends.cudnn.benchmark = not args.no_conv_search
+    # Solver choice: MIOpen in immediate mode with MIOPEN_FIND_MODE=FAST (set in main()): find-db, else its heuristic pick.
+    # torch.backends.cudnn.benchmark (--conv-search 1) makes every new shape go through miopenFind*, which on a fresh box sat
+    # for minutes inside ONE forward 1x1 convolution (gpurun_out/train_small.err, MIOPEN_ENABLE_LOGGING_CMD=1) — off by default.
+    torch.backends.cudnn.benchmark = bool(args.conv_search) and not args.no_conv_search
     config = {"epochs": 1, "num_classes": C, "optimizer": {"type": "adamw", "learning_rate": 1e-4, "weight_decay": 0.01},
               "loss": {"type": "fog_density_aware"}, "grad_clip": 1.0, "seed": 42}
     tmp = tempfile.mkdtemp(prefix="awseg_bench_")

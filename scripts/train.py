@@ -5,12 +5,17 @@ its shard and gradients are averaged in buckets over RCCL."""
 import argparse
 import json
 import logging
+import os
 import random
 import sys
 from pathlib import Path
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
+# Training shapes miss MIOpen's find-db on a fresh machine; its default (hybrid) find mode then BENCHMARKS every candidate solver of
+# every backward convolution — the first step at 1024x2048 did not finish in 7 minutes.  FAST = find-db, else the
+# heuristic pick.  Set before torch loads MIOpen; an explicit MIOPEN_FIND_MODE in the environment wins.
+os.environ.setdefault("MIOPEN_FIND_MODE", "FAST")
 
 import numpy as np
 import torch

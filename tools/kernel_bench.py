@@ -123,6 +123,9 @@ def main():
     cases["style lut3 u8->u8"] = (lambda: ops.lut3_apply(imgs, luts, lut_of, out=out), "hbm", 6 * px * B)
     cases["local_contrast (fog density map)"] = (lambda: ops.local_contrast(imgs), "hbm", (3 + 4) * px * B)
     hist = torch.zeros(2, 8192, dtype=torch.int64, device=dev)
+    cnt6 = torch.zeros(6, C * C, dtype=torch.int64, device=dev); oob1 = torch.zeros(1, dtype=torch.int64, device=dev)
+    cases["combine + confusion + eval stats in one pass"] = (
+        lambda: ops.combine_confusion_stats(s1, s2, 0, wts, T, labels, cond, cnt6, oob1, edges, bins, hist, 0.0, 3.0), "hbm", (2 * C * 4 + 1) * px * B)
     cases["ensemble eval stats (ECE + disagreement hist)"] = (
         lambda: ops.ensemble_eval_stats(s1, s2, 0, wts, T, labels, cond, edges, bins, hist, 0.0, 3.0), "hbm", (2 * C * 4 + 1) * px * B)
     xmp = torch.randn(B, H // 2, W // 2, 64, device=dev)
@@ -131,6 +134,17 @@ def main():
     cases["upsample_bilinear x4 19 planes (deeplab logits)"] = (lambda: ops.upsample_bilinear(lowl, (H, W), True), "hbm", C * 4 * px * B * (1 + 1 / 16))
     xl = torch.randn(B * (H // 4) * (W // 4), 32, device=dev); lw = torch.randn(32, device=dev); lb = torch.randn(32, device=dev)
     cases["layernorm_rows C=32 @1/4"] = (lambda: ops.layernorm_rows(xl, lw, lb, 1e-6), "hbm", 2 * 32 * 4 * xl.shape[0])
+
+    # stride-2 3x3 convolution (resnet layer2 conv2: 128 -> 128 at 1/4 -> 1/8): A operand gathered inside the split GEMM vs im2col + the same GEMM
+    xcv = torch.randn(B, H // 4, W // 4, 128, device=dev); wcv = torch.randn(128, 9 * 128, device=dev) * 0.03; bcv = torch.randn(128, device=dev)
+    wscv = ops.gemm_split_weights(wcv)
+    flc = 3 * 2.0 * B * (H // 8) * (W // 8) * 128 * 9 * 128
+    cases["conv3x3 s2 128->128 @1/4 gathered in the split GEMM [split f16x3, issued flops]"] = (lambda: ops.conv_gemm_split(xcv, wscv, bcv, 1, 3, 3, 2, 1), "mfma_f16", flc)
+
+    def _im2col_then_gemm():
+        cols, _, _ = ops.im2col_nhwc(xcv, 3, 3, 2, 1, 1, 9 * 128)
+        return ops.gemm_split_bias_act(cols, wscv, bcv, 1)
+    cases["conv3x3 s2 128->128 @1/4 im2col + split GEMM [split f16x3, issued flops]"] = (_im2col_then_gemm, "mfma_f16", flc)
 
     # Winograd F(2x2,3x3): MFMA flops actually issued = 16 multiplies per 2x2 outputs (2.25x fewer than direct)
     def wino_case(name, b, hh, ww, cin, cout, dil, head):

@@ -875,7 +875,8 @@ def test_maxpool3x3s2_nhwc_equals_torch(ops, shape):
 
 
 @pytest.mark.parametrize("cfg", [(2, 19, 16, 32, 64, 128, True), (1, 3, 7, 5, 28, 20, True), (2, 1, 4, 8, 64, 128, False),
-                                 (1, 2, 5, 9, 33, 70, False), (1, 19, 256, 512, 1024, 2048, True)])
+                                 (1, 2, 5, 9, 33, 70, False), (1, 19, 256, 512, 1024, 2048, True), (2, 4, 8, 8, 16, 16, False),
+                                 (1, 2, 9, 12, 18, 24, True), (1, 1, 6, 6, 5, 4, True)])
 def test_upsample_bilinear_matches_torch(ops, cfg):
     """awseg_upsample_bilinear against F.interpolate (both corner conventions, non-multiple-of-4 widths, the full DeepLab size)."""
     B, C, h, w, H, W, align = cfg
@@ -1026,6 +1027,25 @@ def test_conv_gemm_split_equals_im2col_plus_gemm(ops, cfg):
     ref = torch.relu(torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=st, padding=pd))
     err = (got.permute(0, 3, 1, 2).double() - ref).abs().max().item()
     assert err < 1e-5 * max(1.0, ref.abs().max().item()), err
+
+
+def test_conv_gemm_split_dilated_and_large_operands(ops):
+    """The gathered-A convolution with dilation (atrous 3x3, stride 1) and with activations beyond the f16 range (the GEMM's
+    second, scaled pass re-gathers the tile): against torch's convolution in float64."""
+    g = torch.Generator(device="cuda").manual_seed(77)
+    B, H, W, C, Nn = 2, 33, 47, 64, 128
+    x = torch.randn(B, H, W, C, device="cuda", generator=g)
+    x[0, 5:9, 7:20] *= 1e5
+    wt = torch.randn(Nn, C, 3, 3, device="cuda", generator=g) * 0.05
+    bias = torch.randn(Nn, device="cuda", generator=g)
+    ws = ops.gemm_split_weights(wt.permute(0, 2, 3, 1).reshape(Nn, 9 * C).contiguous())
+    for dil in (2, 3):
+        got = ops.conv_gemm_split(x, ws, bias, 0, 3, 3, 1, dil, dil)
+        ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), wt.double(), bias.double(), stride=1, padding=dil, dilation=dil)
+        assert got.shape == (B, H, W, Nn)
+        rowmag = ref.abs().amax(dim=1).clamp_min(1.0)                                  # per pixel: rows differ by 1e5
+        err = ((got.permute(0, 3, 1, 2).double() - ref).abs().amax(dim=1) / rowmag).max().item()
+        assert torch.isfinite(got).all() and err < 1e-5, (dil, err)
 
 
 @pytest.mark.parametrize("shape", [(300, 256, 128), (38400, 256, 128), (4100, 320, 72), (131100, 256, 128)])

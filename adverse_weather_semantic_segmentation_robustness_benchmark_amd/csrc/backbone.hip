@@ -374,6 +374,9 @@ void dwconv3x3_upcat_lds_kernel(const float* __restrict__ a, int h, int w, int C
 // nn.MaxPool2d(3, stride 2, padding 1) on an NHWC float32 tensor (the ResNet stem; torch's max_pool2d_with_indices also writes
 // an int64 index per output — 537 MB per batch of 8 at 1024 x 2048 — that nobody reads).  A lane owns 2 adjacent output pixels
 // of one channel quad: 5 columns x 3 rows = 15 loads for 2 outputs.  Out-of-image taps do not take part (-inf padding).
+// max that PROPAGATES NaN like nn.MaxPool2d (fmaxf drops it): a NaN from the stem must reach the logits on this path as on torch's
+__device__ __forceinline__ float nanmax(float m, float v) { return (v > m || v != v) ? v : m; }
+
 __global__ __launch_bounds__(kThreads)
 void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, int64_t batch, int H, int W, int C, int Ho, int Wo, float* __restrict__ out)
 {
@@ -397,7 +400,7 @@ void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, int64_t batch, int H,
                 const int iy = oy * 2 - 1 + r;
                 if (ix >= 0 && ix < W && iy >= 0 && iy < H) {
                     const float4 v = *reinterpret_cast<const float4*>(xb + ((int64_t)iy * W + ix) * C);
-                    m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+                    m.x = nanmax(m.x, v.x); m.y = nanmax(m.y, v.y); m.z = nanmax(m.z, v.z); m.w = nanmax(m.w, v.w);
                 }
             }
             col[q] = m;
@@ -407,7 +410,7 @@ void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, int64_t batch, int H,
             const int ox = xp * 2 + o;
             if (ox >= Wo) break;
             const float4 a = col[2 * o], bq = col[2 * o + 1], c = col[2 * o + 2];
-            const float4 r = make_float4(fmaxf(fmaxf(a.x, bq.x), c.x), fmaxf(fmaxf(a.y, bq.y), c.y), fmaxf(fmaxf(a.z, bq.z), c.z), fmaxf(fmaxf(a.w, bq.w), c.w));
+            const float4 r = make_float4(nanmax(nanmax(a.x, bq.x), c.x), nanmax(nanmax(a.y, bq.y), c.y), nanmax(nanmax(a.z, bq.z), c.z), nanmax(nanmax(a.w, bq.w), c.w));
             *reinterpret_cast<float4*>(out + ((b * Ho + oy) * (int64_t)Wo + ox) * C + c4 * 4) = r;
         }
     }

@@ -351,7 +351,9 @@ void ece_kernel(const float* __restrict__ logits, int C, int64_t hw, const void*
         float m = x[p]; int bi = 0;
         for (int c = 1; c < C; ++c) { float v = x[(int64_t)c * hw + p]; if (v > m) { m = v; bi = c; } }
         float s = 0.f;
-        for (int c = 0; c < C; ++c) s += expf(x[(int64_t)c * hw + p] - m);
+        // the SAME exponential and summation order as ece19_kernel: which of the two kernels runs depends on hw % 4 and on the
+        // pointer's alignment, and a view of the same logits must land in the same bins
+        for (int c = 0; c < C; ++c) s += __expf(x[(int64_t)c * hw + p] - m);
         float conf = 1.0f / s;
         // bins are (lo, hi] on a float32 linspace (metrics.py:179-188); linear scan keeps the
         // reference's comparison semantics exactly.

@@ -39,8 +39,13 @@ class CityscapesKITTIDataset:
         self.weather_schedule = weather_schedule          # 'random' (loader.py:265) or 'round_robin' (bench)
         self.num_samples = num_samples if num_samples is not None else (100 if split == "train" else 20)
         self.seed = int(seed)
+        # The reference redraws pixels, the weather choice and every corruption parameter on each __getitem__
+        # (loader.py:206, 231, 265), so a training epoch never repeats.  Here every draw is a function of
+        # (seed, split, epoch, index): rank-independent, fresh per training epoch (the loader bumps `epoch` on every
+        # pass over a 'train' split), frozen for val / test so a validation curve compares like with like.
+        self.epoch = 0
         self.weather_transforms = WeatherDegradationTransforms(rng=rng, device=self.device)
-        self.weather_transforms._frame_seed = self.seed            # per-frame streams keyed by (seed, global index); no global reseed
+        self.weather_transforms._frame_seed = self._frame_seed()   # per-frame streams keyed by (seed, epoch, global index); no global reseed
         self.depth_preprocessor = DepthEstimationPreprocessor(self.device) if include_depth else None   # loader.py:68-69
         self._gen = torch.Generator(device=self.device)
         logger.info("Generated %d synthetic samples for testing", self.num_samples)
@@ -48,9 +53,20 @@ class CityscapesKITTIDataset:
     def __len__(self) -> int:
         return self.num_samples
 
+    def _epoch_term(self) -> int:
+        return int(self.epoch) if self.split == "train" else 0
+
+    def _frame_seed(self) -> int:
+        return (self.seed + 0x632BE5AB * self._epoch_term()) & 0x7FFFFFFF
+
+    def set_epoch(self, epoch: int) -> None:
+        """Select the draw stream of a training epoch (no effect on val / test splits)."""
+        self.epoch = int(epoch)
+        self.weather_transforms._frame_seed = self._frame_seed()
+
     def _sample_key(self, index: int) -> int:
         split_salt = {"train": 0, "val": 1, "test": 2}.get(self.split, 3)
-        return (self.seed * 1000003 + split_salt * 7919 + int(index) * 0x9E3779B1) & 0x7FFFFFFFFFFFFFFF
+        return (self.seed * 1000003 + split_salt * 7919 + self._epoch_term() * 0x2545F491 + int(index) * 0x9E3779B1) & 0x7FFFFFFFFFFFFFFF
 
     def synth_raw(self, start: int, n: int):
         """uint8 frames / labels generated on device (shapes and ranges of loader.py:206, 231).  Sample i
@@ -163,9 +179,21 @@ class WeatherAugmentationPipeline:
 class _Loader:
     def __init__(self, dataset, batch_size, drop_last, rank, world_size):
         self.dataset, self.batch_size, self.drop_last, self.rank, self.world_size = dataset, batch_size, drop_last, rank, world_size
+        self._passes = 0
 
     def __iter__(self):
-        return self.dataset.batches(self.batch_size, self.drop_last, self.rank, self.world_size)
+        it = self.dataset.batches(self.batch_size, self.drop_last, self.rank, self.world_size)
+        if hasattr(self.dataset, "set_epoch"):
+            # generators run lazily: fix this pass's epoch now, hand the NEXT pass the next one (every rank iterates its
+            # loader once per epoch, so the counters agree across ranks without communication)
+            first = self._passes
+            self._passes += 1
+
+            def run():
+                self.dataset.set_epoch(first)
+                yield from it
+            return run()
+        return it
 
     def __len__(self):
         per = (len(self.dataset) + self.world_size - 1) // self.world_size

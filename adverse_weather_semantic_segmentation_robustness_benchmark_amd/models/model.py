@@ -210,22 +210,26 @@ class SegFormerModel(nn.Module):
     def heads_forward(self, feats: torch.Tensor, H: int, W: int) -> Dict[str, torch.Tensor]:
         """The two heads on the encoder output [B,C,h,w] in the module's current mode, with autograd (model.py:209-221)."""
         hh, ww = feats.shape[2], feats.shape[3]
-        if (feats.is_cuda and getattr(self, "fused_train", True) and
-                ops.upconv3x3_train_supported(self.feature_dim, 256, hh, ww, H, W)):
-            # on the GPU: the first convolution of each head — conv3x3(interpolate(f)), model.py:209-214 / :219-221 — as one small
-            # GEMM at the encoder's resolution + a HIP kernel, forward and backward (ops._UpConv3x3); BatchNorm (batch
-            # statistics in training), ReLU, Dropout2d and the remaining layers are the reference's modules on the result
-            tok = feats.permute(0, 2, 3, 1)
-            head = self.segmentation_head
-            results = {"segmentation": head[1:](ops.upconv3x3_train(tok, head[0].weight, head[0].bias, H, W))}
-            if self.include_depth:
-                dh = self.depth_head.depth_head
-                results["depth"] = dh[1:](ops.upconv3x3_train(tok, dh[0].weight, dh[0].bias, H, W))
-            return results
-        up = F.interpolate(feats, size=(H, W), mode="bilinear", align_corners=False)     # model.py:211
-        results = {"segmentation": self.segmentation_head(up)}
-        if self.include_depth:
-            results["depth"] = self.depth_head(up)
+        on_hip = feats.is_cuda and getattr(self, "fused_train", True)
+
+        def hip_ok(conv: nn.Conv2d) -> bool:
+            # each head is checked with ITS OWN first convolution (a depth head built with other hidden_channels falls back alone)
+            return (on_hip and conv.kernel_size == (3, 3) and conv.padding == (1, 1) and conv.stride == (1, 1) and
+                    ops.upconv3x3_train_supported(conv.in_channels, conv.out_channels, hh, ww, H, W))
+
+        # on the GPU: the first convolution of each head — conv3x3(interpolate(f)), model.py:209-214 / :219-221 — as one small
+        # GEMM at the encoder's resolution + a HIP kernel, forward and backward (ops._UpConv3x3); BatchNorm (batch
+        # statistics in training), ReLU, Dropout2d and the remaining layers are the reference's modules on the result
+        head = self.segmentation_head
+        dh = self.depth_head.depth_head if self.include_depth else None
+        seg_hip, dep_hip = hip_ok(head[0]), dh is not None and hip_ok(dh[0])
+        tok = feats.permute(0, 2, 3, 1) if (seg_hip or dep_hip) else None
+        up = None
+        if not seg_hip or (dh is not None and not dep_hip):
+            up = F.interpolate(feats, size=(H, W), mode="bilinear", align_corners=False)     # model.py:211
+        results = {"segmentation": head[1:](ops.upconv3x3_train(tok, head[0].weight, head[0].bias, H, W)) if seg_hip else head(up)}
+        if dh is not None:
+            results["depth"] = dh[1:](ops.upconv3x3_train(tok, dh[0].weight, dh[0].bias, H, W)) if dep_hip else self.depth_head(up)
         return results
 
     @torch.no_grad()

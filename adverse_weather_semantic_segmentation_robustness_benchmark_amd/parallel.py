@@ -95,8 +95,8 @@ class GradientBuckets:
     is packed or scattered.  A post-accumulate-grad hook per parameter counts its bucket down; the bucket
     whose last gradient has just landed is all-reduced asynchronously (RCCL's own stream) while backward
     continues with earlier layers.  `finish()` launches whatever has not fired (parameters that took no part
-    in this step keep zero gradients, so message sizes never depend on a rank's control flow), waits, and
-    scales by 1/world.  With ~36 M fp32 parameters (144 MB) and 7 x 153 GB/s xGMI links, 25-50 MB buckets
+    in this step contribute zeros, so message sizes never depend on a rank's control flow), waits, scales by
+    1/world, and detaches (.grad = None) the parameters no rank produced a gradient for.  With ~36 M fp32 parameters (144 MB) and 7 x 153 GB/s xGMI links, 25-50 MB buckets
     keep every link busy without serialising behind one giant message."""
 
     def __init__(self, params: List[torch.nn.Parameter], bucket_mb: float = 32.0) -> None:
@@ -128,6 +128,12 @@ class GradientBuckets:
         self._next = 0
         self._work = [None] * len(groups)
         self._armed = False
+        self._fired = set()
+        # host-side control messages (which parameters received a gradient on ANY rank) travel over gloo: a CPU tensor, so
+        # reading the answer does not synchronise the GPU stream.  Created here — every rank constructs its buckets once.
+        self._ctl = None
+        if is_dist() and dist.get_backend() != "gloo":
+            self._ctl = dist.new_group(backend="gloo")
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
 
     def zero_grad(self) -> None:
@@ -139,6 +145,7 @@ class GradientBuckets:
         self._pending = [len(g) for g in self.buckets]
         self._work = [None] * len(self.buckets)
         self._next = 0
+        self._fired = set()
         self._armed = True
 
     def _launch(self, bi: int) -> None:
@@ -150,6 +157,7 @@ class GradientBuckets:
             return
         bi = self._bucket_of[id(p)]
         view = self._view[id(p)]
+        self._fired.add(id(p))
         if p.grad is not None and p.grad.data_ptr() != view.data_ptr():
             # autograd replaced the view instead of accumulating into it: copy the gradient back into the bucket
             view.copy_(p.grad)
@@ -173,6 +181,15 @@ class GradientBuckets:
         for bi, work in enumerate(self._work):
             work.wait()
             self.flat[bi].div_(world)
+        # A parameter NO rank produced a gradient for (a depth head on batches without depth targets, `ensemble_weights`
+        # under the mean strategy) gets .grad = None, exactly what the single-process path's optimizer.zero_grad() leaves:
+        # the optimizer then skips it (no weight decay, no moment update) on 1 and on N GPUs alike.  A parameter that fired
+        # on SOME rank keeps its averaged gradient everywhere.
+        fired = torch.tensor([1 if id(p) in self._fired else 0 for p in self.params], dtype=torch.int32)
+        dist.all_reduce(fired, op=dist.ReduceOp.MAX, group=self._ctl)
+        for p, f in zip(self.params, fired.tolist()):
+            if not f:
+                p.grad = None
 
     def all_reduce_(self) -> None:
         """Non-overlapped form for callers that ran backward without zero_grad(): gather whatever .grad holds (zeros
@@ -180,6 +197,7 @@ class GradientBuckets:
         if not is_dist():
             return
         if not self._armed:
+            self._fired = {id(p) for p, _ in self._views if p.grad is not None}
             for p, view in self._views:
                 if p.grad is None:
                     view.zero_()

@@ -205,6 +205,34 @@ def test_training_mode_graph_matches_reference_contract():
     assert m.ensemble_weights.grad is not None and m.temperature.grad is not None
 
 
+def test_training_epochs_redraw_their_samples_and_validation_does_not():
+    """the reference redraws pixels, the weather choice and every corruption parameter on each __getitem__
+    (PKG/data/loader.py:206, 231, 265); here the draws are keyed by (seed, split, EPOCH, index) — fresh per training
+    epoch, rank-independent, frozen for val / test.  Host-side keys only (no GPU)."""
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.data.loader import CityscapesKITTIDataset, _Loader
+    tr = CityscapesKITTIDataset(split="train", image_size=(8, 8), num_samples=40, device="cpu", include_depth=False)
+    va = CityscapesKITTIDataset(split="val", image_size=(8, 8), num_samples=40, device="cpu", include_depth=False)
+    k0, c0, f0 = [tr._sample_key(i) for i in range(40)], tr.choose_conditions(0, 40), tr.weather_transforms._frame_seed
+    tr.set_epoch(1)
+    k1, c1, f1 = [tr._sample_key(i) for i in range(40)], tr.choose_conditions(0, 40), tr.weather_transforms._frame_seed
+    assert not set(k0) & set(k1) and c0 != c1 and f0 != f1
+    a, _ = tr.synth_raw(0, 2)
+    tr.set_epoch(0)
+    b, _ = tr.synth_raw(0, 2)
+    assert not torch.equal(a, b) and [tr._sample_key(i) for i in range(40)] == k0          # a pure function of the epoch
+    v0 = [va._sample_key(i) for i in range(40)]
+    va.set_epoch(3)
+    assert [va._sample_key(i) for i in range(40)] == v0 and va.weather_transforms._frame_seed == va.seed
+    # the loader advances the epoch once per pass, identically on every rank
+
+    class Probe(CityscapesKITTIDataset):
+        def make_batch(self, start, n, raw=None):
+            return (self.epoch, start, n)
+    ds = Probe(split="train", image_size=(8, 8), num_samples=6, device="cpu", include_depth=False)
+    ld = _Loader(ds, 2, False, 0, 1)
+    assert [list(ld), list(ld)] == [[(0, 0, 2), (0, 2, 2), (0, 4, 2)], [(1, 0, 2), (1, 2, 2), (1, 4, 2)]]
+
+
 def test_shard_range_covers_everything():
     from adverse_weather_semantic_segmentation_robustness_benchmark_amd.parallel import shard_range
     for n in (0, 1, 7, 20, 160):
@@ -254,6 +282,7 @@ class Net(torch.nn.Module):
     def __init__(self):
         super().__init__()
         self.a = torch.nn.Linear(8, 16); self.b = torch.nn.Linear(16, 4); self.unused = torch.nn.Linear(8, 3)
+        self.dead = torch.nn.Linear(8, 3)                        # takes part in NO rank's graph
         self.bn = torch.nn.BatchNorm1d(4)
     def forward(self, x, use_extra):
         y = self.bn(self.b(torch.relu(self.a(x))))
@@ -278,7 +307,19 @@ net2(x, use_extra=(rank == 0)).backward()
 for (n1, p1), (n2, p2) in zip(net.named_parameters(), net2.named_parameters()):
     g = p2.grad.clone() if p2.grad is not None else torch.zeros_like(p2)
     dist.all_reduce(g); g /= world
-    assert torch.allclose(p1.grad, g, atol=1e-6), n1
+    if n1.startswith("dead."):
+        # no rank produced a gradient: .grad is None, as after the single-process optimizer.zero_grad() — the optimizer
+        # skips the parameter (no weight decay / moment update) at any GPU count
+        assert p1.grad is None, n1
+        continue
+    assert p1.grad is not None and torch.allclose(p1.grad, g, atol=1e-6), n1   # `unused`: fired on rank 0 only, averaged everywhere
+dead_before = [p.clone() for p in net.dead.parameters()]
+torch.optim.AdamW(net.parameters(), lr=0.1, weight_decay=0.5).step()          # would shrink `dead` if it carried a zero gradient
+assert all(torch.equal(a, b) for a, b in zip(dead_before, net.dead.parameters()))
+buckets.zero_grad()                                             # the next step re-attaches every view, `dead` included
+assert all(p.grad is not None for p in net.parameters())
+net(x, use_extra=(rank == 0)).backward()
+buckets.finish()
 opt.step()
 after = [None] * world
 dist.all_gather_object(after, [p.detach().tolist() for p in net.parameters()])

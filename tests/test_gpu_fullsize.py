@@ -184,8 +184,9 @@ def test_c1_config_deeplab_fog_only_end_to_end(ops, oracle):
                                            counts=counts, oob=oob)
     with torch.no_grad():
         ref_logits = cpu_model(torch.from_numpy(cpu_in))["segmentation"].numpy()
-    scale = max(1.0, np.abs(ref_logits).max())
-    assert np.abs(logits.cpu().numpy() - ref_logits).max() < 2e-4 * scale   # fp32 conv stacks, different summation order
+    err, mag = np.abs(logits.cpu().numpy() - ref_logits).max(), np.abs(ref_logits).max()
+    print(f"C1 DeepLabV3+ 256x512 logits vs as-written CPU graph: max abs err {err:.3e} at logit magnitude {mag:.3g}")
+    assert err < 1e-4                                                       # north_star: 1e-4 ABSOLUTE on fp32 logits
     ref_pred = oracle.argmax(ref_logits)
     agree = (pred.cpu().numpy() == ref_pred).mean()
     assert agree > 0.999                                                    # label flips only on near-ties
@@ -219,7 +220,8 @@ def test_fullsize_depth_estimate(ops):
 def test_fullsize_ensemble_fused_vs_module_graph():
     """One 1024x2048 frame through the eval executors (Winograd / own attention / fused GEMM epilogues at their real
     shapes: 2048 keys, 2048->256 and full-resolution 128->64 convolutions) against the SAME weights run through the
-    reference's op graph on torch-ROCm (MIOpen, SDPA): 1e-4 on the logits (relative to their magnitude), 1e-4 on depth."""
+    reference's op graph on torch-ROCm (MIOpen, SDPA): 1e-4 ABSOLUTE on the logits and on depth (calibrated BatchNorm keeps
+    the logits O(1)); the absolute error and the reference magnitude are printed."""
     import adverse_weather_semantic_segmentation_robustness_benchmark_amd as P
     torch.manual_seed(11)
     m = P.EnsembleModel(num_classes=C, include_depth=True, pretrained=False).cuda().eval()
@@ -235,11 +237,10 @@ def test_fullsize_ensemble_fused_vs_module_graph():
         for sub in (m, m.segformer, m.deeplabv3plus):
             sub.fused_eval = False
         ref = m(x)
-    for key in ("segformer_seg", "deeplabv3plus_seg", "segmentation"):
-        scale = max(1.0, ref[key].abs().max().item())
-        assert (fused[key] - ref[key]).abs().max().item() / scale < 1e-4, key
-    for key in ("segformer_depth", "deeplabv3plus_depth", "depth"):
-        assert (fused[key] - ref[key]).abs().max().item() < 1e-4, key
+    for key in ("segformer_seg", "deeplabv3plus_seg", "segmentation", "segformer_depth", "deeplabv3plus_depth", "depth"):
+        err, mag = (fused[key] - ref[key]).abs().max().item(), ref[key].abs().max().item()
+        print(f"full-size 1024x2048 {key}: max abs err {err:.3e} at reference magnitude {mag:.3g}")
+        assert err < 1e-4, key                                              # north_star: 1e-4 ABSOLUTE on fp32 logits / depth
 
 
 

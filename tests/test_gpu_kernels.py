@@ -3,6 +3,8 @@ and against the golden vectors the reference produced.  Integer / byte outputs a
 bit-exactly; float32 outputs within the tolerance stated at each assert."""
 import numpy as np
 import pytest
+
+from tests.conftest import maxconf_flips_are_rounding_ties
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -87,7 +89,7 @@ def test_combine_golden(ops, golden_model):
                                                  t if ts else None, want_pred=True)
         ref = g[f"combine{n}"]
         if mode == 1:
-            assert (out.cpu().numpy() != ref).any(axis=1).mean() < 1e-3      # near-tie selections only
+            maxconf_flips_are_rounding_ties(out.cpu().numpy(), ref, g["seg1"], g["seg2"])   # stated tolerance: exact except float32 rounding ties of the two confidences
         else:
             assert np.array_equal(out.cpu().numpy(), ref)                   # bit-exact float32
             assert np.array_equal(pred.cpu().numpy(), ref.argmax(axis=1))
@@ -132,6 +134,29 @@ def test_ece_bins(ops, oracle, golden_metrics):
     # bin membership can differ from the oracle only where expf differs in the last ulp at an edge
     assert np.abs(got["count"] - cnt).sum() <= 2
     assert abs(oracle.ece_from_bins(got["count"], got["sum_conf"], got["sum_correct"]) - float(g["ece"])) < 1e-5
+
+
+def test_ece_bins_do_not_depend_on_pointer_alignment(ops):
+    """awseg_ece_accumulate picks the 4-pixels-per-lane kernel or the scalar one from hw % 4 and the pointer's
+    16-byte alignment; both use the same exponential and summation order, so the same logits land in the same bins
+    whether they are passed aligned or as an offset view (label / logits shifted by one element)."""
+    g = torch.Generator(device="cuda").manual_seed(12)
+    B, C_, hw = 3, 19, 64 * 100
+    base = torch.randn(B * C_ * hw + 1, device="cuda", generator=g) * 3
+    lab = torch.randint(0, C_, (B, hw), device="cuda", generator=g).to(torch.uint8)
+    lab[:, ::53] = 255
+    edges = torch.linspace(0, 1, 16).cuda()
+    aligned = base[:B * C_ * hw].clone().view(B, C_, hw)
+    shifted = base[1:]                                                  # 4-byte offset: the scalar kernel
+    shifted.copy_(aligned.view(-1))
+    a, b = ops.new_ece_bins(15, "cuda"), ops.new_ece_bins(15, "cuda")
+    ops.ece_accumulate(aligned, lab, a, edges)
+    N_ = ops.N
+    ws = N_.workspace.get(aligned.device, N_.lib().awseg_metrics_workspace(B, C_, hw))
+    assert shifted.data_ptr() % 16 != 0
+    N_.call("awseg_ece_accumulate", shifted.data_ptr(), B, C_, hw, N_.ptr(lab), N_.label_dtype(lab), None, N_.ptr(edges), 15, N_.ptr(b), 1,
+            N_.ptr(ws), N_.stream())
+    assert torch.equal(a, b) and int(a[0, :, 0].sum()) == int((lab != 255).sum())
 
 
 # ------------------------------------------------------------------ normalise / weather
@@ -872,6 +897,11 @@ def test_maxpool3x3s2_nhwc_equals_torch(ops, shape):
     x = torch.randn(B, H, W, C, device="cuda", generator=g)
     ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(ops.maxpool3x3s2_nhwc(x), ref)
+    # NaN propagates as in nn.MaxPool2d (fmaxf dropped it): NaNs in a window's first, middle and last taps
+    x[0, 0, 0, 0] = float("nan"); x[-1, H // 2, W // 2, C - 1] = float("nan"); x[0, H - 1, W - 1, 1] = float("nan")
+    ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    got = ops.maxpool3x3s2_nhwc(x)
+    assert ref.isnan().sum().item() >= 3 and torch.equal(got.isnan(), ref.isnan()) and torch.equal(got.nan_to_num(0.0), ref.nan_to_num(0.0))
 
 
 @pytest.mark.parametrize("cfg", [(2, 19, 16, 32, 64, 128, True), (1, 3, 7, 5, 28, 20, True), (2, 1, 4, 8, 64, 128, False),

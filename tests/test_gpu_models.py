@@ -5,6 +5,8 @@ import copy
 
 import numpy as np
 import pytest
+
+from tests.conftest import maxconf_flips_are_rounding_ties
 import torch
 
 pytestmark = pytest.mark.gpu
@@ -64,9 +66,9 @@ def test_segformer_model_hip_vs_as_written(P):
     ref = as_written_cpu(m, x)
     assert set(out) == {"segmentation", "depth"}
     assert out["segmentation"].shape == (2, 19, 128, 192) and out["depth"].shape == (2, 1, 128, 192)
-    # north_star: 1e-4 abs on fp32 logits (scaled by the logit magnitude when it exceeds 1)
-    assert rel_err(out["segmentation"].cpu(), ref["segmentation"]) < 1e-4
-    assert (out["depth"].cpu() - ref["depth"]).abs().max().item() < 1e-4
+    # north_star: 1e-4 ABSOLUTE on fp32 logits (calibrated BatchNorm keeps them O(1)); absolute error and magnitude printed
+    assert abs_err(out["segmentation"].cpu(), ref["segmentation"], "segformer 128x192 logits vs as-written CPU graph") < 1e-4
+    assert abs_err(out["depth"].cpu(), ref["depth"], "segformer 128x192 depth") < 1e-4
 
 
 @pytest.mark.parametrize("split", [False, True])
@@ -81,9 +83,8 @@ def test_segformer_model_hip_vs_as_written_own_attention_path(P, split, monkeypa
     x = torch.randn(1, 3, 256, 256, device="cuda")
     out = m(x)
     ref = as_written_cpu(m, x)
-    print(f"segformer 256x256 split={split}: logits rel err {rel_err(out['segmentation'].cpu(), ref['segmentation']):.3e}")
-    assert rel_err(out["segmentation"].cpu(), ref["segmentation"]) < 1e-4
-    assert (out["depth"].cpu() - ref["depth"]).abs().max().item() < 1e-4
+    assert abs_err(out["segmentation"].cpu(), ref["segmentation"], f"segformer 256x256 split={split} logits vs as-written CPU graph") < 1e-4
+    assert abs_err(out["depth"].cpu(), ref["depth"], f"segformer 256x256 split={split} depth") < 1e-4
 
 
 def test_deeplab_model_hip_vs_as_written(P):
@@ -106,7 +107,7 @@ def test_aspp_fused_vs_module(P):
     with torch.no_grad():
         ref = dec.aspp[0](x)
         got = dec.aspp_fused(x)
-    assert rel_err(got, ref) < 1e-4
+    assert abs_err(got, ref, "fused ASPP vs module graph") < 1e-4
 
 
 @pytest.mark.parametrize("strategy", ["weighted_average", "max_confidence", "mean"])
@@ -124,7 +125,7 @@ def test_ensemble_forward_eval_contract(P, oracle, strategy):
     ref = oracle.combine(s1, s2, mode, float(w[0]), float(w[1]), 1.5)
     got = out["segmentation"].cpu().numpy()
     if mode == 1:
-        assert (got != ref).any(axis=1).mean() < 1e-3
+        maxconf_flips_are_rounding_ties(got, ref, s1, s2)          # exact except float32 rounding ties of the two confidences
     else:
         assert np.array_equal(got, ref)                                                # bit-exact given the member logits
     labels = torch.randint(0, 19, (2, 64, 128), dtype=torch.uint8, device="cuda")

@@ -2,6 +2,8 @@
 (tests/golden/make_golden.py).  This is what pins the oracle."""
 import numpy as np
 import pytest
+
+from tests.conftest import maxconf_flips_are_rounding_ties
 import torch
 
 
@@ -101,8 +103,8 @@ def test_combine(oracle, golden_model):
         mode, ts = [int(v) for v in g[f"combine_cfg{n}"]]
         out = oracle.combine(g["seg1"], g["seg2"], mode, w0, w1, float(g["ens_t"]) if ts else None)
         if mode == 1:
-            # selection may flip only on a numerical near-tie of the two confidences
-            assert (out != g[f"combine{n}"]).any(axis=1).mean() < 1e-3
+            # selection may differ only where the two confidences are a float32 rounding tie (stated tolerance: conftest)
+            maxconf_flips_are_rounding_ties(out, g[f"combine{n}"], g["seg1"], g["seg2"])
         else:
             assert np.array_equal(out, g[f"combine{n}"])              # 4 float32 roundings, bit-exact
 

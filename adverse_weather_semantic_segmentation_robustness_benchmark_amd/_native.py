@@ -47,6 +47,7 @@ SIGNATURES = {
     "awseg_gemm_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p, C.c_size_t, c_p]),
     "awseg_gemm_tune": (c_i, [c_p, c_p, c_p, c_i, c_i, c_p, c_i64, c_i, c_i, c_p, C.c_size_t, c_p]),
     "awseg_gemm_split_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    "awseg_gemm_split_weight_halfs": (c_i64, [c_i, c_i]),
     "awseg_gemm_split_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
     "awseg_gemm_bf16_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
     "awseg_gemm_bf16_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),

@@ -96,3 +96,9 @@ __device__ __forceinline__ void awseg_box_muller16(uint32_t a, float& n0, float&
     n1 = r * __builtin_amdgcn_sinf(u2);
 }
 __device__ __forceinline__ float awseg_u01(uint32_t a) { return (float)(a >> 8) * (1.0f / 16777216.0f); }
+
+// gemm_split3.hip (the LDS-DMA split-operand GEMM for N % 256 == 0, K % 32 == 0), called from gemm_split.hip
+int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const unsigned* trailer, hipStream_t stream);
+bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const void* out, const void* residual, const void* bias);
+int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned* trailer, const float* bias, const float* residual,
+                             int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv = nullptr);

@@ -485,11 +485,20 @@ AWSEG_API int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w
     AWSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(SWT), 0, awseg_s(stream), w, ne, w_split, trailer);
     AWSEG_LAUNCH_CHECK();
+    // K % 32 == 0: the k-blocked image of gemm_split3.hip behind the trailer (awseg_gemm_split_weight_halfs says how much room)
+    if (k % 32 == 0) return awseg_gemm_split3_weights(w, n, k, w_split + 2 * ne + 8, trailer, awseg_s(stream));
     return 0;
 }
 
+AWSEG_API int64_t awseg_gemm_split_weight_halfs(int n, int k)
+{
+    if (n < 1 || k < 1) return -1;
+    const int64_t ne = (int64_t)n * k;
+    return 2 * ne + 8 + (k % 32 == 0 ? 2 * ne : 0);
+}
+
 namespace {
-struct conv_desc { int H, W, C, Ho, Wo, kw, stride, pad, dil; };
+struct conv_desc { int H, W, C, Ho, Wo, kw, stride, pad, dil; int64_t batch; };
 
 int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float* bias, const float* residual,
                 int act, float* out, int64_t m, int n, int k, awseg_stream_t stream, const conv_desc* cv = nullptr)
@@ -510,6 +519,16 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
         int dev = 0, n_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
         cus = n_cu;
+    }
+    static int v3_on = -1;                                       // AWSEG_GEMM_SPLIT_V3=0: keep the register-staged kernels of round 2 (A/B measurements)
+    if (v3_on < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_V3"); v3_on = e ? atoi(e) : 1; }
+    if (v3_on && !bf16 && awseg_gemm_split3_eligible(m, n, k, cv ? nullptr : x, out, residual, bias) &&
+        (!cv || (cv->C % 32 == 0 && (int64_t)cv->batch * cv->H * cv->W * cv->C * 4 <= 0x7fffffff)) &&
+        ((m + 255) / 256) * (int64_t)(n / 256) >= (int64_t)cus / 2) {
+        const int cdesc[10] = { cv ? cv->H : 0, cv ? cv->W : 0, cv ? cv->C : 0, cv ? cv->Ho : 0, cv ? cv->Wo : 0, cv ? cv->kw : 0,
+                                cv ? cv->stride : 0, cv ? cv->pad : 0, cv ? cv->dil : 0, cv ? (int)cv->batch : 0 };
+        return awseg_gemm_split3_launch(x, w_split + 2 * (int64_t)n * k + 8, a.trailer, bias, residual, act, out, m, n, k, cus, awseg_s(stream),
+                                        cv ? cdesc : nullptr);
     }
     static int tile_mode = -1;                                   // AWSEG_GEMM_SPLIT_TILE = 128 / 256 / 512 forces the block tile (measurements; 512 = 256 x 256)
     if (tile_mode < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_TILE"); tile_mode = !e ? 0 : (atoi(e) == 512 ? 3 : (atoi(e) == 256 ? 2 : (atoi(e) == 128 ? 1 : 0))); }
@@ -596,7 +615,7 @@ AWSEG_API int awseg_conv_gemm_split_bias_act(const float* x, int64_t batch, int 
     if (ho < 1 || wo < 1) return AWSEG_ERANGE;
     const int64_t k = (int64_t)kernel_h * kernel_w * channels;
     if (k > 0x7fffffff || batch * height > 0x7fffffff) return AWSEG_ERANGE;
-    const conv_desc cv = { height, width, channels, ho, wo, kernel_w, stride, pad, dilation };
+    const conv_desc cv = { height, width, channels, ho, wo, kernel_w, stride, pad, dilation, batch };
     return gemm_launch(false, x, w_split, bias, residual, act, out, batch * ho * wo, n, (int)k, stream, &cv);
 }
 

@@ -1,0 +1,391 @@
+// gemm_split3.hip — the operator of gemm_split.hip (out[M,N] = act(x[M,K] . w[N,K]^T + bias (+ residual)), float32 grade on
+// the f16 matrix cores with split operands; the 1x1 convolutions behind PKG/models/model.py:349 and the MiT Linear layers
+// behind :193-197) rebuilt around the LDS-DMA pipeline of cdna_hip_programming.md §5 for the shapes that fill 256-wide tiles
+// (N % 256 == 0, K % 32 == 0).  Round 2's kernel staged both operands through registers (global load -> split -> ds_write)
+// with every wave of the block in the same phase: cycle stamps put a third of a K tile into the barrier and a third into
+// staging, with the matrix pipe idle in both.  Here NO operand passes through a staging phase:
+//   * x (raw float32) and the weights (a k-blocked image [N][K/32][32 hi | 32 lo] f16, unscaled low parts, written once by
+//     awseg_gemm_split_weights) go global -> LDS by `buffer_load_dwordx4 ... lds`, one K tile (32 deep: 128-byte rows of both
+//     operands) ahead, two stages of 64 KB; 16-byte chunks XOR-swizzled on the SOURCE address (chunk ^ ((row >> 1) & 7)), so
+//     the linear LDS-DMA image is conflict-free for ds_read_b128 fragment reads;
+//   * ONE barrier per K tile; a wave's only vector work in the loop is splitting the activation fragment it has just read
+//     (4 v_fma_mix per pair: hi = f16(x s), lo = f16(x s - hi); s = 2^4 as in gemm_split.hip's single-accumulator form) and
+//     the running max|x| of the range guard;
+//   * block = 256 x 256, 8 waves as 8 x 1: a wave owns 32 ROWS x all 256 columns (1 x 8 MFMA tiles, ONE accumulator each:
+//     128 registers), so every activation fragment is split by exactly one wave — 20 vector instructions beside 24 MFMAs
+//     per 16-deep step.  (The first build had 2 x 4 waves of 128 x 64: each activation fragment was split by the four waves
+//     that share its rows, 80 vector instructions per 24 MFMAs, and the ablation build without the split ran 25 % faster:
+//     v_fma_mix does not hide behind MFMAs at that density.)  The weight fragments — no vector work — are what the waves
+//     share: 36 ds_read_b128 per wave and K tile, 37 % of the LDS read rate at the MFMA-bound pace;
+//   * the product is computed TRANSPOSED (weights as the MFMA's row operand): a lane owns one output ROW and its registers
+//     4 consecutive COLUMNS, so the epilogue moves 16 bytes per lane and instruction (bias / residual / ReLU / rescale as
+//     before; raw-buffer accesses, rows past M dropped by the hardware range check) — a quarter of the store instructions;
+//   * persistent blocks, XCD-aware tile walk, the next tile's first K tile in flight during the epilogue (as before).
+// Operand range: as gemm_split.hip — weights normalised when they are split, activations split optimistically (x 2^4) while
+// the block tracks max|x|; a tile that met |x| >= 2^11 is recomputed with x 2^-e and rescaled in the epilogue.
+#include "awseg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int G3T = 512;                   // 8 waves
+constexpr int G3M = 256, G3N = 256, G3K = 32;
+constexpr int G3_STAGE = 32768;            // bytes of one operand's stage: 256 rows x 128 B
+constexpr int G3_A0 = 0, G3_B0 = 2 * G3_STAGE;                    // A stage s at s * 32768, B stage s at 65536 + s * 32768
+constexpr int G3_LDS = 4 * G3_STAGE + 64;                         // + sMax[2]
+constexpr float kActScale0 = 16.0f;        // optimistic-pass activation scale (gemm_split.hip: split_pair_unscaled)
+constexpr int kActExp0 = -4;
+constexpr float kSplitLimit3 = 2048.0f;    // |x| below this splits without loss at scale 2^4 (|x s| < 2^15)
+
+__device__ __forceinline__ float pow2f3(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
+
+__device__ __forceinline__ uint32_t lds_addr3(const void* p)
+{
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p;
+}
+// 16 bytes per lane global -> LDS through a buffer descriptor: LDS address = m0 + 16 * lane (wave-uniform base), the
+// source address per lane (vector offset; out-of-range lanes read zeros) + a scalar offset
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "m0", "memory");
+}
+
+// two float32 -> packed f16 high parts and packed f16 low parts of (a s, b s): hi = f16(x s) (round to nearest), lo = f16(x s - hi)
+// (exact in float32, then exactly representable while normal).  Four mixed-precision FMAs, no packed-float32 instruction
+// (those cost extra beside MFMAs: MI355X_MICROARCH.md cycle constants).
+__device__ __forceinline__ void split2(float a, float b, float s, unsigned& hi, unsigned& lo)
+{
+    asm("v_fma_mixlo_f16 %0, %2, %4, 0\n\t"
+        "v_fma_mixhi_f16 %0, %3, %4, 0\n\t"
+        "v_fma_mixlo_f16 %1, %2, %4, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, %4, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"          // a vector write needs two wait states before an MFMA reads the register as an operand; hipcc pads only its own instructions
+        : "=&v"(hi), "=&v"(lo) : "v"(a), "v"(b), "s"(s));
+}
+
+struct g3_args {
+    const float* x; const uint16_t* w3; const float* bias; const float* residual; float* out;
+    const unsigned* trailer;               // {max|w| bits, weight exponent ew, 0, 0}
+    int64_t M; int N, K, act, ntm, ntm8, ntn;
+    // CONV: x is an NHWC image batch [B, cH, cW, cC] (cC % 32 == 0: a K tile lies inside one tap) and row m = (b, oy, ox) of the
+    // A operand is gathered from it by the LDS-DMA's per-lane source address — column k = (ky * ckw + kx) * cC + c is
+    // x[b, oy * cs - cp + ky * cd, ox * cs - cp + kx * cd, c], zero outside (awseg_conv_gemm_split_bias_act)
+    int cH, cW, cC, cHo, cWo, ckw, cs, cp, cd;
+    int64_t x_bytes;
+};
+
+// ABL != 0: ablation builds for measurements (wrong results, valid times; AWSEG_G3_ABL): 1 no LDS-DMA in the K loop, 2 no MFMAs,
+// 3 no operand split, 4 no activation fragment reads
+template <bool CONV, int ABL = 0>
+__global__ __launch_bounds__(G3T, 2)
+void gemm_split3_kernel(g3_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned* sMax = reinterpret_cast<unsigned*>(smem + 4 * G3_STAGE);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int K = a.K, nkt = K / G3K, kb = K / G3K;
+    const int ntiles = a.ntm8 * a.ntn;
+
+    auto tile_of = [&](int slot, int64_t& m0, int& n0) -> bool {   // gemm_split.hip: XCD-aware persistent walk
+        const int xcd = slot & 7, jj = slot >> 3;
+        const int nt_i = jj % a.ntn, mt_i = (jj / a.ntn) * 8 + xcd;
+        m0 = (int64_t)mt_i * G3M; n0 = nt_i * G3N;
+        return mt_i < a.ntm;
+    };
+
+    // ---- LDS-DMA roles.  One instruction covers 8 rows x 128 B (1 KB, linear in LDS); wave w fills row groups 4w .. 4w+3 of
+    // each operand's 256-row stage.  Lane l -> row 8 q + (l >> 3), slot l & 7, which holds source chunk slot ^ ((row >> 1) & 7).
+    const int rl = lane >> 3, sl = lane & 7;
+    uint32_t a_voff[4], b_voff[4];
+    int cby[4], cy0[4], cx0[4];                                    // CONV: image row base b * cH, first tap's input row / column of this lane's A rows (< 0: row past M)
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr3(smem));
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar register: the LDS-DMA base goes through m0
+    __amdgpu_buffer_rsrc_t x_rsrc, w_rsrc;
+    auto point = [&](int64_t m0, int n0) {
+        const int64_t rows_left = a.M - m0;                      // rows past M: out-of-range source -> zeros, never stored
+        const int64_t xbytes = rows_left * (int64_t)K * 4;
+        if (CONV) x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
+        else x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * K), 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * K * 2), 0, G3N * K * 4, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = 8 * (4 * wave + j) + rl;
+            const int c = sl ^ ((row >> 1) & 7);
+            a_voff[j] = (uint32_t)(row * K * 4 + c * 16);
+            b_voff[j] = (uint32_t)(row * kb * 128 + c * 16);
+            if (CONV) {
+                a_voff[j] = (uint32_t)(c * 16);
+                const int64_t m = m0 + row;
+                const int b = (int)(m / ((int64_t)a.cHo * a.cWo));
+                const int rem = (int)(m - (int64_t)b * a.cHo * a.cWo);
+                const int oy = rem / a.cWo, ox = rem - oy * a.cWo;
+                cby[j] = m < a.M ? b * a.cH : -1; cy0[j] = oy * a.cs - a.cp; cx0[j] = ox * a.cs - a.cp;
+            }
+        }
+    };
+    auto issue = [&](int kt, int stage) {                          // 8 LDS-DMA instructions per wave and K tile
+        const uint32_t la = lds0 + (uint32_t)(G3_A0 + stage * G3_STAGE) + wave_u * 4096u;
+        const uint32_t lb = lds0 + (uint32_t)(G3_B0 + stage * G3_STAGE) + wave_u * 4096u;
+        if (CONV) {
+            const int k0 = kt * G3K, tap = k0 / a.cC, c0 = k0 - tap * a.cC;     // block-uniform
+            const int ky = tap / a.ckw, kx = tap - ky * a.ckw;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int iy = cy0[j] + ky * a.cd, ix = cx0[j] + kx * a.cd;
+                const bool ok = cby[j] >= 0 && (unsigned)iy < (unsigned)a.cH && (unsigned)ix < (unsigned)a.cW;
+                const uint32_t vo = ok ? (uint32_t)((((cby[j] + iy) * a.cW + ix) * a.cC + c0) * 4) + a_voff[j] : 0x80000000u;
+                dma16(x_rsrc, vo, 0u, la + (uint32_t)(j * 1024));
+            }
+        } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(x_rsrc, a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * 128), lb + (uint32_t)(j * 1024));
+    };
+
+    // ---- fragment addresses: row li of a 32-row MFMA tile, k = 16 ks + 8 hk .. + 7.  Activations (rows 32 wave + li): float32,
+    // chunks 4 ks + 2 hk and + 1; weights (rows 32 j + li): hi chunk 2 ks + hk, lo chunk 4 + 2 ks + hk.  Swizzle key
+    // (row >> 1) & 7 = (li >> 1) & 7 for every tile row base (multiples of 32).
+    const int sw = (li >> 1) & 7;
+    int fa[2][2], fb[2][2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) fa[ks][e] = G3_A0 + (wave * 32 + li) * 128 + (((4 * ks + 2 * hk + e) ^ sw) * 16);
+        fb[ks][0] = G3_B0 + li * 128 + (((2 * ks + hk) ^ sw) * 16);
+        fb[ks][1] = G3_B0 + li * 128 + (((4 + 2 * ks + hk) ^ sw) * 16);
+    }
+
+    int slot = blockIdx.x;
+    int64_t m0 = 0; int n0 = 0;
+    while (slot < ntiles && !tile_of(slot, m0, n0)) slot += gridDim.x;
+    if (slot >= ntiles) return;
+    if (tid < 2) sMax[tid] = 0u;
+    int par = 0;
+    const int we = (int)a.trailer[1];
+    float amax = 0.f, sx = kActScale0;
+    int xe = kActExp0;
+    bool scaled = false;
+    int g = 0;                                                    // running K-tile counter: stage = g & 1 across output tiles
+    point(m0, n0);
+    issue(0, 0);
+
+    while (true) {
+        int nslot = slot + gridDim.x;
+        int64_t nm0 = 0; int nn0 = 0;
+        while (nslot < ntiles && !tile_of(nslot, nm0, nn0)) nslot += gridDim.x;
+        const bool has_next = nslot < ntiles;
+
+        f32x16 acc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        amax = 0.f;
+
+        for (int t = 0; t < nkt; ++t, ++g) {
+            const int st = g & 1;
+            // K tile t (issued one tile ago) has landed for this wave; behind the barrier for every wave — and every wave has
+            // finished the MFMAs of tile t-1, whose fragments came from the other stage: it may be refilled now.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (t + 1 < nkt && ABL != 1) issue(t + 1, st ^ 1);     // (the next output tile's first K tile is issued behind the guard check)
+            if (t == 0 && tid == 0) sMax[par ^ 1] = 0u;
+            const unsigned char* sa = smem + st * G3_STAGE;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                f32x4 p, q;
+                if (ABL == 4) { p = f32x4{(float)t, 1.f, 2.f, 3.f}; q = f32x4{(float)ks, 1.f, 2.f, 3.f}; }
+                else {
+                    p = *reinterpret_cast<const f32x4*>(sa + fa[ks][0]);
+                    q = *reinterpret_cast<const f32x4*>(sa + fa[ks][1]);
+                }
+                h8 Bh[8], Bl[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    Bh[j] = *reinterpret_cast<const h8*>(sa + fb[ks][0] + j * 4096);
+                    Bl[j] = *reinterpret_cast<const h8*>(sa + fb[ks][1] + j * 4096);
+                }
+                u32x4 H, L; unsigned h, l;
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(p[0])), __builtin_fabsf(p[1]));
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(p[2])), __builtin_fabsf(p[3]));
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(q[0])), __builtin_fabsf(q[1]));
+                amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(q[2])), __builtin_fabsf(q[3]));
+                if (ABL == 3) { H = __builtin_bit_cast(u32x4, p); L = __builtin_bit_cast(u32x4, q); }
+                else {
+                    split2(p[0], p[1], sx, h, l); H[0] = h; L[0] = l;
+                    split2(p[2], p[3], sx, h, l); H[1] = h; L[1] = l;
+                    split2(q[0], q[1], sx, h, l); H[2] = h; L[2] = l;
+                    split2(q[2], q[3], sx, h, l); H[3] = h; L[3] = l;
+                }
+                const h8 Ah = __builtin_bit_cast(h8, H), Al = __builtin_bit_cast(h8, L);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (ABL == 2) { asm volatile("" : : "v"(Ah), "v"(Al), "v"(Bh[j]), "v"(Bl[j])); continue; }
+                    // transposed product: rows of the accumulator tile = weight rows n, columns (lanes) = activation rows m
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[j], Ah, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bl[j], Ah, acc[j], 0, 0, 0);
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[j], Al, acc[j], 0, 0, 0);
+                }
+            }
+        }
+
+        // ---- range guard (gemm_split.hip): the block's max|x| of this pass, through LDS
+        if (!scaled && amax >= kSplitLimit3) atomicMax(&sMax[par], __builtin_bit_cast(unsigned, amax));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // also: every wave is done with the last K tile's stage
+        const unsigned mx = sMax[par];
+        par ^= 1;
+        bool again = false;
+        if (mx != 0u && !scaled) {
+            const int ex = (int)(mx >> 23) & 0xff;
+            if (ex != 0xff) {                                      // Inf / NaN: nothing to rescue, let them propagate
+                xe = ex - 127 - 13;                                // max|x| * 2^-xe in [2^13, 2^14)
+                sx = pow2f3(-xe);
+                scaled = true; again = true;
+            }
+        }
+        if (again) {                                               // same tile again, scaled: its first K tile into the free stage
+            issue(0, g & 1);
+            continue;
+        }
+        // the next output tile's first K tile travels during the epilogue (stage g & 1 was last read two K tiles ago)
+        const int64_t em0 = m0; const int en0 = n0;
+        if (has_next) { point(nm0, nn0); issue(0, g & 1); }
+
+        const int oe = we + xe;
+        const int oe1 = oe / 2, oe2 = oe - oe1;
+        const float os1 = pow2f3(oe1 < -126 ? -126 : (oe1 > 127 ? 127 : oe1)), os2 = pow2f3(oe2 < -126 ? -126 : (oe2 > 127 ? 127 : oe2));
+
+        // ---- epilogue: lane = output row m (32 wave + li), registers 4 g4 .. 4 g4 + 3 of tile j = four consecutive columns
+        // 32 j + 8 g4 + 4 hk ..: 16-byte accesses.  BRANCH-FREE on purpose: a missing bias / residual is read through a
+        // zero-record descriptor (the hardware returns zeros).  With `has_res ? load : 0` the loads sat in their own basic
+        // blocks and hipcc (clang-22) placed a `v_mov v, 0` of a store-data register directly behind a 16-byte store across
+        // the block boundary — the store then wrote the zero (seen as exact zeros in column 8 g4 + 2 of some rows, run-dependent).
+        {
+            const int64_t tile_off = em0 * a.N + en0;
+            const int64_t rem = ((int64_t)a.M * a.N - tile_off) * 4;
+            const int nrec = rem > 0x7fffffff ? 0x7fffffff : (int)rem;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + tile_off), 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.residual ? a.residual : a.out) + tile_off), 0, a.residual ? nrec : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.bias ? a.bias : a.out) + en0), 0, a.bias ? G3N * 4 : 0, 0x00020000);
+            const int voff = ((wave * 32 + li) * a.N + 4 * hk) * 4;
+            const float relu_floor = a.act == 1 ? 0.f : -__builtin_inff();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 bv[4], rv[4];
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    bv[g4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b_rsrc, 16 * hk + (j * 32 + 8 * g4) * 4, 0, 0));
+                    rv[g4] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r_rsrc, voff + (j * 32 + 8 * g4) * 4, 0, 0));
+                }
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    f32x4 v;
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        float vv = acc[j][4 * g4 + qq] * os1 * os2;
+                        vv = vv + bv[g4][qq] + rv[g4][qq];
+                        v[qq] = __builtin_fmaxf(vv, relu_floor);
+                    }
+                    // the column offset rides in the instruction's IMMEDIATE offset (vector offset + constant, scalar offset 0), not in
+                    // a scalar register: with an SGPR offset hipcc pads no wait state between a 16-byte store and the next vector
+                    // write of its data registers (LLVM's rule: that hazard exists only without an soffset register) — on gfx950
+                    // the store then picked up the NEXT group's value in its first dword (wrong, run-dependent outputs)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), o_rsrc, voff + (j * 32 + 8 * g4) * 4, 0, 0);
+                }
+            }
+        }
+        if (!has_next) break;
+        slot = nslot; m0 = nm0; n0 = nn0;
+        scaled = false; sx = kActScale0; xe = kActExp0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// weights float32 [N][K] (already normalised by 2^-e, the trailer's exponent) -> the k-blocked image [N][K/32][32 hi | 32 lo]
+__global__ __launch_bounds__(256)
+void split3_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_t* __restrict__ out, const unsigned* __restrict__ trailer)
+{
+    const int e = (int)trailer[1];
+    const int e1 = e / 2, e2 = e - e1;
+    const float s1 = pow2f3(-e1), s2 = pow2f3(-e2);
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;        // element pair (n, k), (n, k + 1); K % 32 == 0
+    if (i >= n_elems) return;
+    const float x0 = w[i] * s1 * s2, x1 = w[i + 1] * s1 * s2;
+    const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
+    const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
+    const int64_t blk = i >> 5;                                   // (n, k / 32): rows are K long and K % 32 == 0
+    const int kk = (int)(i & 31);
+    uint16_t* d = out + blk * 64 + kk;
+    d[0] = __builtin_bit_cast(uint16_t, h0); d[1] = __builtin_bit_cast(uint16_t, h1);
+    d[32] = __builtin_bit_cast(uint16_t, l0); d[33] = __builtin_bit_cast(uint16_t, l1);
+}
+
+}  // namespace
+
+// Called by awseg_gemm_split_weights once the classic image and the trailer {max|w| bits, ew} are written (same stream).
+int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const unsigned* trailer, hipStream_t stream)
+{
+    const int64_t ne = (int64_t)n * k;
+    hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, ne, w3, trailer);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const void* out, const void* residual, const void* bias)
+{
+    if (n % G3N || k % G3K || k < 64 || m < 1) return false;
+    if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) return false;
+    if ((int64_t)G3M * n * 4 > 0x7fffffff || (int64_t)G3M * k * 4 > 0x7fffffff) return false;
+    return true;
+}
+
+int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned* trailer, const float* bias, const float* residual,
+                             int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv)
+{
+    g3_args a;
+    a.cH = a.cW = a.cC = a.cHo = a.cWo = a.ckw = a.cs = 1; a.cp = 0; a.cd = 1; a.x_bytes = 0;
+    if (conv) {                                                   // {H, W, C, Ho, Wo, kw, stride, pad, dil, batch}
+        a.cH = conv[0]; a.cW = conv[1]; a.cC = conv[2]; a.cHo = conv[3]; a.cWo = conv[4]; a.ckw = conv[5]; a.cs = conv[6]; a.cp = conv[7]; a.cd = conv[8];
+        a.x_bytes = (int64_t)conv[9] * a.cH * a.cW * a.cC * 4;
+        if (a.cC % G3K || a.x_bytes > 0x7fffffff) return AWSEG_ERANGE;    // checked by the caller (eligibility)
+    }
+    a.x = x; a.w3 = w3; a.bias = bias; a.residual = residual; a.out = out; a.trailer = trailer;
+    a.M = m; a.N = n; a.K = k; a.act = act;
+    const int64_t ntm = (m + G3M - 1) / G3M;
+    a.ntn = n / G3N;
+    const int64_t ntm8 = (ntm + 7) / 8 * 8;
+    if (ntm8 * a.ntn > 0x7fffffff) return AWSEG_ERANGE;
+    a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
+    const int64_t slots = ntm8 * a.ntn;
+    int64_t blocks = (int64_t)cus / 8 * 8;
+    if (blocks < 8) blocks = 8;
+    if (blocks > slots) blocks = slots;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+        if (e != hipSuccess) return (int)e;
+        attr_done = true;
+    }
+    static int abl = -1;
+    if (abl < 0) { const char* e = getenv("AWSEG_G3_ABL"); abl = e ? atoi(e) : 0; }
+    if (abl && !conv) {
+#define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a); break; }
+        switch (abl) { G3_ABL(1) G3_ABL(2) G3_ABL(3) G3_ABL(4) default: break; }
+#undef G3_ABL
+        AWSEG_LAUNCH_CHECK();
+        return 0;
+    }
+    if (conv) hipLaunchKernelGGL(gemm_split3_kernel<true>, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
+    else hipLaunchKernelGGL(gemm_split3_kernel<false>, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

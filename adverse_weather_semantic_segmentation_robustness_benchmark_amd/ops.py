@@ -636,9 +636,15 @@ def gemm_split_weights(w: torch.Tensor) -> torch.Tensor:
     (a clone would drop the trailer)."""
     w = w.contiguous()
     n, k = w.shape
-    buf = torch.empty(2 * n * k + 8, dtype=torch.int16, device=w.device)
+    # room for the classic [2][N][K] image, the 16-byte trailer and — K % 32 == 0 — the k-blocked image of gemm_split3.hip
+    buf = torch.empty(int(N.lib().awseg_gemm_split_weight_halfs(n, k)), dtype=torch.int16, device=w.device)
     N.call("awseg_gemm_split_weights", N.ptr(w), n, k, N.ptr(buf), N.stream())
     return buf[:2 * n * k].view(2, n, k)
+
+
+def _split_weights_intact(w_split: torch.Tensor, n: int, k: int) -> bool:
+    """the view gemm_split_weights returned still sits in front of its trailer (+ k-blocked image): a clone would drop them"""
+    return w_split.untyped_storage().nbytes() - w_split.storage_offset() * 2 >= int(N.lib().awseg_gemm_split_weight_halfs(n, k)) * 2
 
 
 def gemm_split_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0,
@@ -647,7 +653,7 @@ def gemm_split_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[t
     x = x.contiguous()
     m, k = x.shape
     n = w_split.shape[1]
-    if w_split.untyped_storage().nbytes() - w_split.storage_offset() * 2 < (2 * n * k + 8) * 2:
+    if not _split_weights_intact(w_split, n, k):
         raise N.AwsegError("w_split lost its 16-byte trailer (weight exponent): pass the tensor gemm_split_weights returned, not a copy")
     if out is None:
         out = torch.empty(m, n, dtype=torch.float32, device=x.device)
@@ -669,7 +675,7 @@ def conv_gemm_split(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch
     n, k = w_split.shape[1], w_split.shape[2]
     if k != kh * kw * c:
         raise N.AwsegError(f"conv_gemm_split: weights have K = {k}, the convolution needs {kh * kw * c}")
-    if w_split.untyped_storage().nbytes() - w_split.storage_offset() * 2 < (2 * n * k + 8) * 2:
+    if not _split_weights_intact(w_split, n, k):
         raise N.AwsegError("w_split lost its 16-byte trailer (weight exponent): pass the tensor gemm_split_weights returned, not a copy")
     ho = (h + 2 * pad - dilation * (kh - 1) - 1) // stride + 1
     wo = (w + 2 * pad - dilation * (kw - 1) - 1) // stride + 1

@@ -485,8 +485,8 @@ AWSEG_API int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w
     AWSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(SWT), 0, awseg_s(stream), w, ne, w_split, trailer);
     AWSEG_LAUNCH_CHECK();
-    // K % 32 == 0: the k-blocked image of gemm_split3.hip behind the trailer (awseg_gemm_split_weight_halfs says how much room)
-    if (k % 32 == 0) return awseg_gemm_split3_weights(w, n, k, w_split + 2 * ne + 8, trailer, awseg_s(stream));
+    // N % 256 == 0, K % 8 == 0: the k-blocked image of gemm_split3.hip behind the trailer (awseg_gemm_split_weight_halfs says how much room)
+    if (n % 256 == 0 && k % 8 == 0) return awseg_gemm_split3_weights(w, n, k, w_split + 2 * ne + 8, trailer, awseg_s(stream));
     return 0;
 }
 
@@ -494,7 +494,7 @@ AWSEG_API int64_t awseg_gemm_split_weight_halfs(int n, int k)
 {
     if (n < 1 || k < 1) return -1;
     const int64_t ne = (int64_t)n * k;
-    return 2 * ne + 8 + (k % 32 == 0 ? 2 * ne : 0);
+    return 2 * ne + 8 + ((n % 256 == 0 && k % 8 == 0) ? (int64_t)2 * n * ((k + 31) / 32 * 32) : 0);
 }
 
 namespace {

@@ -39,7 +39,10 @@ constexpr int G3_A0 = 0, G3_B0 = 2 * G3_STAGE;                    // A stage s a
 constexpr int G3_LDS = 4 * G3_STAGE + 64;                         // + sMax[2]
 constexpr float kActScale0 = 16.0f;        // optimistic-pass activation scale (gemm_split.hip: split_pair_unscaled)
 constexpr int kActExp0 = -4;
-constexpr float kSplitLimit3 = 2048.0f;    // |x| below this splits without loss at scale 2^4 (|x s| < 2^15)
+constexpr float kSplitLimit3 = 2048.0f;
+#ifndef G3_TRANSPOSED
+#define G3_TRANSPOSED 0                    // 1: weights as the MFMA's row operand, lane = output row, 16-byte epilogue accesses (measured slower)
+#endif    // |x| below this splits without loss at scale 2^4 (|x s| < 2^15)
 
 __device__ __forceinline__ float pow2f3(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }
 
@@ -71,6 +74,7 @@ struct g3_args {
     const float* x; const uint16_t* w3; const float* bias; const float* residual; float* out;
     const unsigned* trailer;               // {max|w| bits, weight exponent ew, 0, 0}
     int64_t M; int N, K, act, ntm, ntm8, ntn;
+    int rot;                               // measurement switch (AWSEG_G3_ROT): block b starts its K loop at K tile (b * rot) % nkt
     // CONV: x is an NHWC image batch [B, cH, cW, cC] (cC % 32 == 0: a K tile lies inside one tap) and row m = (b, oy, ox) of the
     // A operand is gathered from it by the LDS-DMA's per-lane source address — column k = (ky * ckw + kx) * cC + c is
     // x[b, oy * cs - cp + ky * cd, ox * cs - cp + kx * cd, c], zero outside (awseg_conv_gemm_split_bias_act)
@@ -79,7 +83,7 @@ struct g3_args {
 };
 
 // ABL != 0: ablation builds for measurements (wrong results, valid times; AWSEG_G3_ABL): 1 no LDS-DMA in the K loop, 2 no MFMAs,
-// 3 no operand split, 4 no activation fragment reads
+// 3 no operand split, 4 no activation fragment reads, 5 no weight fragment reads
 template <bool CONV, int ABL = 0>
 __global__ __launch_bounds__(G3T, 2)
 void gemm_split3_kernel(g3_args a)
@@ -88,7 +92,8 @@ void gemm_split3_kernel(g3_args a)
     unsigned* sMax = reinterpret_cast<unsigned*>(smem + 4 * G3_STAGE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = lane >> 5, li = lane & 31;
-    const int K = a.K, nkt = K / G3K, kb = K / G3K;
+    const int K = a.K, nkt = (K + G3K - 1) / G3K, kb = nkt;         // K % 32 != 0 (K % 8 == 0): the last K tile is zero-filled past K
+    const int ktail = K % G3K;
     const int ntiles = a.ntm8 * a.ntn;
 
     auto tile_of = [&](int slot, int64_t& m0, int& n0) -> bool {   // gemm_split.hip: XCD-aware persistent walk
@@ -101,7 +106,7 @@ void gemm_split3_kernel(g3_args a)
     // ---- LDS-DMA roles.  One instruction covers 8 rows x 128 B (1 KB, linear in LDS); wave w fills row groups 4w .. 4w+3 of
     // each operand's 256-row stage.  Lane l -> row 8 q + (l >> 3), slot l & 7, which holds source chunk slot ^ ((row >> 1) & 7).
     const int rl = lane >> 3, sl = lane & 7;
-    uint32_t a_voff[4], b_voff[4];
+    uint32_t a_voff[4], a_voff_last[4], b_voff[4];
     int cby[4], cy0[4], cx0[4];                                    // CONV: image row base b * cH, first tap's input row / column of this lane's A rows (< 0: row past M)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr3(smem));
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar register: the LDS-DMA base goes through m0
@@ -111,13 +116,14 @@ void gemm_split3_kernel(g3_args a)
         const int64_t xbytes = rows_left * (int64_t)K * 4;
         if (CONV) x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
         else x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * K), 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
-        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * K * 2), 0, G3N * K * 4, 0x00020000);
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * kb * 64), 0, G3N * kb * 128, 0x00020000);   // n-tile n0 / 256: kb blocks of 32 KB
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 8 * (4 * wave + j) + rl;
             const int c = sl ^ ((row >> 1) & 7);
             a_voff[j] = (uint32_t)(row * K * 4 + c * 16);
-            b_voff[j] = (uint32_t)(row * kb * 128 + c * 16);
+            b_voff[j] = (uint32_t)(row * 128 + c * 16);             // inside the K tile's contiguous 32 KB (256 rows x 128 B)
+            a_voff_last[j] = (ktail == 0 || c * 4 < ktail) ? a_voff[j] : 0x80000000u;     // chunks past K read zeros (the weight image is zero there too)
             if (CONV) {
                 a_voff[j] = (uint32_t)(c * 16);
                 const int64_t m = m0 + row;
@@ -143,10 +149,10 @@ void gemm_split3_kernel(g3_args a)
             }
         } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(x_rsrc, a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
+        for (int j = 0; j < 4; ++j) dma16(x_rsrc, kt == nkt - 1 ? a_voff_last[j] : a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * 128), lb + (uint32_t)(j * 1024));
+        for (int j = 0; j < 4; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * 32768), lb + (uint32_t)(j * 1024));
     };
 
     // ---- fragment addresses: row li of a 32-row MFMA tile, k = 16 ks + 8 hk .. + 7.  Activations (rows 32 wave + li): float32,
@@ -172,9 +178,12 @@ void gemm_split3_kernel(g3_args a)
     float amax = 0.f, sx = kActScale0;
     int xe = kActExp0;
     bool scaled = false;
+    bool stores_pending = false;                                  // an epilogue's stores may still be in flight
     int g = 0;                                                    // running K-tile counter: stage = g & 1 across output tiles
+    const int kt0 = a.rot ? (int)(((unsigned)blockIdx.x * (unsigned)a.rot) % (unsigned)nkt) : 0;
+    auto ktile = [&](int t) { const int u = t + kt0; return u >= nkt ? u - nkt : u; };
     point(m0, n0);
-    issue(0, 0);
+    issue(ktile(0), 0);
 
     while (true) {
         int nslot = slot + gridDim.x;
@@ -193,9 +202,13 @@ void gemm_split3_kernel(g3_args a)
             const int st = g & 1;
             // K tile t (issued one tile ago) has landed for this wave; behind the barrier for every wave — and every wave has
             // finished the MFMAs of tile t-1, whose fragments came from the other stage: it may be refilled now.
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (first K tile behind an epilogue: the epilogue's stores — 128, or 32 in the transposed form — are the youngest
+            // vector-memory operations and the 8 LDS-DMA of this K tile are older than all of them: "at most 63 (32)
+            // outstanding" means the DMA have landed, without waiting out the stores' write latency)
+            if (t == 0 && stores_pending) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G3_TRANSPOSED ? 32 : 63) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (t + 1 < nkt && ABL != 1) issue(t + 1, st ^ 1);     // (the next output tile's first K tile is issued behind the guard check)
+            if (t + 1 < nkt && ABL != 1) issue(ktile(t + 1), st ^ 1);     // (the next output tile's first K tile is issued behind the guard check)
             if (t == 0 && tid == 0) sMax[par ^ 1] = 0u;
             const unsigned char* sa = smem + st * G3_STAGE;
 #pragma unroll
@@ -209,6 +222,7 @@ void gemm_split3_kernel(g3_args a)
                 h8 Bh[8], Bl[8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
+                    if (ABL == 5) { Bh[j] = h8{(_Float16)t, (_Float16)j, 1, 2, 3, 4, 5, 6}; Bl[j] = h8{(_Float16)ks, (_Float16)j, 1, 2, 3, 4, 5, 6}; continue; }
                     Bh[j] = *reinterpret_cast<const h8*>(sa + fb[ks][0] + j * 4096);
                     Bl[j] = *reinterpret_cast<const h8*>(sa + fb[ks][1] + j * 4096);
                 }
@@ -228,10 +242,16 @@ void gemm_split3_kernel(g3_args a)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (ABL == 2) { asm volatile("" : : "v"(Ah), "v"(Al), "v"(Bh[j]), "v"(Bl[j])); continue; }
-                    // transposed product: rows of the accumulator tile = weight rows n, columns (lanes) = activation rows m
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[j], Ah, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bl[j], Ah, acc[j], 0, 0, 0);
-                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[j], Al, acc[j], 0, 0, 0);
+                    if (G3_TRANSPOSED) {
+                        // transposed product: rows of the accumulator tile = weight rows n, columns (lanes) = activation rows m
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[j], Ah, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bl[j], Ah, acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Bh[j], Al, acc[j], 0, 0, 0);
+                    } else {
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bh[j], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah, Bl[j], acc[j], 0, 0, 0);
+                        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al, Bh[j], acc[j], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -252,17 +272,19 @@ void gemm_split3_kernel(g3_args a)
             }
         }
         if (again) {                                               // same tile again, scaled: its first K tile into the free stage
-            issue(0, g & 1);
+            stores_pending = false;
+            issue(ktile(0), g & 1);
             continue;
         }
         // the next output tile's first K tile travels during the epilogue (stage g & 1 was last read two K tiles ago)
         const int64_t em0 = m0; const int en0 = n0;
-        if (has_next) { point(nm0, nn0); issue(0, g & 1); }
+        if (has_next) { point(nm0, nn0); issue(ktile(0), g & 1); }
 
         const int oe = we + xe;
         const int oe1 = oe / 2, oe2 = oe - oe1;
         const float os1 = pow2f3(oe1 < -126 ? -126 : (oe1 > 127 ? 127 : oe1)), os2 = pow2f3(oe2 < -126 ? -126 : (oe2 > 127 ? 127 : oe2));
 
+#if G3_TRANSPOSED
         // ---- epilogue: lane = output row m (32 wave + li), registers 4 g4 .. 4 g4 + 3 of tile j = four consecutive columns
         // 32 j + 8 g4 + 4 hk ..: 16-byte accesses.  BRANCH-FREE on purpose: a missing bias / residual is read through a
         // zero-record descriptor (the hardware returns zeros).  With `has_res ? load : 0` the loads sat in their own basic
@@ -302,28 +324,70 @@ void gemm_split3_kernel(g3_args a)
                 }
             }
         }
+#else
+        // ---- epilogue: lane = output column n (32 j + li), registers = rows m (32 wave + 8 (r >> 2) + 4 hk + (r & 3)): a store
+        // instruction writes two full 128-byte lines.  (The transposed form — lane = row, 16-byte accesses, a quarter of the
+        // instructions — was measured SLOWER wherever the epilogue dominates (K = 64: 0.62 against 0.48 ms): each of its
+        // instructions touches 32 rows x 32 bytes, four times the write requests at the L2 for the same bytes.)
+        {
+            const int64_t tile_off = em0 * a.N + en0;
+            const int64_t rem = ((int64_t)a.M * a.N - tile_off) * 4;
+            const int nrec = rem > 0x7fffffff ? 0x7fffffff : (int)rem;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + tile_off), 0, nrec, 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.residual ? a.residual : a.out) + tile_off), 0, a.residual ? nrec : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.bias ? a.bias : a.out) + en0), 0, a.bias ? G3N * 4 : 0, 0x00020000);
+            const int voff = ((wave * 32 + 4 * hk) * a.N + li) * 4;
+            const float relu_floor = a.act == 1 ? 0.f : -__builtin_inff();
+            const int rowb = a.N * 4;                              // bytes per output row
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float bvj = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, (j * 32 + li) * 4, 0, 0));
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float rv[8];
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
+                        rv[r8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, voff + j * 128, rowc * rowb, 0));
+                    }
+#pragma unroll
+                    for (int r8 = 0; r8 < 8; ++r8) {
+                        const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
+                        float vv = acc[j][r] * os1 * os2;
+                        vv = vv + bvj + rv[r8];
+                        vv = __builtin_fmaxf(vv, relu_floor);
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, voff + j * 128, rowc * rowb, 0);
+                    }
+                }
+            }
+        }
+#endif
         if (!has_next) break;
+        stores_pending = true;
         slot = nslot; m0 = nm0; n0 = nn0;
         scaled = false; sx = kActScale0; xe = kActExp0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-// weights float32 [N][K] (already normalised by 2^-e, the trailer's exponent) -> the k-blocked image [N][K/32][32 hi | 32 lo]
+// weights float32 [N][K] (normalised by 2^-e, the trailer's exponent) -> the k-blocked image [N/256][KB][256][32 hi | 32 lo],
+// KB = ceil(K / 32), zeros past K: the K tile of a 256-row n-tile is one contiguous 32 KB block (a tile's rows at stride K * 4 B
+// would all fall into the same few L2 channels)
 __global__ __launch_bounds__(256)
-void split3_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_t* __restrict__ out, const unsigned* __restrict__ trailer)
+void split3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, int kb, uint16_t* __restrict__ out, const unsigned* __restrict__ trailer)
 {
     const int e = (int)trailer[1];
     const int e1 = e / 2, e2 = e - e1;
     const float s1 = pow2f3(-e1), s2 = pow2f3(-e2);
-    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;        // element pair (n, k), (n, k + 1); K % 32 == 0
-    if (i >= n_elems) return;
-    const float x0 = w[i] * s1 * s2, x1 = w[i + 1] * s1 * s2;
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;        // padded element pair (n, k), (n, k + 1), k < 32 KB
+    const int kp = kb * 32;
+    if (i >= (int64_t)n_rows * kp) return;
+    const int64_t n = i / kp;
+    const int k = (int)(i - n * kp);
+    const float x0 = k < k_dim ? w[n * k_dim + k] * s1 * s2 : 0.f, x1 = k + 1 < k_dim ? w[n * k_dim + k + 1] * s1 * s2 : 0.f;
     const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
     const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-    const int64_t blk = i >> 5;                                   // (n, k / 32): rows are K long and K % 32 == 0
-    const int kk = (int)(i & 31);
-    uint16_t* d = out + blk * 64 + kk;
+    uint16_t* d = out + (((n >> 8) * kb + (k >> 5)) * 256 + (n & 255)) * 64 + (k & 31);
     d[0] = __builtin_bit_cast(uint16_t, h0); d[1] = __builtin_bit_cast(uint16_t, h1);
     d[32] = __builtin_bit_cast(uint16_t, l0); d[33] = __builtin_bit_cast(uint16_t, l1);
 }
@@ -333,17 +397,18 @@ void split3_weights_kernel(const float* __restrict__ w, int64_t n_elems, uint16_
 // Called by awseg_gemm_split_weights once the classic image and the trailer {max|w| bits, ew} are written (same stream).
 int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const unsigned* trailer, hipStream_t stream)
 {
-    const int64_t ne = (int64_t)n * k;
-    hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, ne, w3, trailer);
+    const int kb = (k + 31) / 32;
+    const int64_t ne = (int64_t)n * kb * 32;
+    hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, n, k, kb, w3, trailer);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
 
 bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const void* out, const void* residual, const void* bias)
 {
-    if (n % G3N || k % G3K || k < 64 || m < 1) return false;
+    if (n % G3N || k % 8 || k < 64 || m < 1) return false;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) return false;
-    if ((int64_t)G3M * n * 4 > 0x7fffffff || (int64_t)G3M * k * 4 > 0x7fffffff) return false;
+    if ((int64_t)G3M * n * 4 > 0x7fffffff || (int64_t)G3M * (k + 32) * 4 > 0x7fffffff) return false;
     return true;
 }
 
@@ -357,6 +422,9 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
         a.x_bytes = (int64_t)conv[9] * a.cH * a.cW * a.cC * 4;
         if (a.cC % G3K || a.x_bytes > 0x7fffffff) return AWSEG_ERANGE;    // checked by the caller (eligibility)
     }
+    static int rot = -1;
+    if (rot < 0) { const char* e = getenv("AWSEG_G3_ROT"); rot = e ? atoi(e) : 0; }
+    a.rot = rot;
     a.x = x; a.w3 = w3; a.bias = bias; a.residual = residual; a.out = out; a.trailer = trailer;
     a.M = m; a.N = n; a.K = k; a.act = act;
     const int64_t ntm = (m + G3M - 1) / G3M;
@@ -379,7 +447,7 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     if (abl < 0) { const char* e = getenv("AWSEG_G3_ABL"); abl = e ? atoi(e) : 0; }
     if (abl && !conv) {
 #define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a); break; }
-        switch (abl) { G3_ABL(1) G3_ABL(2) G3_ABL(3) G3_ABL(4) default: break; }
+        switch (abl) { G3_ABL(1) G3_ABL(2) G3_ABL(3) G3_ABL(4) G3_ABL(5) default: break; }
 #undef G3_ABL
         AWSEG_LAUNCH_CHECK();
         return 0;

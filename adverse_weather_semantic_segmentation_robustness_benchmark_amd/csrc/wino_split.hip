@@ -56,6 +56,7 @@ struct ws_args {
     const float* x; const uint16_t* U; const float* shift; const float* residual; const float* w2; const float* b2;
     float* out;
     int H, W, Cin, Cout, dil, act, nbx, nby, ngroups, batch;
+    int span;                              // wino8_kernel: spatial tiles of one XCD that run the same cout group back to back (block order)
     int64_t u_halfs;                       // halfs of U in front of the trailer {2^eu as float}
 };
 
@@ -100,6 +101,17 @@ __device__ __forceinline__ void split_pair(v2f v, unsigned& hi, unsigned& lo)
     asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
         "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]"
         : "=&v"(lo) : "v"(v.x), "v"(v.y), "v"(hi));
+}
+
+// the same split for values that go STRAIGHT into an MFMA operand register: a vector write needs two wait states before an MFMA
+// reads the register, and hipcc pads only instructions it emitted itself (gemm_split3.hip)
+__device__ __forceinline__ void split_pair_mfma(float x, float y, unsigned& hi, unsigned& lo)
+{
+    asm("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(hi), "=&v"(lo) : "v"(x), "v"(y));
 }
 
 #ifdef AWSEG_WS_STAMP
@@ -554,15 +566,435 @@ void wino_split_kernel(ws_args a)
 #endif
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Round 3: the same operator with EIGHT waves per block that ALTERNATE between two roles.  The four-wave kernel above keeps one
+// wave per SIMD: its ~280 transform instructions, 64 LDS accesses and 48 MFMAs per chunk share ONE instruction stream, and the
+// stamps show 5 100 ticks per chunk against 1 536 of matrix time.  Here a wave owns ONE V row (4 positions) x all
+// 64 tiles x 32 couts — 128 accumulator registers, two waves per SIMD — and every U fragment is still fetched by exactly one wave:
+//   * waves 0-3 own V rows {0, 2} ("even"), waves 4-7 rows {1, 3} ("odd"); wave w and w + 4 share a SIMD;
+//   * slot A of chunk c: the even waves run their 24 MFMAs on rows {0, 2} while the odd waves turn patch c into rows {1, 3} of
+//     the same chunk (they need only rows 1..3 of the 4x4 input tile: B^T rows 1 and 3), fetch their U fragments of chunk c and
+//     issue the LDS-DMA of patch c + 2; slot B: the odd waves run their MFMAs, the even waves build rows {0, 2} of chunk c + 1
+//     (input rows 0..2) and fetch their U of chunk c + 1.  One barrier per slot.  On every SIMD one wave feeds the matrix pipe
+//     while its partner does vector / LDS work, and the roles swap each slot — no wave is ever a dedicated loader;
+//   * the partial inverse transforms of the four V rows meet through LDS in the epilogue (V and the patches are dead by then):
+//     wave (nt, row) finishes m-tile row >> 1, output row row & 1.
+constexpr int W8T = 512;
+#ifdef AWSEG_WS_STAMP
+__device__ unsigned long long g_w8_stamp[2][8];                       // [wave 0 | wave 4][slot A work, barrier A, slot B work, barrier B, chunks, whole block]
+#endif
+constexpr int X_BYTES = 8 * 64 * 64 * 4;                              // epilogue exchange: 8 waves x 64 lanes x 64 floats
+
+template <int MODE, bool BF16>
+__global__ __launch_bounds__(W8T, 2)
+void wino8_kernel(ws_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sV = smem;
+    unsigned char* sP = smem + V_BYTES;
+    unsigned* sMax = reinterpret_cast<unsigned*>(smem + V_BYTES + P_RING * P_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int grp = wave >> 2;                                       // 0: V rows {0, 2}; 1: rows {1, 3}
+    const int gw = wave & 3;                                         // wave within its group
+    const int nt = wave & 1;
+    const int vrow = 2 * ((wave >> 1) & 1) + grp;                    // this wave's V row (positions 4 vrow .. 4 vrow + 3)
+    // Block order.  Blocks b, b + 8, ... share an XCD (and its L2).  U of a layer with many channels does not fit an L2
+    // (2048 -> 256: 33 MB) and streams from the Infinity Cache at ~8.6 TB/s chip-wide — the measured pace of both kernels —
+    // unless the CUs of an XCD read the SAME cout group's U at about the same time: `span` consecutive spatial tiles of the
+    // XCD run cout group 0, then the same tiles group 1, ... (span = 1: a tile's groups back to back, the round-2 order).
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int per = a.span * a.ngroups, sg = jj / per, rr = jj - sg * per;
+    const int ng = rr / a.span, t = (sg * a.span + (rr - ng * a.span)) * 8 + xcd;
+    const int gx = a.nbx * a.dil, gy = a.nby * a.dil;
+    if (t >= gx * gy * a.batch) return;
+    const int b = t / (gx * gy), txy = t - b * (gx * gy), tyy = txy / gx, txx = txy - tyy * gx;
+    const int bx = txx % a.nbx, rx = txx / a.nbx;
+    const int by = tyy % a.nby, ry = tyy / a.nby;
+    const int Hs = (a.H - ry + a.dil - 1) / a.dil, Ws = (a.W - rx + a.dil - 1) / a.dil;
+    if (by * 2 * TB >= Hs || bx * 2 * TB >= Ws) return;
+    const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
+    const int n0 = ng * NB;
+    const int nchunks = a.Cin / KC;
+
+    // ---- patch LDS-DMA (issued by the odd group at the start of its transform slot: 21 instructions over its 4 waves), layout as
+    // in the kernel above.  (Measured and dropped: every wave issuing its share and its next U fragments from its MFMA slot — that
+    // slot went from 1 060 to 2 750 ticks for 10 vector-memory instructions, the chunk from 4 950 to 5 700.)
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+    uint32_t pvoff[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = (gw + 4 * j) * 64 + lane;
+        const int g = q >> 2, h = q & 3;
+        const int py = g / PW, pos = g - py * PW;
+        const int px = pos < PW / 2 ? 2 * pos : 2 * (pos - PW / 2) + 1;
+        const int sy = by * 2 * TB - 1 + py, sx = bx * 2 * TB - 1 + px;
+        const int y = ry + a.dil * sy, x = rx + a.dil * sx;
+        const bool ok = g < NPIX && sy >= 0 && sx >= 0 && y < a.H && x < a.W;
+        pvoff[j] = ok ? (uint32_t)(((y * a.W + x) * a.Cin + h * 4) * 4) : 0x80000000u;
+    }
+    const int gw_u = __builtin_amdgcn_readfirstlane(gw);
+    const int n_pinstr = gw_u == 0 ? 6 : 5;
+    const uint32_t p_lds = __builtin_amdgcn_readfirstlane(lds_addr(sP)) + (uint32_t)gw_u * 1024u;
+    auto glds_patch = [&](int chunk, int slot) {
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((chunk < nchunks ? chunk : nchunks - 1) * KC * 4);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p_lds + (uint32_t)(slot * P_BYTES)));
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j < n_pinstr) bufdma16(x_rsrc, pvoff[j], soff, base + (uint32_t)(j * 4096));
+    };
+
+    // ---- transform role: item (tile, channel quad) of the group's 256 threads
+    const int it = tid & 255;
+    const int xtile = it >> 2, xq = it & 3;
+    const int xty = xtile >> 3, xtx = xtile & 7;
+    const int prd = (2 * xty * PW + xtx) * 64 + xq * 16;
+    const int xsw = (xtile >> 2) & 3;
+    const int vw_hi = xtile * 64 + (((xq >> 1) ^ xsw) * 16) + (xq & 1) * 8;
+    const int vw_lo = xtile * 64 + (((2 + (xq >> 1)) ^ xsw) * 16) + (xq & 1) * 8;
+
+    // ---- MFMA role.  (Measured and dropped: V as float32 in LDS, split by the multiplying wave beside its MFMAs — the MFMA slot
+    // went from 1 060 to 2 000 - 2 270 ticks, the transform slot from 2 100 to 1 400, the chunk stayed at 4 950.)
+    int a_hi[2], a_lo[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int tile = m * 32 + li, sw = (tile >> 2) & 3;
+        a_hi[m] = tile * 64 + ((hk ^ sw) * 16);
+        a_lo[m] = tile * 64 + (((2 + hk) ^ sw) * 16);
+    }
+    const int ncb = a.Cout / 32, cb = (n0 >> 5) + nt;
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, (int)(a.u_halfs * 2), 0x00020000);
+    const uint32_t ulane = (uint32_t)(hk * 512 + li * 16);
+    const uint32_t u_p = (uint32_t)ncb * 2048u, u_c = 16u * u_p;
+    const uint32_t u_w = (uint32_t)(__builtin_amdgcn_readfirstlane(4 * vrow) * (int)u_p + __builtin_amdgcn_readfirstlane(cb) * 2048);
+    const float uscale = *reinterpret_cast<const float*>(a.U + a.u_halfs);
+
+    f32x16 acc[4][2];
+    float amax = 0.f, xs = 1.0f;
+    int sx = 0;
+    if (tid == 0) sMax[0] = 0u;
+
+    auto run = [&](auto SC) {
+        constexpr bool SCALED = decltype(SC)::value;
+        h8 uh[4], ul[4];
+        auto u_fetch = [&](int c) {
+#pragma unroll
+            for (int lp = 0; lp < 4; ++lp) {
+                const uint32_t so = (uint32_t)c * u_c + u_w + (uint32_t)lp * u_p;
+                uh[lp] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane, so, 0));
+                if (!BF16) ul[lp] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane + 1024u, so, 0));
+            }
+        };
+        // patch `slot` -> the group's two V rows (grp, grp + 2).  B^T rows:  0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3, so the
+        // even group reads input rows 0, 1, 2 (shared: d2) and the odd group rows 1, 2, 3 (shared: d1).  One V row at a time — the
+        // second row's private input row is loaded after the first row's four positions are stored — keeps 32 registers of patch
+        // data alive instead of 80 (the wave's 128 accumulators and 32 U registers leave ~70 for either role).
+        auto transform = [&](int slot) {
+            const unsigned char* pp = sP + slot * P_BYTES + prd;
+            auto load_row = [&](int i, v2f (&d)[2][4]) {               // input row i of the tile's 4 x 4 patch, both channel pairs
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v2f v = *reinterpret_cast<const v2f*>(pp + e * 8 + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
+                        if (BF16) {
+                        } else if (!SCALED) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
+                        else v = v * v2f{xs, xs};
+                        d[e][j] = v;
+                    }
+            };
+            auto cols_store = [&](int vr, const v2f (&tt)[2][4]) {     // row vr of (B^T d) -> positions 4 vr .. 4 vr + 3, split, stored
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v2f va, vb;
+                    if (j == 0) { va = pk_sub(tt[0][0], tt[0][2]); vb = pk_sub(tt[1][0], tt[1][2]); }
+                    else if (j == 1) { va = pk_add(tt[0][1], tt[0][2]); vb = pk_add(tt[1][1], tt[1][2]); }
+                    else if (j == 2) { va = pk_sub(tt[0][2], tt[0][1]); vb = pk_sub(tt[1][2], tt[1][1]); }
+                    else { va = pk_sub(tt[0][1], tt[0][3]); vb = pk_sub(tt[1][1], tt[1][3]); }
+                    u32x2 H, L; unsigned h, l;
+                    if (BF16) {
+                        H[0] = pack_bf16(va); H[1] = pack_bf16(vb);
+                        *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_hi) = H;
+                        continue;
+                    }
+                    split_pair(va, h, l); H[0] = h; L[0] = l;
+                    split_pair(vb, h, l); H[1] = h; L[1] = l;
+                    *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_hi) = H;
+                    *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_lo) = L;
+                }
+            };
+            v2f sh_[2][4], pr[2][4];                                   // shared input row, private input row -> B^T d row (in place)
+            if (grp == 0) {
+                load_row(2, sh_); load_row(0, pr);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pr[e][j] = pk_sub(pr[e][j], sh_[e][j]);            // row 0: d0 - d2
+                cols_store(0, pr);
+                load_row(1, pr);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pr[e][j] = pk_sub(sh_[e][j], pr[e][j]);            // row 2: d2 - d1
+                cols_store(2, pr);
+            } else {
+                load_row(1, sh_); load_row(2, pr);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pr[e][j] = pk_add(sh_[e][j], pr[e][j]);            // row 1: d1 + d2
+                cols_store(1, pr);
+                load_row(3, pr);
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pr[e][j] = pk_sub(sh_[e][j], pr[e][j]);            // row 3: d1 - d3
+                cols_store(3, pr);
+            }
+        };
+        auto mma = [&]() {
+#pragma unroll
+            for (int lp = 0; lp < 4; ++lp) {
+                const unsigned char* vp = sV + (4 * vrow + lp) * V_POS;
+                h8 vh[2], vl[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    vh[m] = *reinterpret_cast<const h8*>(vp + a_hi[m]);
+                    if (!BF16) vl[m] = *reinterpret_cast<const h8*>(vp + a_lo[m]);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    f32x16 z = acc[lp][m];
+                    if (BF16) {
+                        if (MODE == 1) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, uh[lp]), __builtin_bit_cast(bf8, vh[m]), z, 0, 0, 0);
+                        else z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, vh[m]), __builtin_bit_cast(bf8, uh[lp]), z, 0, 0, 0);
+                    } else if (MODE == 1) {
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh[lp], vh[m], z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ul[lp], vh[m], z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(uh[lp], vl[m], z, 0, 0, 0);
+                    } else {
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[m], uh[lp], z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[m], ul[lp], z, 0, 0, 0);
+                        z = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[m], uh[lp], z, 0, 0, 0);
+                    }
+                    acc[lp][m] = z;
+                }
+            }
+        };
+
+#pragma unroll
+        for (int lp = 0; lp < 4; ++lp)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[lp][m][r] = 0.f;
+        // ---- prologue: patches 0 and 1 in flight, patch 0 landed; the even waves build rows {0, 2} of chunk 0
+        if (grp == 1) {
+            glds_patch(0, 0);
+            glds_patch(1, 1);
+            if (gw_u == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        }
+        __syncthreads();                                             // (also orders sMax[0] = 0 and the previous pass's V reads)
+        if (grp == 0) { u_fetch(0); transform(0); }
+        __syncthreads();
+#ifdef AWSEG_WS_STAMP
+        unsigned long long w8s[5] = {0, 0, 0, 0, 0};
+#define W8_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define W8_ACC(t0, t1, t2, t3, t4) { w8s[0] += t1 - t0; w8s[1] += t2 - t1; w8s[2] += t3 - t2; w8s[3] += t4 - t3; w8s[4] += 1; }
+#else
+#define W8_T(v)
+#define W8_ACC(t0, t1, t2, t3, t4)
+#endif
+        for (int c = 0; c < nchunks; ++c) {
+            W8_T(q0);
+            // slot A: even waves multiply rows {0, 2} of chunk c | odd waves: DMA of patch c + 2, U of chunk c, patch c -> rows {1, 3}
+            if (grp == 0) mma();
+            else {
+                glds_patch(c + 2, (c + 2) % 3);                      // that ring slot held patch c - 1 (last read in slot A of chunk c - 1)
+                u_fetch(c);
+                transform(c % 3);
+                // patch c + 1 (DMA issued a chunk ago, older than this slot's n_pinstr + 8 operations) has landed
+                if (BF16) { if (gw_u == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
+                else { if (gw_u == 0) asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); }
+            }
+            W8_T(q1);
+            __syncthreads();
+            W8_T(q2);
+            // slot B: odd waves multiply rows {1, 3} of chunk c | even waves: patch c + 1 -> rows {0, 2} of chunk c + 1, U of chunk c + 1
+            if (grp == 1) mma();
+            else if (c + 1 < nchunks) { u_fetch(c + 1); transform((c + 1) % 3); }
+            W8_T(q3);
+            __syncthreads();
+            W8_T(q4);
+            W8_ACC(q0, q1, q2, q3, q4)
+        }
+        vm_wait_all();
+#ifdef AWSEG_WS_STAMP
+        if (blockIdx.x == 0 && (tid == 0 || tid == 256)) for (int i = 0; i < 5; ++i) g_w8_stamp[tid >> 8][i] += w8s[i];
+#endif
+#undef W8_T
+#undef W8_ACC
+    };
+
+    run(awseg_false{});
+    if (!BF16) {
+        if (amax > 0.f) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, amax));
+        __syncthreads();
+        const unsigned mx = sMax[0];
+        const int ex = (int)(mx >> 23) & 0xff;
+        const float mf = __builtin_bit_cast(float, mx);
+        if (!(mx == 0u || ex == 0xff || (mf < 8192.0f && mf >= 0.0625f))) {
+            sx = 11 - (ex - 127);
+            sx = sx > 126 ? 126 : sx;
+            xs = pow2f(sx);
+            run(awseg_true{});
+        }
+    }
+
+    // ---- output transform.  This wave holds M[vrow][0..3] (its four positions); Y = A^T M A:
+    //   R_0 = M_i0 + M_i1 + M_i2, R_1 = M_i1 - M_i2 - M_i3 (column factor, in registers), then over the V rows i
+    //   Y[0][b] = R_b(0) + R_b(1) + R_b(2),  Y[1][b] = R_b(1) - R_b(2) - R_b(3)  — through LDS.
+    // exchange layout: float4 [nt][V row][m][b][r >> 2][lane]
+    float* xch = reinterpret_cast<float*>(smem);
+    {
+        float* dst = xch + ((size_t)(nt * 4 + vrow) * 16 * 64 + lane) * 4;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 q0, q1;
+                float* p0 = &q0.x; float* p1 = &q1.x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * r4 + q;
+                    p0[q] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
+                    p1[q] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
+                }
+                *reinterpret_cast<float4*>(dst + ((m * 2 + 0) * 4 + r4) * 64 * 4) = q0;
+                *reinterpret_cast<float4*>(dst + ((m * 2 + 1) * 4 + r4) * 64 * 4) = q1;
+            }
+    }
+    __syncthreads();
+    const int mt = vrow >> 1, oa = vrow & 1;                          // this wave finishes m-tile mt, output row oa
+    const float ysc = uscale * pow2f(-sx);
+    f32x16 y[2];                                                      // [output column b]
+    {
+#pragma unroll
+        for (int bcol = 0; bcol < 2; ++bcol)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 s0, s1, s2;
+                auto ld = [&](int i) {
+                    return *reinterpret_cast<const float4*>(xch + (((size_t)(nt * 4 + i) * 16 + (mt * 2 + bcol) * 4 + r4) * 64 + lane) * 4);
+                };
+                s0 = ld(oa); s1 = ld(oa + 1); s2 = ld(oa + 2);       // oa = 0: rows 0, 1, 2 (+ + +); oa = 1: rows 1, 2, 3 (+ - -)
+                const float* f0 = &s0.x; const float* f1 = &s1.x; const float* f2 = &s2.x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[bcol][4 * r4 + q] = (oa == 0 ? f0[q] + f1[q] + f2[q] : f0[q] - f1[q] - f2[q]) * ysc;
+            }
+    }
+
+    if (MODE == 0) {
+        // rows = tiles of m-tile mt (tile row 4 mt + (r >> 2), tile column 4 hk + (r & 3)), columns (lanes) = couts; output row 2 ty + oa
+        const int n = n0 + nt * 32 + li;
+        const float sh = a.shift[n];
+        const size_t img = (size_t)a.H * a.W * a.Cout;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img), 0, (int)(img * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual ? a.residual + (size_t)b * img : a.out), 0, a.residual ? (int)(img * 4) : 0, 0x00020000);
+        const int mt_u = __builtin_amdgcn_readfirstlane(mt), oa_u = __builtin_amdgcn_readfirstlane(oa);
+        const uint32_t kOob = 0x80000000u;
+        uint32_t vsel[4][2];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + bb);
+                const int xl = a.dil * 8 * hk;
+                vsel[c][bb] = (xs0 + xl < a.W) ? (uint32_t)((xl * a.Cout + n) * 4) : kOob;
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ty = mt_u * 4 + (r >> 2), c = r & 3;
+            const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + oa_u);
+            if (yy >= a.H) continue;                                 // wave-uniform
+#pragma unroll
+            for (int bb = 0; bb < 2; ++bb) {
+                const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + bb);
+                const uint32_t soff = (uint32_t)((yy * a.W + xs0) * a.Cout * 4);
+                float v = y[bb][r] + sh;
+                v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vsel[c][bb], soff, 0));   // zero-record descriptor without a residual
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, act_apply(v, a.act)), o_rsrc, vsel[c][bb], soff, 0);
+            }
+        }
+    } else {
+        // rows = couts n0 + 32 nt + (r & 3) + 8 (r >> 2) + 4 hk, columns (lanes) = tiles of m-tile mt (tile = 32 mt + li); output row oa
+        float z[2] = {0.f, 0.f};
+        float shv[16], wv[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = n0 + nt * 32 + 8 * g4 + 4 * hk;
+            const float4 s4 = *reinterpret_cast<const float4*>(a.shift + co), w4 = *reinterpret_cast<const float4*>(a.w2 + co);
+            shv[4 * g4] = s4.x; shv[4 * g4 + 1] = s4.y; shv[4 * g4 + 2] = s4.z; shv[4 * g4 + 3] = s4.w;
+            wv[4 * g4] = w4.x; wv[4 * g4 + 1] = w4.y; wv[4 * g4 + 2] = w4.z; wv[4 * g4 + 3] = w4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) z[o] += fmaxf(y[o][r] + shv[r], 0.f) * wv[r];
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) z[o] += __shfl_xor(z[o], 32, 64);
+        __syncthreads();                                             // every wave has read its exchange data
+        float* red = reinterpret_cast<float*>(smem);                 // [nt][tile][output row][2]
+        if (hk == 0) *reinterpret_cast<float2*>(red + ((nt * NTILE + mt * 32 + li) * 2 + oa) * 2) = make_float2(z[0], z[1]);
+        __syncthreads();
+        if (tid < 256) {
+            const int tile = tid >> 2, q = tid & 3;                  // q = 2 * output row + output column
+            const int uy = by * 2 * TB + 2 * (tile >> 3) + (q >> 1), ux = bx * 2 * TB + 2 * (tile & 7) + (q & 1);
+            const int yy = ry + a.dil * uy, xx = rx + a.dil * ux;
+            if (yy < a.H && xx < a.W) {
+                const float zz = red[tile * 4 + q] + red[(NTILE + tile) * 4 + q] + a.b2[0];
+                a.out[((int64_t)b * a.H + yy) * a.W + xx] = 1.0f / (1.0f + expf(-zz));
+            }
+        }
+    }
+}
+
+
+// (Measured and dropped in round 3: the same block on SIXTEEN waves of 128 registers — wave = 2 positions x 64 tiles x 32 couts, every
+// slot all 1 024 threads share the transform (item = tile x channel pair x one V row), eight waves multiply.  Correct on the first
+// run and 5-10 % slower than this kernel on every shape: 4, 8 and 16 waves all land at ~5 000 cycles per chunk, with MFMA 32 %,
+// LDS 40-48 % and vector ALU 28 % busy (profiles/r03_pmc_winograd_lds.csv) — the pipes take turns instead of overlapping.)
+
 template <int MODE, bool BF16>
 int launch_ws(const ws_args& a, hipStream_t s)
 {
-    auto kern = wino_split_kernel<MODE, BF16>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    if (e != hipSuccess) return (int)e;
+    static int w8 = -1;                                              // AWSEG_WINO8=0: the four-wave kernel of round 2 (A/B measurements)
+    if (w8 < 0) { const char* e = getenv("AWSEG_WINO8"); w8 = e ? atoi(e) : 1; }
     const int64_t tiles = (int64_t)a.nbx * a.dil * a.nby * a.dil * a.batch;
     const int64_t nblocks = ((tiles + 7) / 8) * a.ngroups * 8;
     if (nblocks >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
+    if (w8) {
+        static int span_env = -1;
+        if (span_env < 0) { const char* e = getenv("AWSEG_WINO8_SPAN"); span_env = e ? atoi(e) : 0; }
+        ws_args a8 = a;
+        const int64_t tiles_x = (tiles + 7) / 8;                        // spatial tiles per XCD
+        int span = span_env > 0 ? span_env : 1;
+        if (span > tiles_x) span = (int)tiles_x;
+        while (tiles_x % span) --span;                                   // whole spans only (the grid stays a rectangle)
+        a8.span = span;
+        auto k8 = wino8_kernel<MODE, BF16>;
+        constexpr int LDS8 = (LDS_BYTES > X_BYTES ? LDS_BYTES : X_BYTES);
+        hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+        if (e8 != hipSuccess) return (int)e8;
+        hipLaunchKernelGGL(k8, dim3((unsigned)nblocks), dim3(W8T), LDS8, s, a8);
+        AWSEG_LAUNCH_CHECK();
+        return 0;
+    }
+    auto kern = wino_split_kernel<MODE, BF16>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kern, dim3((unsigned)nblocks), dim3(WT), LDS_BYTES, s, a);
     AWSEG_LAUNCH_CHECK();
     return 0;
@@ -597,6 +1029,7 @@ int ws_entry(bool bf16, const float* x, int batch, int height, int width, int ci
     const int hs = (height + dilation - 1) / dilation, ws = (width + dilation - 1) / dilation;
     a.nbx = (ws + 2 * TB - 1) / (2 * TB); a.nby = (hs + 2 * TB - 1) / (2 * TB); a.ngroups = cout / NB; a.batch = batch;
     a.u_halfs = (int64_t)16 * cin * cout * 2;
+    a.span = 1;
     if (bf16) return w2 ? launch_ws<1, true>(a, awseg_s(stream)) : launch_ws<0, true>(a, awseg_s(stream));
     return w2 ? launch_ws<1, false>(a, awseg_s(stream)) : launch_ws<0, false>(a, awseg_s(stream));
 }

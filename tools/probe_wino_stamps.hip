@@ -38,6 +38,16 @@ static void run(int B, int H, int W, int cin, int cout, int dil, bool head)
     printf("  per chunk (s_memtime ticks): slot A work %.0f | barrier A %.0f | slot B work %.0f | barrier B %.0f | total %.0f;  prologue %llu, whole block %llu\n",
            r[0] / n, r[1] / n, r[2] / n, r[3] / n, (r[0] + r[1] + r[2] + r[3]) / n, r[5], r[7]);
     printf("  slot A in detail: vmcnt wait %.0f | DMA issue %.0f | position group 0 %.0f | group 1 %.0f | group 2 %.0f\n", r2[0] / n, r2[1] / n, r2[2] / n, r2[3] / n, r2[4] / n);
+    unsigned long long w8[2][8];
+    hipMemcpyFromSymbol(w8, HIP_SYMBOL(g_w8_stamp), sizeof w8);
+    for (int g = 0; g < 2; ++g) {
+        const double m = (double)w8[g][4];
+        if (m > 0) printf("  8-wave kernel, block 0 wave %d (%s rows): per chunk: slot A work %.0f | barrier A %.0f | slot B work %.0f | barrier B %.0f | total %.0f (%.0f chunks)\n",
+                          4 * g, g ? "odd: A = DMA + U + transform, B = MFMA" : "even: A = MFMA, B = U + transform", w8[g][0] / m, w8[g][1] / m, w8[g][2] / m, w8[g][3] / m,
+                          (w8[g][0] + w8[g][1] + w8[g][2] + w8[g][3]) / m, m);
+    }
+    unsigned long long z2[2][8]; memset(z2, 0, sizeof z2);
+    hipMemcpyToSymbol(HIP_SYMBOL(g_w8_stamp), z2, sizeof z2);
     hipFree(x); hipFree(o); hipFree(sh); hipFree(w2); hipFree(b2); hipFree(u);
 }
 

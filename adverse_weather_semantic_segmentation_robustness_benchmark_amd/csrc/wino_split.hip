@@ -693,16 +693,20 @@ void wino8_kernel(ws_args a)
         auto transform = [&](int slot) {
             const unsigned char* pp = sP + slot * P_BYTES + prd;
             auto load_row = [&](int i, v2f (&d)[2][4]) {               // input row i of the tile's 4 x 4 patch, both channel pairs
+                // ONE 16-byte read per pixel (the quad's four channels are contiguous in the pixel-major patch): the four lanes of
+                // a tile cover 64 contiguous bytes and 16 lanes 256 — conflict-free, where the two 8-byte reads per pixel of the
+                // four-wave kernel are 2-way conflicted (a fifth of its LDS cycles)
 #pragma unroll
-                for (int e = 0; e < 2; ++e)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v2f v = *reinterpret_cast<const v2f*>(pp + e * 8 + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
-                        if (BF16) {
-                        } else if (!SCALED) amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v.x)), __builtin_fabsf(v.y));
-                        else v = v * v2f{xs, xs};
-                        d[e][j] = v;
-                    }
+                for (int j = 0; j < 4; ++j) {
+                    const float4 q = *reinterpret_cast<const float4*>(pp + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
+                    v2f v0 = {q.x, q.y}, v1 = {q.z, q.w};
+                    if (BF16) {
+                    } else if (!SCALED) {
+                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v0.x)), __builtin_fabsf(v0.y));
+                        amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v1.x)), __builtin_fabsf(v1.y));
+                    } else { v0 = v0 * v2f{xs, xs}; v1 = v1 * v2f{xs, xs}; }
+                    d[0][j] = v0; d[1][j] = v1;
+                }
             };
             auto cols_store = [&](int vr, const v2f (&tt)[2][4]) {     // row vr of (B^T d) -> positions 4 vr .. 4 vr + 3, split, stored
 #pragma unroll

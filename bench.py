@@ -125,6 +125,22 @@ def launch_work(name, args):
         return "hbm", 4.0 * npx * c * (3 if res is not None else 2)
     if name == "awseg_layernorm_rows":
         return "hbm", 8.0 * args[1] * args[2]            # (x, n_rows, C, ...)
+    # ---- training step (BASELINE configs[3]) ----
+    if name == "awseg_upconv3x3_adjoint":
+        # (dz, batch, cmid, h, w, height, width, dg9): ONE read of the full-resolution gradient map; the low-resolution output is noise beside it
+        _, b, cmid, _, _, hh, ww = args[:7]
+        return "hbm", 4.0 * b * cmid * hh * ww
+    if name == "awseg_upconv3x3_linear":
+        # (g9, batch, cmid, h, w, height, width, ...): the write of the full-resolution pre-activation map
+        _, b, cmid, _, _, hh, ww = args[:7]
+        return "hbm", 4.0 * b * cmid * hh * ww
+    if name == "awseg_fog_ce_forward":
+        # (logits, label, label_dtype, density, batch, C, hw, ...): logits + label + density in
+        b, c, hw = args[4:7]
+        return "hbm", float(b) * hw * (4 * c + 1 + 4)
+    if name == "awseg_fog_ce_backward":
+        b, c, hw = args[4:7]
+        return "hbm", float(b) * hw * (8 * c + 1 + 4)
     return None
 
 
@@ -248,6 +264,45 @@ def cpu_baseline(model, H, W, C, seed=0, fwd_div=1, max_threads=16):
                       f"({cores} torch threads); oracle argmax+confusion on 1 frame {H}x{W} ({t_metric:.2f} s, 1 thread)"}
 
 
+def cpu_train_baseline(model, H, W, C, div=8, max_threads=16):
+    """One optimisation step of the AS-WRITTEN graph on the host cores (torch-CPU autograd: F.interpolate -> Conv2d heads,
+    module ASPP, cross_entropy * (1 + 2 density) + 0.1 MSE depth, clip, AdamW) on a batch of 2 frames of (H/div)x(W/div),
+    time scaled by div^2 (convolution cost is linear in pixels).  A reported baseline, not the optimisation target."""
+    import copy
+    import torch.nn.functional as F
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, max_threads))
+    torch.set_num_threads(cores)
+    m = copy.deepcopy(model).cpu().train()
+    for mod in m.modules():
+        mod.fused_eval = False
+        mod.fused_train = False
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.01)
+    h, w, nb = H // div, W // div, 2
+    g = torch.Generator().manual_seed(0)
+
+    def one(hh, ww):
+        x = torch.randn(nb, 3, hh, ww, generator=g)
+        lab = torch.randint(0, C, (nb, hh, ww), generator=g)
+        dens, dep = torch.rand(nb, hh, ww, generator=g), torch.rand(nb, hh, ww, generator=g)
+        opt.zero_grad()
+        out = m(x)
+        loss = (F.cross_entropy(out["segmentation"], lab, reduction="none") * (1.0 + 2.0 * dens)).mean() + 0.1 * F.mse_loss(out["depth"].squeeze(1), dep)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
+        opt.step()
+    one(64, 64)                                              # warm-up (thread pool, allocator, optimizer state)
+    t0 = time.perf_counter()
+    one(h, w)
+    dt = (time.perf_counter() - t0) * div * div / nb
+    return {"value": round(1.0 / dt, 5), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"one as-written torch-CPU optimisation step (forward + loss + backward + clip + AdamW) on {nb} frames of {h}x{w}, x{div * div} "
+                      f"= {dt:.1f} s/frame ({cores} torch threads)"}
+
+
 GLOBAL_FRAMES = 160          # SURVEY §8(d): C2 / C3 evaluate N = 160 frames (8 GPUs x 5 conditions x 4)
 CONDITIONS = ["clean", "fog", "rain", "snow", "night"]
 
@@ -264,6 +319,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-depth", action="store_true", help="build the ensemble with include_depth=False")
     ap.add_argument("--no-stats", action="store_true", help="leave ECE + disagreement-AUROC accumulation (evaluate.py:230-255) out of the step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--resident", action="store_true",
+                    help="time the step on frames that are already resident in HBM (round-2 behaviour) instead of ingesting every batch from "
+                         "pinned host memory on a side stream (REF/scripts/evaluate.py:172-173 starts each batch from host memory)")
+    ap.add_argument("--resident-steps", type=int, default=5, help="steps of the resident-frames comparison pass (0: skip)")
     ap.add_argument("--no-parity-pass", action="store_true", help="skip the untimed pass over the whole global sample set (miou is then the timed region's)")
     ap.add_argument("--kernel-steps", type=int, default=2, help="steps of the untimed per-kernel HIP-event pass (0: no roofline / kernels)")
     ap.add_argument("--fp32-steps", type=int, default=3, help="steps of the float32-input-MFMA comparison pass at N=1 (0: skip)")
@@ -424,6 +483,41 @@ def train_main(args):
     if parallel.is_dist():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
     dt = float(tmax.item())
+    # ---- per-kernel pass (untimed): HIP event pairs around every C-ABI launch of ONE more step -> roofline of the dominant
+    # hand-written kernel (the convolutions' forward / backward run on MIOpen: profiles/r03_train_step_kernels.csv lists them)
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd import _native
+    _native.launch_hook = CLOCK.hook
+    kernels, roofline = [], None
+    if args.kernel_steps > 0:
+        trainer.train_loader = Batches(args.warmup + args.steps, 1)
+        torch.cuda.synchronize()
+        CLOCK.enabled = True
+        trainer.train_epoch()
+        torch.cuda.synchronize()
+        CLOCK.enabled = False
+        step_ms_t = dt / args.steps * 1e3
+        for name, (count, avg_ms, own_work) in CLOCK.summary().items():
+            if own_work is None:                             # (the per-condition weather launches cover 1-2 frames each here: priced in the eval line)
+                continue
+            bound, work = own_work
+            if work <= 0 or avg_ms <= 0:
+                continue
+            achieved, peak, unit = work / (avg_ms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s"
+            kernels.append({"kernel": name, "launches_per_step": count, "avg_ms": round(avg_ms, 4), "bound": bound, "achieved": round(achieved, 2),
+                            "peak": peak, "unit": unit, "frac": round(achieved / peak, 4), "time_share_of_step": round(count * avg_ms / step_ms_t, 4)})
+        kernels.sort(key=lambda k: -k["launches_per_step"] * k["avg_ms"])
+        if kernels:
+            k0 = kernels[0]
+            roofline = {"kernel": k0["kernel"], "bound": "hbm", "achieved": k0["achieved"], "peak": k0["peak"], "unit": k0["unit"], "frac": k0["frac"],
+                        "traffic": None, "traffic_source": None,
+                        "measured": "HIP events around each launch on the launching stream, one untimed step after the timed region; dominant HAND-WRITTEN "
+                                    "kernel (the forward / backward convolutions are MIOpen's: profiles/r03_train_step_kernels.csv)"}
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_train_baseline(model, H, W, C)
+        except Exception as e:  # noqa: BLE001
+            cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
     if rank == 0:
         line = {
             "metric": f"images/sec ({H}x{W}, AdverseWeatherTrainer train step: ensemble + FogDensityAwareLoss + depth heads)",
@@ -436,7 +530,7 @@ def train_main(args):
                                            "Normalize and depth target on HIP kernels", "dist_backend": backend,
                        "gradient_all_reduce": "flat float32 buckets of 32 MB, launched from post-accumulate-grad hooks during backward"},
             "rccl_ranks": world if backend == "nccl" else 0,
-            "roofline": None, "cpu_baseline": None,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
             "losses": {k: round(float(v), 6) for k, v in res.items()},
         }
@@ -518,14 +612,16 @@ def main():
     def new_state():
         return EvalState(metrics, CONDITIONS, dev, 15, ensemble=True)
 
-    def run_frames(st, local_idx):
-        """One step over the rank's resident frames `local_idx` (positions in its block)."""
+    def run_frames(st, local_idx, buffers=None):
+        """One step over the rank's frames `local_idx` (positions in its block): resident in HBM, or — `buffers` — just ingested."""
         ids = [mine[k] for k in local_idx]
         conds = [CONDITIONS[g % len(CONDITIONS)] for g in ids]
         info.update({"awseg_fog_fused": conds.count("fog"), "awseg_night_apply": conds.count("night"),
                      "awseg_rain_apply": conds.count("rain"), "awseg_snow_apply": conds.count("snow"),
                      "awseg_normalize": conds.count("clean"), "awseg_weather_batch": len(ids)})
-        if local_idx == list(range(local_idx[0], local_idx[0] + len(local_idx))):
+        if buffers is not None:
+            r, l = buffers[0][:len(local_idx)], buffers[1][:len(local_idx)]
+        elif local_idx == list(range(local_idx[0], local_idx[0] + len(local_idx))):
             r, l = raw[local_idx[0]:local_idx[0] + len(local_idx)], labels[local_idx[0]:local_idx[0] + len(local_idx)]
         else:
             # a batch that wraps around the rank's block: gather it (index built on the host and copied without a
@@ -536,8 +632,50 @@ def main():
         tf.apply_batch(r, conds, norm_out=img, frame_ids=ids)
         eval_batch(model, st, img, l, conds, metrics, with_stats=with_stats)
 
+    # ---- ingestion (REF/scripts/evaluate.py:172-173: every batch starts in host memory).  The rank's frames + labels also live in
+    # PINNED host memory; step i runs on a device double buffer that a side stream filled during step i-1 (uint8: 6.3 + 2.1 MB per
+    # frame, ~70 MB per batch of 8 at ~50 GB/s = 1.4 ms of a 44 ms step, off the compute stream), and the copy of batch i+1 is
+    # enqueued before step i's kernels.
+    ingest = not args.resident
+    if ingest:
+        host_raw, host_lab = raw.cpu().pin_memory(), labels.cpu().pin_memory()
+        dbuf = [(torch.empty(B, H, W, 3, dtype=torch.uint8, device=dev), torch.empty(B, H, W, dtype=torch.uint8, device=dev)) for _ in range(2)]
+        copy_stream = torch.cuda.Stream(device=dev)
+        copied = [torch.cuda.Event(), torch.cuda.Event()]
+        consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        staged = [None, None]                         # step index whose batch each buffer holds (or is receiving)
+
+        def enqueue_copy(i):
+            """host -> device copy of step i's batch into buffer i % 2 on the side stream (after the step that last used it)"""
+            k = i % 2
+            idx = [(i * B + j) % len(mine) for j in range(B)]
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(consumed[k])
+                r, l = dbuf[k]
+                if idx == list(range(idx[0], idx[0] + B)):
+                    r.copy_(host_raw[idx[0]:idx[0] + B], non_blocking=True); l.copy_(host_lab[idx[0]:idx[0] + B], non_blocking=True)
+                else:
+                    for j, g in enumerate(idx):
+                        r[j].copy_(host_raw[g], non_blocking=True); l[j].copy_(host_lab[g], non_blocking=True)
+                copied[k].record(copy_stream)
+            staged[k] = i
+        for k in range(2):
+            consumed[k].record()
+
     def step(st, i):
-        run_frames(st, [(i * B + k) % len(mine) for k in range(B)])
+        idx = [(i * B + k) % len(mine) for k in range(B)]
+        if not ingest or not staging_on[0]:
+            return run_frames(st, idx)
+        k = i % 2
+        if staged[k] != i:
+            enqueue_copy(i)
+        torch.cuda.current_stream().wait_event(copied[k])
+        if staged[1 - k] != i + 1:
+            enqueue_copy(i + 1)                        # next batch travels while this one computes
+        run_frames(st, idx, buffers=dbuf[k])
+        consumed[k].record()
+
+    staging_on = [True]
 
     def finish(st):
         """Counters -> all-reduce -> the result dict (host math of evaluate.py:214-271)."""
@@ -598,6 +736,17 @@ def main():
                     "steps": args.fp32_steps, "what": "same step with attention / 1x1 GEMMs / Winograd on the float32-input MFMA kernels "
                     "(v_mfma_f32_32x32x2_f32, hipBLASLt f32) instead of split-operand f16 MFMA"}
 
+        # ---- resident-frames comparison: the same step without ingestion (the round-1/2 figure) --------------------------------
+        resident = None
+        if ingest and args.resident_steps > 0:
+            staging_on[0] = False
+            st = new_state()
+            step(st, 0)
+            dtr, _ = timed(args.resident_steps, 1)
+            staging_on[0] = True
+            resident = {"value": round(B * args.resident_steps * world / dtr, 3), "unit": "images/s", "ms_per_step": round(dtr / args.resident_steps * 1e3, 3),
+                        "steps": args.resident_steps, "what": "same step on frames already resident in HBM (no host -> device copy)"}
+
     total_images = B * args.steps * world
     step_ms = dt / args.steps * 1e3
 
@@ -649,6 +798,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
             "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world,
                        "global_sample_set": args.frames, "frames_per_rank": len(mine),
+                       "ingest": ("h2d overlapped (pinned host -> HBM double buffer on a side stream, uint8 frames + labels)" if ingest
+                                  else "none (frames resident in HBM)"),
                        "include_depth": not args.no_depth, "eval_stats_in_step": with_stats,
                        "weather_rng": "philox (in-kernel), keyed by global frame index", "ensemble_logits_materialised": False,
                        "split_operand_kernels": split,
@@ -656,7 +807,7 @@ def main():
                        "parallelism": f"batch-sharded x{world}, one counter all-reduce (int64 confusion + ECE bins + AUROC histogram)",
                        "dist_backend": backend},
             "rccl_ranks": world if backend == "nccl" else 0,
-            "roofline": roofline, "cpu_baseline": cpu, "fp32_mfma": fp32, "kernels": kernels,
+            "roofline": roofline, "cpu_baseline": cpu, "fp32_mfma": fp32, "resident_frames": resident if ingest else None, "kernels": kernels,
             "miou": {k: round(float(v), 6) for k, v in results.items()},
             "miou_source": ("parity pass: every frame of the global set exactly once, sharded by parallel.shard_range, counters all-reduced"
                             if not args.no_parity_pass else "timed region"),

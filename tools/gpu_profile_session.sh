@@ -2,7 +2,7 @@
 # tools/make_profiles.py turns the rocprofv3 directories into the committed CSV summaries).
 set -x
 cd $GRAFT_REPO_ROOT
-R=r02
+R=r03
 timeout -k 10 500 python tools/kernel_bench.py --iters 10 > gpurun_out/${R}_kernel_bench_hip_events.log 2>&1; echo "kernel_bench exit $?"
 timeout -k 10 400 python bench.py > gpurun_out/${R}_bench_line_default.json 2> gpurun_out/${R}_bench_line_default.err; echo "bench exit $?"
 timeout -k 10 400 python bench.py --model b5_r101 --no-cpu-baseline > gpurun_out/${R}_bench_line_b5_r101_bf16.json 2> gpurun_out/${R}_bench_line_b5.err; echo "bench b5 exit $?"
@@ -16,13 +16,16 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_kb_trace -o kb -- python3 $K > $O/${R}_prof_kb_trace.log 2>&1; echo "kb trace exit $?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_kb_fetch -o kb -- python3 $K > $O/${R}_prof_kb_fetch.log 2>&1; echo "kb fetch exit $?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_kb_write -o kb -- python3 $K > $O/${R}_prof_kb_write.log 2>&1; echo "kb write exit $?"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_train -o train -- python3 $GRAFT_REPO_ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --kernel-steps 0 > $O/${R}_prof_train.log 2>&1; echo "prof train exit $?"
+cd $GRAFT_REPO_ROOT
+timeout -k 10 500 python bench.py --mode train --steps 3 --warmup 1 > gpurun_out/${R}_bench_line_train_1024x2048_bs8.json 2> gpurun_out/${R}_bench_line_train.err; echo "bench train exit $?"
 du -sh $O/${R}_prof_* | tail -8
 # Afterwards, in the repo (CPU is enough):
-#   python tools/make_profiles.py step gpurun_out/r02_prof_step ensemble_stats_kernel profiles/r02_bench_step_kernels.csv "<header>"
+#   python tools/make_profiles.py step gpurun_out/r03_prof_step ensemble_stats_kernel profiles/r03_bench_step_kernels.csv "<header>"
 #        (marker = a kernel that runs once per step: the one-pass confusion + statistics kernel)
-#   python tools/make_profiles.py kernel-table gpurun_out/r02_prof_step gpurun_out/r02_prof_step_fetch gpurun_out/r02_prof_step_write \
-#        profiles/r02_bench_step_stats_and_traffic.csv "<header>" mean
-#   python tools/make_profiles.py kernel-table gpurun_out/r02_prof_kb_trace gpurun_out/r02_prof_kb_fetch gpurun_out/r02_prof_kb_write \
-#        profiles/r02_kernel_bench_stats_and_traffic.csv "<header>"
-#   cp gpurun_out/r02_kernel_bench_hip_events.log gpurun_out/r02_bench_line_default.json gpurun_out/r02_bench_line_b5_r101_bf16.json profiles/
-#   python tools/make_profiles.py check-log profiles/r02_kernel_bench_hip_events.log
+#   python tools/make_profiles.py kernel-table gpurun_out/r03_prof_step gpurun_out/r03_prof_step_fetch gpurun_out/r03_prof_step_write \
+#        profiles/r03_bench_step_stats_and_traffic.csv "<header>" mean
+#   python tools/make_profiles.py kernel-table gpurun_out/r03_prof_kb_trace gpurun_out/r03_prof_kb_fetch gpurun_out/r03_prof_kb_write \
+#        profiles/r03_kernel_bench_stats_and_traffic.csv "<header>"
+#   cp gpurun_out/r03_kernel_bench_hip_events.log gpurun_out/r03_bench_line_default.json gpurun_out/r03_bench_line_b5_r101_bf16.json profiles/
+#   python tools/make_profiles.py check-log profiles/r03_kernel_bench_hip_events.log

@@ -50,6 +50,7 @@ SIGNATURES = {
     "awseg_gemm_split_weight_halfs": (c_i64, [c_i, c_i]),
     "awseg_gemm_split_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
     "awseg_gemm_bf16_weights": (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    "awseg_gemm_bf16_weight_halfs": (c_i64, [c_i, c_i]),
     "awseg_gemm_bf16_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
     "awseg_conv3x3_winograd_bf16_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "awseg_attention_d32_bf16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),

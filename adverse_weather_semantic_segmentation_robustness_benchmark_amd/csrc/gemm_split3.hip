@@ -84,7 +84,15 @@ struct g3_args {
 
 // ABL != 0: ablation builds for measurements (wrong results, valid times; AWSEG_G3_ABL): 1 no LDS-DMA in the K loop, 2 no MFMAs,
 // 3 no operand split, 4 no activation fragment reads, 5 no weight fragment reads
-template <bool CONV, int ABL = 0>
+// BF16: BASELINE config 5 — ONE v_mfma_f32_32x32x16_bf16 per product tile: the activation fragment is rounded to bf16 (RNE) by the
+// wave that multiplies it, the weights come as a bf16 image [N/256][KB][256][32] (64-byte rows: a 16 KB stage), float32
+// accumulation and epilogue; bf16 has float32's exponent range: no range guard, no scaling.
+typedef __bf16 bf8_3 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf2_3 __attribute__((ext_vector_type(2)));
+typedef float f2_3 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_3(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2_3{x, y}, bf2_3)); }
+
+template <bool CONV, int ABL = 0, bool BF16 = false>
 __global__ __launch_bounds__(G3T, 2)
 void gemm_split3_kernel(g3_args a)
 {
@@ -116,7 +124,8 @@ void gemm_split3_kernel(g3_args a)
         const int64_t xbytes = rows_left * (int64_t)K * 4;
         if (CONV) x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
         else x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * K), 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
-        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * kb * 64), 0, G3N * kb * 128, 0x00020000);   // n-tile n0 / 256: kb blocks of 32 KB
+        if (BF16) w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * kb * 32), 0, G3N * kb * 64, 0x00020000);
+        else w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * kb * 64), 0, G3N * kb * 128, 0x00020000);   // n-tile n0 / 256: kb blocks of 32 KB
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 8 * (4 * wave + j) + rl;
@@ -124,6 +133,10 @@ void gemm_split3_kernel(g3_args a)
             a_voff[j] = (uint32_t)(row * K * 4 + c * 16);
             b_voff[j] = (uint32_t)(row * 128 + c * 16);             // inside the K tile's contiguous 32 KB (256 rows x 128 B)
             a_voff_last[j] = (ktail == 0 || c * 4 < ktail) ? a_voff[j] : 0x80000000u;     // chunks past K read zeros (the weight image is zero there too)
+            if (BF16) {                                            // 64-byte weight rows: instruction 2 wave + j covers 16 rows, lane -> row 16 q + (l >> 2), slot l & 3
+                const int brow = 16 * (2 * wave + j) + (lane >> 2);
+                b_voff[j] = (uint32_t)(brow * 64 + (((lane & 3) ^ ((brow >> 2) & 3)) * 16));
+            }
             if (CONV) {
                 a_voff[j] = (uint32_t)(c * 16);
                 const int64_t m = m0 + row;
@@ -151,8 +164,14 @@ void gemm_split3_kernel(g3_args a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma16(x_rsrc, kt == nkt - 1 ? a_voff_last[j] : a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
         }
+        if (BF16) {
+            const uint32_t lb2 = lds0 + (uint32_t)(G3_B0 + stage * G3_STAGE) + wave_u * 2048u;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * 16384), lb2 + (uint32_t)(j * 1024));
+        } else {
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * 32768), lb + (uint32_t)(j * 1024));
+        }
     };
 
     // ---- fragment addresses: row li of a 32-row MFMA tile, k = 16 ks + 8 hk .. + 7.  Activations (rows 32 wave + li): float32,
@@ -164,7 +183,7 @@ void gemm_split3_kernel(g3_args a)
     for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
         for (int e = 0; e < 2; ++e) fa[ks][e] = G3_A0 + (wave * 32 + li) * 128 + (((4 * ks + 2 * hk + e) ^ sw) * 16);
-        fb[ks][0] = G3_B0 + li * 128 + (((2 * ks + hk) ^ sw) * 16);
+        fb[ks][0] = BF16 ? G3_B0 + li * 64 + (((2 * ks + hk) ^ ((li >> 2) & 3)) * 16) : G3_B0 + li * 128 + (((2 * ks + hk) ^ sw) * 16);
         fb[ks][1] = G3_B0 + li * 128 + (((4 + 2 * ks + hk) ^ sw) * 16);
     }
 
@@ -223,10 +242,18 @@ void gemm_split3_kernel(g3_args a)
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     if (ABL == 5) { Bh[j] = h8{(_Float16)t, (_Float16)j, 1, 2, 3, 4, 5, 6}; Bl[j] = h8{(_Float16)ks, (_Float16)j, 1, 2, 3, 4, 5, 6}; continue; }
+                    if (BF16) { Bh[j] = *reinterpret_cast<const h8*>(sa + fb[ks][0] + j * 2048); Bl[j] = Bh[j]; continue; }
                     Bh[j] = *reinterpret_cast<const h8*>(sa + fb[ks][0] + j * 4096);
                     Bl[j] = *reinterpret_cast<const h8*>(sa + fb[ks][1] + j * 4096);
                 }
                 u32x4 H, L; unsigned h, l;
+                if (BF16) {
+                    H[0] = pack_bf16_3(p[0], p[1]); H[1] = pack_bf16_3(p[2], p[3]); H[2] = pack_bf16_3(q[0], q[1]); H[3] = pack_bf16_3(q[2], q[3]);
+                    const bf8_3 Ab = __builtin_bit_cast(bf8_3, H);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, __builtin_bit_cast(bf8_3, Bh[j]), acc[j], 0, 0, 0);
+                    continue;
+                }
                 amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(p[0])), __builtin_fabsf(p[1]));
                 amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(p[2])), __builtin_fabsf(p[3]));
                 amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(q[0])), __builtin_fabsf(q[1]));
@@ -257,7 +284,7 @@ void gemm_split3_kernel(g3_args a)
         }
 
         // ---- range guard (gemm_split.hip): the block's max|x| of this pass, through LDS
-        if (!scaled && amax >= kSplitLimit3) atomicMax(&sMax[par], __builtin_bit_cast(unsigned, amax));
+        if (!BF16 && !scaled && amax >= kSplitLimit3) atomicMax(&sMax[par], __builtin_bit_cast(unsigned, amax));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                              // also: every wave is done with the last K tile's stage
         const unsigned mx = sMax[par];
@@ -280,7 +307,7 @@ void gemm_split3_kernel(g3_args a)
         const int64_t em0 = m0; const int en0 = n0;
         if (has_next) { point(nm0, nn0); issue(ktile(0), g & 1); }
 
-        const int oe = we + xe;
+        const int oe = BF16 ? 0 : we + xe;
         const int oe1 = oe / 2, oe2 = oe - oe1;
         const float os1 = pow2f3(oe1 < -126 ? -126 : (oe1 > 127 ? 127 : oe1)), os2 = pow2f3(oe2 < -126 ? -126 : (oe2 > 127 ? 127 : oe2));
 
@@ -392,7 +419,29 @@ void split3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, i
     d[32] = __builtin_bit_cast(uint16_t, l0); d[33] = __builtin_bit_cast(uint16_t, l1);
 }
 
+__global__ __launch_bounds__(256)
+void bf16_3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, int kb, uint16_t* __restrict__ out)
+{
+    const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
+    const int kp = kb * 32;
+    if (i >= (int64_t)n_rows * kp) return;
+    const int64_t n = i / kp;
+    const int k = (int)(i - n * kp);
+    const unsigned pr = pack_bf16_3(k < k_dim ? w[n * k_dim + k] : 0.f, k + 1 < k_dim ? w[n * k_dim + k + 1] : 0.f);
+    uint16_t* d = out + (((n >> 8) * kb + (k >> 5)) * 256 + (n & 255)) * 32 + (k & 31);
+    d[0] = (uint16_t)pr; d[1] = (uint16_t)(pr >> 16);
+}
+
 }  // namespace
+
+int awseg_gemm_bf16_3_weights(const float* w, int n, int k, uint16_t* w3, hipStream_t stream)
+{
+    const int kb = (k + 31) / 32;
+    const int64_t ne = (int64_t)n * kb * 32;
+    hipLaunchKernelGGL(bf16_3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, n, k, kb, w3);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
 
 // Called by awseg_gemm_split_weights once the classic image and the trailer {max|w| bits, ew} are written (same stream).
 int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const unsigned* trailer, hipStream_t stream)
@@ -413,7 +462,7 @@ bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const vo
 }
 
 int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned* trailer, const float* bias, const float* residual,
-                             int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv)
+                             int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv, bool bf16)
 {
     g3_args a;
     a.cH = a.cW = a.cC = a.cHo = a.cWo = a.ckw = a.cs = 1; a.cp = 0; a.cd = 1; a.x_bytes = 0;
@@ -446,13 +495,23 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("AWSEG_G3_ABL"); abl = e ? atoi(e) : 0; }
     if (abl && !conv) {
-#define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a); break; }
+#define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a); break; }
         switch (abl) { G3_ABL(1) G3_ABL(2) G3_ABL(3) G3_ABL(4) G3_ABL(5) default: break; }
 #undef G3_ABL
         AWSEG_LAUNCH_CHECK();
         return 0;
     }
-    if (conv) hipLaunchKernelGGL(gemm_split3_kernel<true>, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
+    if (bf16) {
+        auto kb16 = gemm_split3_kernel<false, 0, true>;
+        static bool attr16 = false;
+        if (!attr16) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kb16), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
+            if (e != hipSuccess) return (int)e;
+            attr16 = true;
+        }
+        hipLaunchKernelGGL(kb16, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
+    }
+    else if (conv) hipLaunchKernelGGL(gemm_split3_kernel<true>, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
     else hipLaunchKernelGGL(gemm_split3_kernel<false>, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
     AWSEG_LAUNCH_CHECK();
     return 0;

@@ -763,7 +763,7 @@ def gemm_bf16_weights(w: torch.Tensor) -> torch.Tensor:
     """w float32 [N,K] -> int16 view [2,N,K] of a buffer with a 16-byte trailer (plane 0 = bf16(w), plane 1 unused)."""
     w = w.contiguous()
     n, k = w.shape
-    buf = torch.zeros(2 * n * k + 8, dtype=torch.int16, device=w.device)
+    buf = torch.zeros(int(N.lib().awseg_gemm_bf16_weight_halfs(n, k)), dtype=torch.int16, device=w.device)
     N.call("awseg_gemm_bf16_weights", N.ptr(w), n, k, N.ptr(buf), N.stream())
     return buf[:2 * n * k].view(2, n, k)
 

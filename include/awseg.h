@@ -525,6 +525,9 @@ int awseg_conv_gemm_split_bias_act(const float* x, int64_t batch, int height, in
  *   awseg_conv3x3_winograd_bf16_nhwc                    <->  awseg_conv3x3_winograd_split_nhwc
  *       (u_bf16: the same image with bf16(U * 2^-eu) in the "high" slots; the "low" slots are not read)
  *   awseg_attention_d32_bf16                            <->  awseg_attention_d32_split */
+/* uint16 the awseg_gemm_bf16_weights buffer must hold: 2NK + 8, plus N ceil32(K) for the k-blocked bf16 image
+ * [N/256][ceil(K/32)][256][32] that csrc/gemm_split3.hip streams into LDS (N % 256 == 0, K % 8 == 0). */
+int64_t awseg_gemm_bf16_weight_halfs(int n, int k);
 int awseg_gemm_bf16_weights(const float* w, int n, int k, uint16_t* w_bf16, awseg_stream_t stream);
 int awseg_gemm_bf16_bias_act(const float* x, const uint16_t* w_bf16, const float* bias, const float* residual, int act,
                              float* out, int64_t m, int n, int k, awseg_stream_t stream);

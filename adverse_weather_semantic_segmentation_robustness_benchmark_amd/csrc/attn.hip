@@ -28,6 +28,9 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int AT = 256;          // threads
+#ifndef AWSEG_ATTN_SPLIT_WAVES
+#define AWSEG_ATTN_SPLIT_WAVES 2      // minimum waves per SIMD asked of the split-operand kernel (4 was measured: see DESIGN.md)
+#endif
 constexpr int D = 32;            // head dim
 constexpr int TK = 32;           // keys per tile
 constexpr int LDK = 36;          // padded row length (floats): conflict-free ds_read_b128 at a 144-byte lane stride
@@ -438,7 +441,7 @@ __device__ __forceinline__ int guard_exponent(unsigned maxbits)
     return ex - 127 - 13;
 }
 
-__global__ __launch_bounds__(AT, 2)
+__global__ __launch_bounds__(AT, AWSEG_ATTN_SPLIT_WAVES)
 void attention_d32_split_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                 float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
 {

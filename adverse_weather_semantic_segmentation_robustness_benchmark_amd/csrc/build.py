@@ -21,7 +21,7 @@ SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "b
 ARCH = "gfx950"
 # per-file extras.  wino.hip: the SLP vectoriser packs the scalar inverse transform of the fused-head epilogue into
 # v_pk_add_f32 fed by ~220 v_mov (and spills); the kernel packs by hand where adjacent registers make it free.
-EXTRA_FLAGS = {"wino.hip": ["-fno-slp-vectorize"], "wino_split.hip": ["-fno-slp-vectorize", "-DAWSEG_WS_ASM_PK"]}
+EXTRA_FLAGS = {"attn.hip": ["-DAWSEG_ATTN_SPLIT_WAVES=" + os.environ.get("AWSEG_ATTN_SPLIT_WAVES", "2")], "wino.hip": ["-fno-slp-vectorize"], "wino_split.hip": ["-fno-slp-vectorize", "-DAWSEG_WS_ASM_PK"]}
 
 
 def hipcc() -> str:

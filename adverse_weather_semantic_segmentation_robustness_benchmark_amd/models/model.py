@@ -23,7 +23,7 @@ import torch.nn.functional as F
 from .. import _native as N
 from .. import ops
 from . import fused
-from .deeplab import DeepLabV3Plus, _bn_fold
+from .deeplab import Conv2d, DeepLabV3Plus, _bn_fold
 
 logger = logging.getLogger(__name__)
 
@@ -89,7 +89,7 @@ class DepthEstimationHead(nn.Module):
             nn.Conv2d(hidden_channels, hidden_channels // 2, kernel_size=3, padding=1),
             nn.BatchNorm2d(hidden_channels // 2),
             nn.ReLU(inplace=True),
-            nn.Conv2d(hidden_channels // 2, out_channels, kernel_size=1),
+            Conv2d(hidden_channels // 2, out_channels, kernel_size=1),
             nn.Sigmoid())
         for m in self.modules():
             if isinstance(m, nn.Conv2d):
@@ -177,7 +177,7 @@ class SegFormerModel(nn.Module):
             nn.BatchNorm2d(256),
             nn.ReLU(inplace=True),
             nn.Dropout2d(0.1),
-            nn.Conv2d(256, num_classes, kernel_size=1))
+            Conv2d(256, num_classes, kernel_size=1))
         if self.include_depth:
             self.depth_head = DepthEstimationHead(in_channels=self.feature_dim, hidden_channels=128, out_channels=1)
         for m in self.segmentation_head.modules():

@@ -133,3 +133,16 @@ def test_c3_two_gpus_over_rccl_reproduce_the_single_gpu_miou(native):
     print("N=1:", one["value"], one["miou"]); print("N=2:", two["value"], two["miou"])
     assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["config"]["dist_backend"] == "nccl"
     assert one["miou"] == two["miou"], "pooled mIoU dict differs between 1 and 2 GPUs"
+
+
+@pytest.mark.parametrize("env", [{"AWSEG_WINO8": "0"}, {"AWSEG_GEMM_SPLIT_V3": "0"}])
+def test_round2_kernels_stay_selectable_and_correct(env):
+    """The round-2 kernels (four-wave split-operand Winograd; register-staged split GEMM) remain behind environment switches for
+    A/B measurements (tools/ab_kernel.sh): their own parity tests run in a child process with the switch set (the launchers read
+    it once per process)."""
+    e = dict(os.environ, **env)
+    r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_kernels.py"), "-q", "-x", "-m", "gpu", "-k",
+                        "winograd_split or gemm_split_float32_grade or conv_gemm_split_equals"], env=e, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=600, cwd=str(ROOT))
+    tail = r.stdout.decode()[-600:]
+    assert r.returncode == 0 and " passed" in tail, tail

@@ -7,10 +7,10 @@ timeout -k 10 500 python tools/kernel_bench.py --iters 10 > gpurun_out/${R}_kern
 timeout -k 10 400 python bench.py > gpurun_out/${R}_bench_line_default.json 2> gpurun_out/${R}_bench_line_default.err; echo "bench exit $?"
 timeout -k 10 400 python bench.py --model b5_r101 --no-cpu-baseline > gpurun_out/${R}_bench_line_b5_r101_bf16.json 2> gpurun_out/${R}_bench_line_b5.err; echo "bench b5 exit $?"
 cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass"
+B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0"
 K="$GRAFT_REPO_ROOT/tools/kernel_bench.py --iters 2 --only winograd,gemm_l4,gemm_aspp,combine,fog,night,rain,snow,normalize,segformer_head,stats,ece,aspp_dep,dwconv"
 O=$GRAFT_REPO_ROOT/gpurun_out
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_step -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass > $O/${R}_prof_step.log 2>&1; echo "prof step exit $?"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_step -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0 > $O/${R}_prof_step.log 2>&1; echo "prof step exit $?"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_step_fetch -o step -- python3 $B > $O/${R}_prof_step_fetch.log 2>&1; echo "step fetch exit $?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_step_write -o step -- python3 $B > $O/${R}_prof_step_write.log 2>&1; echo "step write exit $?"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_kb_trace -o kb -- python3 $K > $O/${R}_prof_kb_trace.log 2>&1; echo "kb trace exit $?"

@@ -18,7 +18,7 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_kb_write -o kb -- python3 $K > $O/${R}_prof_kb_write.log 2>&1; echo "kb write exit $?"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_train -o train -- python3 $GRAFT_REPO_ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --kernel-steps 0 > $O/${R}_prof_train.log 2>&1; echo "prof train exit $?"
 cd $GRAFT_REPO_ROOT
-timeout -k 10 500 python bench.py --mode train --steps 3 --warmup 1 > gpurun_out/${R}_bench_line_train_1024x2048_bs8.json 2> gpurun_out/${R}_bench_line_train.err; echo "bench train exit $?"
+timeout -k 10 500 python bench.py --mode train --steps 3 --warmup 2 > gpurun_out/${R}_bench_line_train_1024x2048_bs8.json 2> gpurun_out/${R}_bench_line_train.err; echo "bench train exit $?"
 du -sh $O/${R}_prof_* | tail -8
 # Afterwards, in the repo (CPU is enough):
 #   python tools/make_profiles.py step gpurun_out/r03_prof_step ensemble_stats_kernel profiles/r03_bench_step_kernels.csv "<header>"

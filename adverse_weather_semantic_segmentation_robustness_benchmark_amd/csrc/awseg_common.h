@@ -102,4 +102,5 @@ int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const 
 bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const void* out, const void* residual, const void* bias);
 int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned* trailer, const float* bias, const float* residual,
                              int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv = nullptr, bool bf16 = false);
+int awseg_gemm_split3_bn(int n);
 int awseg_gemm_bf16_3_weights(const float* w, int n, int k, uint16_t* w3, hipStream_t stream);

@@ -486,7 +486,7 @@ AWSEG_API int awseg_gemm_split_weights(const float* w, int n, int k, uint16_t* w
     hipLaunchKernelGGL(split_weights_kernel, dim3((unsigned)blocks), dim3(SWT), 0, awseg_s(stream), w, ne, w_split, trailer);
     AWSEG_LAUNCH_CHECK();
     // N % 256 == 0, K % 8 == 0: the k-blocked image of gemm_split3.hip behind the trailer (awseg_gemm_split_weight_halfs says how much room)
-    if (n % 256 == 0 && k % 8 == 0) return awseg_gemm_split3_weights(w, n, k, w_split + 2 * ne + 8, trailer, awseg_s(stream));
+    if (awseg_gemm_split3_bn(n) && k % 8 == 0) return awseg_gemm_split3_weights(w, n, k, w_split + 2 * ne + 8, trailer, awseg_s(stream));
     return 0;
 }
 
@@ -494,7 +494,7 @@ AWSEG_API int64_t awseg_gemm_split_weight_halfs(int n, int k)
 {
     if (n < 1 || k < 1) return -1;
     const int64_t ne = (int64_t)n * k;
-    return 2 * ne + 8 + ((n % 256 == 0 && k % 8 == 0) ? (int64_t)2 * n * ((k + 31) / 32 * 32) : 0);
+    return 2 * ne + 8 + ((awseg_gemm_split3_bn(n) && k % 8 == 0) ? (int64_t)2 * n * ((k + 31) / 32 * 32) : 0);
 }
 
 namespace {
@@ -524,7 +524,7 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     if (v3_on < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_V3"); v3_on = e ? atoi(e) : 1; }
     if (v3_on && awseg_gemm_split3_eligible(m, n, k, cv ? nullptr : x, out, residual, bias) && !(bf16 && cv) &&
         (!cv || (cv->C % 32 == 0 && (int64_t)cv->batch * cv->H * cv->W * cv->C * 4 <= 0x7fffffff)) &&
-        ((m + 255) / 256) * (int64_t)(n / 256) >= (int64_t)cus / 2) {
+        ((m + 255) / 256) * (int64_t)(n / awseg_gemm_split3_bn(n)) >= (int64_t)cus / 2) {
         const int cdesc[10] = { cv ? cv->H : 0, cv ? cv->W : 0, cv ? cv->C : 0, cv ? cv->Ho : 0, cv ? cv->Wo : 0, cv ? cv->kw : 0,
                                 cv ? cv->stride : 0, cv ? cv->pad : 0, cv ? cv->dil : 0, cv ? (int)cv->batch : 0 };
         return awseg_gemm_split3_launch(x, w_split + 2 * (int64_t)n * k + 8, a.trailer, bias, residual, act, out, m, n, k, cus, awseg_s(stream),
@@ -629,7 +629,7 @@ AWSEG_API int awseg_gemm_bf16_weights(const float* w, int n, int k, uint16_t* w_
     hipLaunchKernelGGL(bf16_weights_kernel, dim3((unsigned)((ne / 2 + SWT) / SWT)), dim3(SWT), 0, awseg_s(stream), w, ne, w_bf16, trailer);
     AWSEG_LAUNCH_CHECK();
     // N % 256 == 0, K % 8 == 0: the k-blocked bf16 image of gemm_split3.hip behind the trailer (awseg_gemm_bf16_weight_halfs)
-    if (n % 256 == 0 && k % 8 == 0) return awseg_gemm_bf16_3_weights(w, n, k, w_bf16 + 2 * ne + 8, awseg_s(stream));
+    if (awseg_gemm_split3_bn(n) && k % 8 == 0) return awseg_gemm_bf16_3_weights(w, n, k, w_bf16 + 2 * ne + 8, awseg_s(stream));
     return 0;
 }
 
@@ -637,7 +637,7 @@ AWSEG_API int64_t awseg_gemm_bf16_weight_halfs(int n, int k)
 {
     if (n < 1 || k < 1) return -1;
     const int64_t ne = (int64_t)n * k;
-    return 2 * ne + 8 + ((n % 256 == 0 && k % 8 == 0) ? (int64_t)n * ((k + 31) / 32 * 32) : 0);
+    return 2 * ne + 8 + ((awseg_gemm_split3_bn(n) && k % 8 == 0) ? (int64_t)n * ((k + 31) / 32 * 32) : 0);
 }
 
 AWSEG_API int awseg_gemm_bf16_bias_act(const float* x, const uint16_t* w_bf16, const float* bias, const float* residual,

@@ -92,10 +92,16 @@ typedef __bf16 bf2_3 __attribute__((ext_vector_type(2)));
 typedef float f2_3 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pack_bf16_3(float x, float y) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f2_3{x, y}, bf2_3)); }
 
-template <bool CONV, int ABL = 0, bool BF16 = false>
+// NT: MFMA tiles of 32 columns per wave: block tile 256 x (32 NT) — 8 for N % 256 == 0, 4 for N % 128 == 0, 2 for N % 64 == 0 (the
+// narrow tiles serve HBM-bound shapes: l1 / l2 conv1, MiT projections; the weight image is cut into n-tiles of the same width)
+template <bool CONV, int ABL = 0, bool BF16 = false, int NT = 8>
 __global__ __launch_bounds__(G3T, 2)
 void gemm_split3_kernel(g3_args a)
 {
+    constexpr int BN = 32 * NT;
+    constexpr int ROWB = BF16 ? 64 : 128;                          // bytes of a weight row in a K tile
+    constexpr int NBI_ALL = BN * ROWB / 1024;                      // LDS-DMA instructions per weight K tile (1 KB each)
+    constexpr int NBI = NBI_ALL >= 8 ? NBI_ALL / 8 : 1;            // per wave (fewer than 8 in all: the first NBI_ALL waves issue one each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* sMax = reinterpret_cast<unsigned*>(smem + 4 * G3_STAGE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,7 +113,7 @@ void gemm_split3_kernel(g3_args a)
     auto tile_of = [&](int slot, int64_t& m0, int& n0) -> bool {   // gemm_split.hip: XCD-aware persistent walk
         const int xcd = slot & 7, jj = slot >> 3;
         const int nt_i = jj % a.ntn, mt_i = (jj / a.ntn) * 8 + xcd;
-        m0 = (int64_t)mt_i * G3M; n0 = nt_i * G3N;
+        m0 = (int64_t)mt_i * G3M; n0 = nt_i * BN;
         return mt_i < a.ntm;
     };
 
@@ -124,18 +130,22 @@ void gemm_split3_kernel(g3_args a)
         const int64_t xbytes = rows_left * (int64_t)K * 4;
         if (CONV) x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
         else x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * K), 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
-        if (BF16) w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * kb * 32), 0, G3N * kb * 64, 0x00020000);
-        else w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * kb * 64), 0, G3N * kb * 128, 0x00020000);   // n-tile n0 / 256: kb blocks of 32 KB
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * kb * (ROWB / 2)), 0, BN * kb * ROWB, 0x00020000);   // n-tile n0 / BN: kb K tiles of BN rows
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 8 * (4 * wave + j) + rl;
             const int c = sl ^ ((row >> 1) & 7);
             a_voff[j] = (uint32_t)(row * K * 4 + c * 16);
-            b_voff[j] = (uint32_t)(row * 128 + c * 16);             // inside the K tile's contiguous 32 KB (256 rows x 128 B)
             a_voff_last[j] = (ktail == 0 || c * 4 < ktail) ? a_voff[j] : 0x80000000u;     // chunks past K read zeros (the weight image is zero there too)
-            if (BF16) {                                            // 64-byte weight rows: instruction 2 wave + j covers 16 rows, lane -> row 16 q + (l >> 2), slot l & 3
-                const int brow = 16 * (2 * wave + j) + (lane >> 2);
-                b_voff[j] = (uint32_t)(brow * 64 + (((lane & 3) ^ ((brow >> 2) & 3)) * 16));
+            {   // weights: instruction wave * NBI + j covers 1 KB = 8 (split: 128-byte rows) or 16 (bf16: 64-byte rows) rows of the K tile
+                const int qi = wave * NBI + j;
+                if (BF16) {
+                    const int brow = 16 * qi + (lane >> 2);
+                    b_voff[j] = (uint32_t)(brow * 64 + (((lane & 3) ^ ((brow >> 2) & 3)) * 16));
+                } else {
+                    const int brow = 8 * qi + rl;
+                    b_voff[j] = (uint32_t)(brow * 128 + ((sl ^ ((brow >> 1) & 7)) * 16));
+                }
             }
             if (CONV) {
                 a_voff[j] = (uint32_t)(c * 16);
@@ -149,7 +159,6 @@ void gemm_split3_kernel(g3_args a)
     };
     auto issue = [&](int kt, int stage) {                          // 8 LDS-DMA instructions per wave and K tile
         const uint32_t la = lds0 + (uint32_t)(G3_A0 + stage * G3_STAGE) + wave_u * 4096u;
-        const uint32_t lb = lds0 + (uint32_t)(G3_B0 + stage * G3_STAGE) + wave_u * 4096u;
         if (CONV) {
             const int k0 = kt * G3K, tap = k0 / a.cC, c0 = k0 - tap * a.cC;     // block-uniform
             const int ky = tap / a.ckw, kx = tap - ky * a.ckw;
@@ -164,13 +173,12 @@ void gemm_split3_kernel(g3_args a)
 #pragma unroll
         for (int j = 0; j < 4; ++j) dma16(x_rsrc, kt == nkt - 1 ? a_voff_last[j] : a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
         }
-        if (BF16) {
-            const uint32_t lb2 = lds0 + (uint32_t)(G3_B0 + stage * G3_STAGE) + wave_u * 2048u;
+        {
+            const uint32_t lbw = lds0 + (uint32_t)(G3_B0 + stage * G3_STAGE) + wave_u * (uint32_t)(NBI * 1024);
+            if (NBI_ALL >= 8 || (int)wave_u < NBI_ALL) {
 #pragma unroll
-            for (int j = 0; j < 2; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * 16384), lb2 + (uint32_t)(j * 1024));
-        } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * 32768), lb + (uint32_t)(j * 1024));
+                for (int j = 0; j < NBI; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * BN * ROWB), lbw + (uint32_t)(j * 1024));
+            }
         }
     };
 
@@ -210,9 +218,9 @@ void gemm_split3_kernel(g3_args a)
         while (nslot < ntiles && !tile_of(nslot, nm0, nn0)) nslot += gridDim.x;
         const bool has_next = nslot < ntiles;
 
-        f32x16 acc[8];
+        f32x16 acc[NT];
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
+        for (int j = 0; j < NT; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
         amax = 0.f;
@@ -238,9 +246,9 @@ void gemm_split3_kernel(g3_args a)
                     p = *reinterpret_cast<const f32x4*>(sa + fa[ks][0]);
                     q = *reinterpret_cast<const f32x4*>(sa + fa[ks][1]);
                 }
-                h8 Bh[8], Bl[8];
+                h8 Bh[NT], Bl[NT];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     if (ABL == 5) { Bh[j] = h8{(_Float16)t, (_Float16)j, 1, 2, 3, 4, 5, 6}; Bl[j] = h8{(_Float16)ks, (_Float16)j, 1, 2, 3, 4, 5, 6}; continue; }
                     if (BF16) { Bh[j] = *reinterpret_cast<const h8*>(sa + fb[ks][0] + j * 2048); Bl[j] = Bh[j]; continue; }
                     Bh[j] = *reinterpret_cast<const h8*>(sa + fb[ks][0] + j * 4096);
@@ -251,7 +259,7 @@ void gemm_split3_kernel(g3_args a)
                     H[0] = pack_bf16_3(p[0], p[1]); H[1] = pack_bf16_3(p[2], p[3]); H[2] = pack_bf16_3(q[0], q[1]); H[3] = pack_bf16_3(q[2], q[3]);
                     const bf8_3 Ab = __builtin_bit_cast(bf8_3, H);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, __builtin_bit_cast(bf8_3, Bh[j]), acc[j], 0, 0, 0);
+                    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ab, __builtin_bit_cast(bf8_3, Bh[j]), acc[j], 0, 0, 0);
                     continue;
                 }
                 amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(p[0])), __builtin_fabsf(p[1]));
@@ -267,7 +275,7 @@ void gemm_split3_kernel(g3_args a)
                 }
                 const h8 Ah = __builtin_bit_cast(h8, H), Al = __builtin_bit_cast(h8, L);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < NT; ++j) {
                     if (ABL == 2) { asm volatile("" : : "v"(Ah), "v"(Al), "v"(Bh[j]), "v"(Bl[j])); continue; }
                     if (G3_TRANSPOSED) {
                         // transposed product: rows of the accumulator tile = weight rows n, columns (lanes) = activation rows m
@@ -323,11 +331,11 @@ void gemm_split3_kernel(g3_args a)
             const int nrec = rem > 0x7fffffff ? 0x7fffffff : (int)rem;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + tile_off), 0, nrec, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.residual ? a.residual : a.out) + tile_off), 0, a.residual ? nrec : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.bias ? a.bias : a.out) + en0), 0, a.bias ? G3N * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.bias ? a.bias : a.out) + en0), 0, a.bias ? BN * 4 : 0, 0x00020000);
             const int voff = ((wave * 32 + li) * a.N + 4 * hk) * 4;
             const float relu_floor = a.act == 1 ? 0.f : -__builtin_inff();
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 f32x4 bv[4], rv[4];
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
@@ -362,12 +370,12 @@ void gemm_split3_kernel(g3_args a)
             const int nrec = rem > 0x7fffffff ? 0x7fffffff : (int)rem;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + tile_off), 0, nrec, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.residual ? a.residual : a.out) + tile_off), 0, a.residual ? nrec : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.bias ? a.bias : a.out) + en0), 0, a.bias ? G3N * 4 : 0, 0x00020000);
+            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.bias ? a.bias : a.out) + en0), 0, a.bias ? BN * 4 : 0, 0x00020000);
             const int voff = ((wave * 32 + 4 * hk) * a.N + li) * 4;
             const float relu_floor = a.act == 1 ? 0.f : -__builtin_inff();
             const int rowb = a.N * 4;                              // bytes per output row
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NT; ++j) {
                 const float bvj = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, (j * 32 + li) * 4, 0, 0));
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
@@ -401,7 +409,7 @@ void gemm_split3_kernel(g3_args a)
 // KB = ceil(K / 32), zeros past K: the K tile of a 256-row n-tile is one contiguous 32 KB block (a tile's rows at stride K * 4 B
 // would all fall into the same few L2 channels)
 __global__ __launch_bounds__(256)
-void split3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, int kb, uint16_t* __restrict__ out, const unsigned* __restrict__ trailer)
+void split3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, int kb, int bn, uint16_t* __restrict__ out, const unsigned* __restrict__ trailer)
 {
     const int e = (int)trailer[1];
     const int e1 = e / 2, e2 = e - e1;
@@ -414,13 +422,13 @@ void split3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, i
     const float x0 = k < k_dim ? w[n * k_dim + k] * s1 * s2 : 0.f, x1 = k + 1 < k_dim ? w[n * k_dim + k + 1] * s1 * s2 : 0.f;
     const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1;
     const _Float16 l0 = (_Float16)(x0 - (float)h0), l1 = (_Float16)(x1 - (float)h1);
-    uint16_t* d = out + (((n >> 8) * kb + (k >> 5)) * 256 + (n & 255)) * 64 + (k & 31);
+    uint16_t* d = out + (((n / bn) * kb + (k >> 5)) * bn + (n % bn)) * 64 + (k & 31);
     d[0] = __builtin_bit_cast(uint16_t, h0); d[1] = __builtin_bit_cast(uint16_t, h1);
     d[32] = __builtin_bit_cast(uint16_t, l0); d[33] = __builtin_bit_cast(uint16_t, l1);
 }
 
 __global__ __launch_bounds__(256)
-void bf16_3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, int kb, uint16_t* __restrict__ out)
+void bf16_3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, int kb, int bn, uint16_t* __restrict__ out)
 {
     const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 2;
     const int kp = kb * 32;
@@ -428,17 +436,20 @@ void bf16_3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, i
     const int64_t n = i / kp;
     const int k = (int)(i - n * kp);
     const unsigned pr = pack_bf16_3(k < k_dim ? w[n * k_dim + k] : 0.f, k + 1 < k_dim ? w[n * k_dim + k + 1] : 0.f);
-    uint16_t* d = out + (((n >> 8) * kb + (k >> 5)) * 256 + (n & 255)) * 32 + (k & 31);
+    uint16_t* d = out + (((n / bn) * kb + (k >> 5)) * bn + (n % bn)) * 32 + (k & 31);
     d[0] = (uint16_t)pr; d[1] = (uint16_t)(pr >> 16);
 }
 
 }  // namespace
 
+// width of the block tile (and of the weight image's n-tiles) for an N-column problem; 0: not served
+int awseg_gemm_split3_bn(int n) { return n % 256 == 0 ? 256 : (n % 128 == 0 ? 128 : (n % 64 == 0 ? 64 : 0)); }
+
 int awseg_gemm_bf16_3_weights(const float* w, int n, int k, uint16_t* w3, hipStream_t stream)
 {
     const int kb = (k + 31) / 32;
     const int64_t ne = (int64_t)n * kb * 32;
-    hipLaunchKernelGGL(bf16_3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, n, k, kb, w3);
+    hipLaunchKernelGGL(bf16_3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, n, k, kb, awseg_gemm_split3_bn(n), w3);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -448,14 +459,14 @@ int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const 
 {
     const int kb = (k + 31) / 32;
     const int64_t ne = (int64_t)n * kb * 32;
-    hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, n, k, kb, w3, trailer);
+    hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, n, k, kb, awseg_gemm_split3_bn(n), w3, trailer);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
 
 bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const void* out, const void* residual, const void* bias)
 {
-    if (n % G3N || k % 8 || k < 64 || m < 1) return false;
+    if (awseg_gemm_split3_bn(n) == 0 || k % 8 || k < 64 || m < 1) return false;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) return false;
     if ((int64_t)G3M * n * 4 > 0x7fffffff || (int64_t)G3M * (k + 32) * 4 > 0x7fffffff) return false;
     return true;
@@ -477,7 +488,8 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     a.x = x; a.w3 = w3; a.bias = bias; a.residual = residual; a.out = out; a.trailer = trailer;
     a.M = m; a.N = n; a.K = k; a.act = act;
     const int64_t ntm = (m + G3M - 1) / G3M;
-    a.ntn = n / G3N;
+    const int bn = awseg_gemm_split3_bn(n);
+    a.ntn = n / bn;
     const int64_t ntm8 = (ntm + 7) / 8 * 8;
     if (ntm8 * a.ntn > 0x7fffffff) return AWSEG_ERANGE;
     a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
@@ -485,34 +497,32 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     int64_t blocks = (int64_t)cus / 8 * 8;
     if (blocks < 8) blocks = 8;
     if (blocks > slots) blocks = slots;
-    static bool attr_done = false;
-    if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
-        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_split3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
-        if (e != hipSuccess) return (int)e;
-        attr_done = true;
-    }
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("AWSEG_G3_ABL"); abl = e ? atoi(e) : 0; }
-    if (abl && !conv) {
+    if (abl && !conv && !bf16 && bn == 256) {
 #define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a); break; }
         switch (abl) { G3_ABL(1) G3_ABL(2) G3_ABL(3) G3_ABL(4) G3_ABL(5) default: break; }
 #undef G3_ABL
         AWSEG_LAUNCH_CHECK();
         return 0;
     }
-    if (bf16) {
-        auto kb16 = gemm_split3_kernel<false, 0, true>;
-        static bool attr16 = false;
-        if (!attr16) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kb16), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS);
-            if (e != hipSuccess) return (int)e;
-            attr16 = true;
-        }
-        hipLaunchKernelGGL(kb16, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
-    }
-    else if (conv) hipLaunchKernelGGL(gemm_split3_kernel<true>, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
-    else hipLaunchKernelGGL(gemm_split3_kernel<false>, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);
+#define G3_GO(CONV_, BF_, NT_)                                                                                                         \
+    do {                                                                                                                              \
+        auto kf = gemm_split3_kernel<CONV_, 0, BF_, NT_>;                                                                             \
+        static bool attr = false;                                                                                                     \
+        if (!attr) {                                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS); \
+            if (e != hipSuccess) return (int)e;                                                                                       \
+            attr = true;                                                                                                              \
+        }                                                                                                                             \
+        hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);                                                 \
+    } while (0)
+#define G3_BY_NT(CONV_, BF_) do { if (bn == 256) G3_GO(CONV_, BF_, 8); else if (bn == 128) G3_GO(CONV_, BF_, 4); else G3_GO(CONV_, BF_, 2); } while (0)
+    if (bf16) G3_BY_NT(false, true);
+    else if (conv) G3_BY_NT(true, false);
+    else G3_BY_NT(false, false);
+#undef G3_BY_NT
+#undef G3_GO
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

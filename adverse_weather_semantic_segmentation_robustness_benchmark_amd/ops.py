@@ -623,10 +623,14 @@ def gemm_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int
 # ones; narrow outputs (N < 128 = one block tile) stay on the library.  AWSEG_GEMM_SPLIT=0 turns the split path off.
 GEMM_SPLIT = os.environ.get("AWSEG_GEMM_SPLIT", "1") != "0"
 GEMM_SPLIT_MIN_M, GEMM_SPLIT_MIN_N, GEMM_SPLIT_MIN_K = 128, 128, 64
+GEMM_SPLIT_N64 = os.environ.get("AWSEG_GEMM_SPLIT_N64", "1") != "0"
 
 
 def gemm_wants_split(m: int, n: int, k: int) -> bool:
-    return GEMM_SPLIT and m >= GEMM_SPLIT_MIN_M and n >= GEMM_SPLIT_MIN_N and k >= GEMM_SPLIT_MIN_K and k % 8 == 0
+    if not GEMM_SPLIT or m < GEMM_SPLIT_MIN_M or k < GEMM_SPLIT_MIN_K or k % 8:
+        return False
+    # N = 64 (ResNet layer1 conv1, MiT stage-2 projections): only where the LDS-DMA kernel's 256 x 64 tiles fill the chip
+    return n >= GEMM_SPLIT_MIN_N or (n == 64 and GEMM_SPLIT_N64 and ((m + 255) // 256) >= 128)
 
 
 def gemm_split_weights(w: torch.Tensor) -> torch.Tensor:

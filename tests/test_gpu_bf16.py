@@ -20,7 +20,7 @@ def bf(t):
     return t.to(torch.bfloat16).double()
 
 
-@pytest.mark.parametrize("shape", [(300, 256, 128), (257, 2048, 512), (4100, 320, 72), (38400, 256, 128), (1000, 64, 304), (20000, 32, 64)])
+@pytest.mark.parametrize("shape", [(300, 256, 128), (257, 2048, 512), (4100, 320, 72), (38400, 256, 128), (1000, 64, 304), (20000, 32, 64), (66000, 320, 320), (66000, 128, 64), (40000, 64, 200)])
 def test_gemm_bf16(ops, shape):
     M, Nn, K = shape
     g = torch.Generator(device="cuda").manual_seed(sum(shape))

@@ -1005,7 +1005,7 @@ def test_attention_d32_split_flat_softmax(ops):
 
 
 @pytest.mark.parametrize("shape", [(300, 256, 128), (1000, 19, 304), (257, 2048, 512), (128, 128, 2048), (4100, 320, 72), (200, 160, 264), (1100, 384, 1024), (38400, 256, 128), (38500, 512, 104),
-                                   (131100, 256, 128), (65600, 512, 104), (65700, 128, 512), (70000, 384, 136)])
+                                   (131100, 256, 128), (65600, 512, 104), (65700, 128, 512), (70000, 384, 136), (66000, 64, 256), (40000, 320, 96)])
 @pytest.mark.parametrize("res_act", [(False, 0), (True, 1)])
 def test_gemm_split_float32_grade(ops, shape, res_act):
     """Split-operand f16-MFMA GEMM against float64, next to the hipBLASLt float32 GEMM on the same inputs: ragged M and

@@ -175,6 +175,8 @@ def main():
         cases[f"gemm {name} M={m} N={n} K={k} [split f16x3, issued flops]"] = (lambda: ops.gemm_split_bias_act(xg, wsg, bg, 1, residual=rg, out=og), "mfma_f16", 3 * fl)
         cases[f"gemm {name} M={m} N={n} K={k} [split, as HBM bytes]"] = (lambda: ops.gemm_split_bias_act(xg, wsg, bg, 1, residual=rg, out=og), "hbm", by)
     px4, px8, px16 = B * (H // 4) * (W // 4), B * (H // 8) * (W // 8), B * (H // 16) * (W // 16)
+    gemm_case("l1 conv1", px4, 64, 256, False)
+    gemm_case("mit s2 fc2", px8, 64, 256, True)
     gemm_case("l1 conv3", px4, 256, 64, True)
     gemm_case("l2 conv1", px8, 128, 512, False)
     gemm_case("l2 conv3", px8, 512, 128, True)

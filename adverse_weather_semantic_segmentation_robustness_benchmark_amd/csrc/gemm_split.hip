@@ -522,7 +522,9 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     }
     static int v3_on = -1;                                       // AWSEG_GEMM_SPLIT_V3=0: keep the register-staged kernels of round 2 (A/B measurements)
     if (v3_on < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_V3"); v3_on = e ? atoi(e) : 1; }
-    if (v3_on && awseg_gemm_split3_eligible(m, n, k, cv ? nullptr : x, out, residual, bias) && !(bf16 && cv) &&
+    // (bf16: only the 256-wide tile — on B5 + R101's N = 64 / 128 / 320 projections the narrow tiles measured slower than the
+    // round-2 bf16 kernel: 105.0 against 98.7 ms per step)
+    if (v3_on && awseg_gemm_split3_eligible(m, n, k, cv ? nullptr : x, out, residual, bias) && !(bf16 && (cv || n % 256)) &&
         (!cv || (cv->C % 32 == 0 && (int64_t)cv->batch * cv->H * cv->W * cv->C * 4 <= 0x7fffffff)) &&
         ((m + 255) / 256) * (int64_t)(n / awseg_gemm_split3_bn(n)) >= (int64_t)cus / 2) {
         const int cdesc[10] = { cv ? cv->H : 0, cv ? cv->W : 0, cv ? cv->C : 0, cv ? cv->Ho : 0, cv ? cv->Wo : 0, cv ? cv->kw : 0,

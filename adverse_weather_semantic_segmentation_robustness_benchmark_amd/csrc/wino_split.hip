@@ -126,6 +126,7 @@ __device__ unsigned long long g_ws_stamp2[8];                      // slot A in 
 
 struct awseg_false { static constexpr bool value = false; };
 struct awseg_true { static constexpr bool value = true; };
+template <int N> struct awseg_int { static constexpr int value = N; };
 
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); }   // -126 <= e <= 127
 
@@ -584,6 +585,9 @@ constexpr int W8T = 512;
 #ifdef AWSEG_WS_STAMP
 __device__ unsigned long long g_w8_stamp[2][8];                       // [wave 0 | wave 4][slot A work, barrier A, slot B work, barrier B, chunks, whole block]
 #endif
+#ifndef AWSEG_W8_ABL
+#define AWSEG_W8_ABL 0
+#endif
 constexpr int X_BYTES = 8 * 64 * 64 * 4;                              // epilogue exchange: 8 waves x 64 lanes x 64 floats
 
 template <int MODE, bool BF16>
@@ -617,6 +621,7 @@ void wino8_kernel(ws_args a)
     const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
     const int n0 = ng * NB;
     const int nchunks = a.Cin / KC;
+    constexpr int abl = AWSEG_W8_ABL;                                // timing experiments only: compile-time switches that REMOVE one ingredient of the chunk loop
 
     // ---- patch LDS-DMA (issued by the odd group at the start of its transform slot: 21 instructions over its 4 waves), layout as
     // in the kernel above.  (Measured and dropped: every wave issuing its share and its next U fragments from its MFMA slot — that
@@ -698,12 +703,15 @@ void wino8_kernel(ws_args a)
                 // four-wave kernel are 2-way conflicted (a fifth of its LDS cycles)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const float4 q = *reinterpret_cast<const float4*>(pp + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
+                    float4 q = make_float4(uscale, xs, uscale, xs);
+                    if (!(abl & 32)) q = *reinterpret_cast<const float4*>(pp + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
                     v2f v0 = {q.x, q.y}, v1 = {q.z, q.w};
                     if (BF16) {
                     } else if (!SCALED) {
+                        if (!(abl & 1)) {
                         amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v0.x)), __builtin_fabsf(v0.y));
                         amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(v1.x)), __builtin_fabsf(v1.y));
+                        }
                     } else { v0 = v0 * v2f{xs, xs}; v1 = v1 * v2f{xs, xs}; }
                     d[0][j] = v0; d[1][j] = v1;
                 }
@@ -722,8 +730,12 @@ void wino8_kernel(ws_args a)
                         *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_hi) = H;
                         continue;
                     }
+                    if (abl & 4) { H[0] = __builtin_bit_cast(unsigned, va.x); L[0] = __builtin_bit_cast(unsigned, va.y); H[1] = __builtin_bit_cast(unsigned, vb.x); L[1] = __builtin_bit_cast(unsigned, vb.y); }
+                    else {
                     split_pair(va, h, l); H[0] = h; L[0] = l;
                     split_pair(vb, h, l); H[1] = h; L[1] = l;
+                    }
+                    if (abl & 2) { if (H[0] == 0x12345678u && L[1] == 0x9abcdef0u) *reinterpret_cast<u32x2*>(sV + vw_hi) = H; continue; }
                     *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_hi) = H;
                     *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_lo) = L;
                 }
@@ -813,10 +825,10 @@ void wino8_kernel(ws_args a)
         for (int c = 0; c < nchunks; ++c) {
             W8_T(q0);
             // slot A: even waves multiply rows {0, 2} of chunk c | odd waves: DMA of patch c + 2, U of chunk c, patch c -> rows {1, 3}
-            if (grp == 0) mma();
+            if (grp == 0) { if (!(abl & 64)) mma(); }
             else {
-                glds_patch(c + 2, (c + 2) % 3);                      // that ring slot held patch c - 1 (last read in slot A of chunk c - 1)
-                u_fetch(c);
+                if (!(abl & 16)) glds_patch(c + 2, (c + 2) % 3);     // that ring slot held patch c - 1 (last read in slot A of chunk c - 1)
+                if (!(abl & 8)) u_fetch(c);
                 transform(c % 3);
                 // patch c + 1 (DMA issued a chunk ago, older than this slot's n_pinstr + 8 operations) has landed
                 if (BF16) { if (gw_u == 0) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); }
@@ -826,8 +838,8 @@ void wino8_kernel(ws_args a)
             __syncthreads();
             W8_T(q2);
             // slot B: odd waves multiply rows {1, 3} of chunk c | even waves: patch c + 1 -> rows {0, 2} of chunk c + 1, U of chunk c + 1
-            if (grp == 1) mma();
-            else if (c + 1 < nchunks) { u_fetch(c + 1); transform((c + 1) % 3); }
+            if (grp == 1) { if (!(abl & 64)) mma(); }
+            else if (c + 1 < nchunks) { if (!(abl & 8)) u_fetch(c + 1); transform((c + 1) % 3); }
             W8_T(q3);
             __syncthreads();
             W8_T(q4);
@@ -966,6 +978,419 @@ void wino8_kernel(ws_args a)
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// The eight-wave block with SYMMETRIC slots.  wino8_kernel gives the two waves of a SIMD opposite roles per slot, but the roles
+// are not equally long: the stamps (tools/probe_wino_stamps.hip) read 1 060 cycles for a wave's 24 MFMAs and 2 100 - 2 600 for
+// its partner's transform of two V rows, so the multiplying group waits at the barrier for half of every slot and a chunk costs
+// two transform slots (~4 950 cycles).  tools/scratch/pipe_overlap.hip shows the pipes themselves DO run side by side when
+// different waves of a SIMD feed them (MFMA + LDS + vector work of two waves: both at their stand-alone pace), with two
+// exceptions this kernel avoids: v_pk_*_f32 waits for the matrix pipe to go idle (7x slower beside MFMAs), and MFMAs that
+// depend on their predecessor hold the SIMD's vector issue.  Here EVERY wave does half of both jobs in every slot:
+//   * wave (nt, j) owns V COLUMN j — positions j, 4 + j, 8 + j, 12 + j — x all 64 tiles x 32 couts (128 accumulators);
+//   * slot A of chunk c: 12 MFMAs on its positions of V rows {0, 2}, and ONE V row of the transform (threads 0-255: row 1,
+//     256-511: row 3, of the same chunk); slot B: 12 MFMAs on rows {1, 3}, and row 0 / row 2 of chunk c + 1;
+//   * waves 0-3 multiply first and transform second, waves 4-7 (their SIMD partners) the other way round — at any time one
+//     wave of a SIMD feeds the matrix pipe while the other does LDS / vector work, and both reach the barrier together;
+//   * the 12 MFMAs of a slot rotate over four accumulators (dependency distance 4);
+//   * U: the two rows' fragments are re-fetched right behind the MFMAs that consumed them (for the next chunk): 4 loads per slot;
+//   * epilogue: the inverse transform over the V rows happens in registers (a wave holds all four rows of its column), the
+//     columns meet through LDS: wave (nt, j) finishes m-tile j >> 1, output COLUMN j & 1, both output rows.
+template <int MODE, bool BF16>
+__global__ __launch_bounds__(W8T, 2)
+void wino8s_kernel(ws_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sV = smem;
+    unsigned char* sP = smem + V_BYTES;
+    unsigned* sMax = reinterpret_cast<unsigned*>(smem + V_BYTES + P_RING * P_BYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int grp = wave >> 2;                                       // 0: multiply, then transform; 1: transform, then multiply
+    const int nt = wave & 1, vcol = wave >> 1;                       // cout half, V column
+    const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
+    const int per = a.span * a.ngroups, sg = jj / per, rr = jj - sg * per;
+    const int ng = rr / a.span, t = (sg * a.span + (rr - ng * a.span)) * 8 + xcd;
+    const int gx = a.nbx * a.dil, gy = a.nby * a.dil;
+    if (t >= gx * gy * a.batch) return;
+    const int b = t / (gx * gy), txy = t - b * (gx * gy), tyy = txy / gx, txx = txy - tyy * gx;
+    const int bx = txx % a.nbx, rx = txx / a.nbx;
+    const int by = tyy % a.nby, ry = tyy / a.nby;
+    const int Hs = (a.H - ry + a.dil - 1) / a.dil, Ws = (a.W - rx + a.dil - 1) / a.dil;
+    if (by * 2 * TB >= Hs || bx * 2 * TB >= Ws) return;
+    const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
+    const int n0 = ng * NB;
+    const int nchunks = a.Cin / KC;
+
+    // ---- patch LDS-DMA: the 21 wave-wide instructions of a patch are dealt over ALL eight waves (instruction wave + 8 k: three for
+    // waves 0-4, two for 5-7) — issuing one costs a wave ~100 cycles, and the six per wave of wino8_kernel made slot A 700 cycles
+    // longer for the issuing group than for its partners.  Layout as in wino8_kernel.
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)xb, 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+    uint32_t pvoff[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = (wave + 8 * j) * 64 + lane;
+        const int g = q >> 2, h = q & 3;
+        const int py = g / PW, pos = g - py * PW;
+        const int px = pos < PW / 2 ? 2 * pos : 2 * (pos - PW / 2) + 1;
+        const int sy = by * 2 * TB - 1 + py, sx = bx * 2 * TB - 1 + px;
+        const int y = ry + a.dil * sy, x = rx + a.dil * sx;
+        const bool ok = g < NPIX && sy >= 0 && sx >= 0 && y < a.H && x < a.W;
+        pvoff[j] = ok ? (uint32_t)(((y * a.W + x) * a.Cin + h * 4) * 4) : 0x80000000u;
+    }
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool three = wave_u < P_INSTR - 16;                        // this wave issues three (else two) instructions per patch
+    const uint32_t p_lds = __builtin_amdgcn_readfirstlane(lds_addr(sP)) + (uint32_t)wave_u * 1024u;
+    auto glds_patch = [&](int chunk, int slot) {
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((chunk < nchunks ? chunk : nchunks - 1) * KC * 4);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p_lds + (uint32_t)(slot * P_BYTES)));
+        bufdma16(x_rsrc, pvoff[0], soff, base);
+        bufdma16(x_rsrc, pvoff[1], soff, base + 8192u);
+        if (three) bufdma16(x_rsrc, pvoff[2], soff, base + 16384u);
+    };
+    // s_waitcnt vmcnt(n + 2 | n + 3): everything but this wave's youngest n register loads and ONE patch's DMA instructions
+    auto vm_wait_keep_patch_and = [&](auto NC) {
+        constexpr int N = decltype(NC)::value;
+        if (three) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 2) : "memory");
+    };
+
+    // ---- transform item: (tile, channel quad) x ONE V row per slot (the thread's half of the block picks the row)
+    const int it = tid & 255;
+    const int xtile = it >> 2, xq = it & 3;
+    const int xty = xtile >> 3, xtx = xtile & 7;
+    const int prd = (2 * xty * PW + xtx) * 64 + xq * 16;
+    const int xsw = (xtile >> 2) & 3;
+    const int vw_hi = xtile * 64 + (((xq >> 1) ^ xsw) * 16) + (xq & 1) * 8;
+    const int vw_lo = xtile * 64 + (((2 + (xq >> 1)) ^ xsw) * 16) + (xq & 1) * 8;
+
+    // ---- MFMA operands
+    int a_hi[2], a_lo[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int tile = m * 32 + li, sw = (tile >> 2) & 3;
+        a_hi[m] = tile * 64 + ((hk ^ sw) * 16);
+        a_lo[m] = tile * 64 + (((2 + hk) ^ sw) * 16);
+    }
+    const int ncb = a.Cout / 32, cb = (n0 >> 5) + nt;
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, (int)(a.u_halfs * 2), 0x00020000);
+    const uint32_t ulane = (uint32_t)(hk * 512 + li * 16);
+    const uint32_t u_p = (uint32_t)ncb * 2048u, u_c = 16u * u_p;
+    const uint32_t u_w = (uint32_t)(__builtin_amdgcn_readfirstlane(vcol) * (int)u_p + __builtin_amdgcn_readfirstlane(cb) * 2048);
+    const float uscale = *reinterpret_cast<const float*>(a.U + a.u_halfs);
+
+    f32x16 acc[4][2];                                                // [V row][m-tile]
+    float amax = 0.f, xs = 1.0f;
+    int sx = 0;
+    if (tid == 0) sMax[0] = 0u;
+
+    auto run = [&](auto SC) {
+        constexpr bool SCALED = decltype(SC)::value;
+        h8 uh[4], ul[4];                                             // [V row]
+        auto u_fetch2 = [&](int c, int r0) {                         // rows r0 and r0 + 2 of chunk c
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = r0 + 2 * e;
+                const uint32_t so = (uint32_t)c * u_c + u_w + (uint32_t)(4 * i) * u_p;
+                uh[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane, so, 0));
+                if (!BF16) ul[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane + 1024u, so, 0));
+            }
+        };
+        // patch `slot` -> ONE V row.  B^T rows:  0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3.  PHASE 0 (slot A): threads 0-255 build
+        // row 1, 256-511 row 3 (input rows 1, 2 | 1, 3); PHASE 1 (slot B, next chunk's patch): row 0 | row 2 (input rows 0, 2 | 2, 1).
+        // max|x| is taken once per input row and block: d1 by the row-1 threads, d3 by row 3, d0 and d2 by row 0.
+        auto transform = [&](int slot, auto PH) {
+            constexpr int PHASE = decltype(PH)::value ? 1 : 0;
+            const unsigned char* pp = sP + slot * P_BYTES + prd;
+            // scalar float32 arithmetic on purpose: v_pk_add_f32 waits for the matrix pipe (see the header of this kernel)
+            auto load_row = [&](int i, bool track, float (&d)[4][4]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 q = *reinterpret_cast<const float4*>(pp + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
+                    d[j][0] = q.x; d[j][1] = q.y; d[j][2] = q.z; d[j][3] = q.w;
+                    if (BF16) {
+                    } else if (!SCALED) {
+                        if (track) {
+                            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(q.x)), __builtin_fabsf(q.y));
+                            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(q.z)), __builtin_fabsf(q.w));
+                        }
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < 4; ++ch) d[j][ch] *= xs;
+                    }
+                }
+            };
+            auto cols_store = [&](int vr, const float (&tt)[4][4]) {   // row vr of (B^T d) -> positions 4 vr .. 4 vr + 3, split, stored
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float o[4];
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch)
+                        o[ch] = j == 0 ? tt[0][ch] - tt[2][ch] : j == 1 ? tt[1][ch] + tt[2][ch] : j == 2 ? tt[2][ch] - tt[1][ch] : tt[1][ch] - tt[3][ch];
+                    const v2f va = {o[0], o[1]}, vb = {o[2], o[3]};
+                    u32x2 H, L; unsigned h, l;
+                    if (BF16) {
+                        H[0] = pack_bf16(va); H[1] = pack_bf16(vb);
+                        *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_hi) = H;
+                        continue;
+                    }
+                    split_pair(va, h, l); H[0] = h; L[0] = l;
+                    split_pair(vb, h, l); H[1] = h; L[1] = l;
+                    *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_hi) = H;
+                    *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_lo) = L;
+                }
+            };
+            float p[4][4], q[4][4];
+            auto combine = [&](bool plus) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) p[j][ch] = plus ? p[j][ch] + q[j][ch] : p[j][ch] - q[j][ch];
+            };
+            if (PHASE == 0) {
+                if (grp == 0) { load_row(1, true, p); load_row(2, false, q); combine(true); cols_store(1, p); }     // row 1: d1 + d2
+                else { load_row(1, false, p); load_row(3, true, q); combine(false); cols_store(3, p); }             // row 3: d1 - d3
+            } else {
+                if (grp == 0) { load_row(0, true, p); load_row(2, true, q); combine(false); cols_store(0, p); }     // row 0: d0 - d2
+                else { load_row(2, false, p); load_row(1, false, q); combine(false); cols_store(2, p); }            // row 2: d2 - d1
+            }
+        };
+        // 12 MFMAs on V rows r0 and r0 + 2 of this wave's column: the three product terms, each over the four accumulators
+        auto mma2 = [&](int r0) {
+            h8 vh[2][2], vl[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned char* vp = sV + (4 * (r0 + 2 * e)) * V_POS + vcol * V_POS;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    vh[e][m] = *reinterpret_cast<const h8*>(vp + a_hi[m]);
+                    if (!BF16) vl[e][m] = *reinterpret_cast<const h8*>(vp + a_lo[m]);
+                }
+            }
+#pragma unroll
+            for (int term = 0; term < (BF16 ? 1 : 3); ++term)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int i = r0 + 2 * e;
+                        f32x16 z = acc[i][m];
+                        if (BF16) {
+                            if (MODE == 1) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, uh[i]), __builtin_bit_cast(bf8, vh[e][m]), z, 0, 0, 0);
+                            else z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, vh[e][m]), __builtin_bit_cast(bf8, uh[i]), z, 0, 0, 0);
+                        } else {
+                            const h8 va = term == 2 ? vl[e][m] : vh[e][m];
+                            const h8 ua = term == 1 ? ul[i] : uh[i];
+                            if (MODE == 1) z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua, va, z, 0, 0, 0);
+                            else z = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, ua, z, 0, 0, 0);
+                        }
+                        acc[i][m] = z;
+                    }
+        };
+
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+        // ---- prologue: patches 0 and 1 in flight, U of chunk 0, patch 0 landed; every thread builds its row (0 | 2) of chunk 0
+        glds_patch(0, 0);
+        glds_patch(1, 1);
+        u_fetch2(0, 0);
+        u_fetch2(0, 1);
+        vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});            // patch 0: everything but patch 1 and the U fragments behind it
+        __syncthreads();                                             // (also orders sMax[0] = 0 and the previous pass's V reads)
+        transform(0, awseg_true{});
+        __syncthreads();
+#ifdef AWSEG_WS_STAMP
+        unsigned long long w8s[5] = {0, 0, 0, 0, 0}, w8f[2] = {0, 0};
+#define W8_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#define W8_ACC(t0, t1, t2, t3, t4) { w8s[0] += t1 - t0; w8s[1] += t2 - t1; w8s[2] += t3 - t2; w8s[3] += t4 - t3; w8s[4] += 1; }
+#define W8_FINE(t0, t1, t2) { w8f[0] += t1 - t0; w8f[1] += t2 - t1; }
+#else
+#define W8_T(v)
+#define W8_ACC(t0, t1, t2, t3, t4)
+#define W8_FINE(t0, t1, t2)
+#endif
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more = c + 1 < nchunks;
+            W8_T(q0);
+            // slot A: MFMAs on rows {0, 2} of chunk c | patch c -> rows {1, 3} of chunk c | DMA of patch c + 2 (its ring slot held patch
+            // c - 1, last read in slot A of chunk c - 1).  At the end patch c + 1 (DMA issued a chunk ago) has landed: behind it this
+            // wave issued, in program order, the U loads counted below and one patch's DMA instructions.
+            if (grp == 0) {
+                mma2(0);
+                if (more) u_fetch2(c + 1, 0);
+                W8_T(qa);
+                glds_patch(c + 2, (c + 2) % 3);
+                W8_T(qb);
+                transform(c % 3, awseg_false{});
+                W8_FINE(q0, qa, qb)
+                if (more) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});      // U rows {1, 3} of chunk c (slot B), rows {0, 2} of chunk c + 1
+            } else {
+                W8_T(qa);
+                glds_patch(c + 2, (c + 2) % 3);
+                W8_T(qb);
+                transform(c % 3, awseg_false{});
+                W8_T(qc);
+                W8_FINE(qa, qb, qc)
+                mma2(0);
+                if (more) {
+                    u_fetch2(c + 1, 0);
+                    vm_wait_keep_patch_and(awseg_int<BF16 ? 6 : 12>{});           // U rows {0, 2} and {1, 3} of chunk c, rows {0, 2} of chunk c + 1
+                }
+            }
+            W8_T(q1);
+            __syncthreads();
+            W8_T(q2);
+            // slot B: MFMAs on rows {1, 3} of chunk c | patch c + 1 -> rows {0, 2} of chunk c + 1
+            if (grp == 0) {
+                mma2(1);
+                if (more) { u_fetch2(c + 1, 1); transform((c + 1) % 3, awseg_true{}); }
+            } else {
+                if (more) transform((c + 1) % 3, awseg_true{});
+                mma2(1);
+                if (more) u_fetch2(c + 1, 1);
+            }
+            W8_T(q3);
+            __syncthreads();
+            W8_T(q4);
+            W8_ACC(q0, q1, q2, q3, q4)
+        }
+        vm_wait_all();
+#ifdef AWSEG_WS_STAMP
+        if (blockIdx.x == 0 && (tid == 0 || tid == 256)) { for (int i = 0; i < 5; ++i) g_w8_stamp[tid >> 8][i] += w8s[i]; g_w8_stamp[tid >> 8][5] += w8f[0]; g_w8_stamp[tid >> 8][6] += w8f[1]; }
+#endif
+#undef W8_T
+#undef W8_ACC
+#undef W8_FINE
+    };
+
+    run(awseg_false{});
+    if (!BF16) {
+        if (amax > 0.f) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, amax));
+        __syncthreads();
+        const unsigned mx = sMax[0];
+        const int ex = (int)(mx >> 23) & 0xff;
+        const float mf = __builtin_bit_cast(float, mx);
+        if (!(mx == 0u || ex == 0xff || (mf < 8192.0f && mf >= 0.0625f))) {
+            sx = 11 - (ex - 127);
+            sx = sx > 126 ? 126 : sx;
+            xs = pow2f(sx);
+            run(awseg_true{});
+        }
+    }
+
+    // ---- output transform.  This wave holds M[0..3][vcol]; Y = A^T M A:
+    //   C_0 = M_0j + M_1j + M_2j, C_1 = M_1j - M_2j - M_3j (row factor, in registers), then over the V columns j
+    //   Y[a][0] = C_a(0) + C_a(1) + C_a(2),  Y[a][1] = C_a(1) - C_a(2) - C_a(3)  — through LDS.
+    // exchange layout: float4 [nt][V column][m][a][r >> 2][lane]
+    float* xch = reinterpret_cast<float*>(smem);
+    {
+        float* dst = xch + ((size_t)(nt * 4 + vcol) * 16 * 64 + lane) * 4;
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 q0, q1;
+                float* p0 = &q0.x; float* p1 = &q1.x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = 4 * r4 + q;
+                    p0[q] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
+                    p1[q] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
+                }
+                *reinterpret_cast<float4*>(dst + ((m * 2 + 0) * 4 + r4) * 64 * 4) = q0;
+                *reinterpret_cast<float4*>(dst + ((m * 2 + 1) * 4 + r4) * 64 * 4) = q1;
+            }
+    }
+    __syncthreads();
+    const int mt = vcol >> 1, ob = vcol & 1;                          // this wave finishes m-tile mt, output column ob
+    const float ysc = uscale * pow2f(-sx);
+    f32x16 y[2];                                                      // [output row a]
+    {
+#pragma unroll
+        for (int arow = 0; arow < 2; ++arow)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float4 s0, s1, s2;
+                auto ld = [&](int j) {
+                    return *reinterpret_cast<const float4*>(xch + (((size_t)(nt * 4 + j) * 16 + (mt * 2 + arow) * 4 + r4) * 64 + lane) * 4);
+                };
+                s0 = ld(ob); s1 = ld(ob + 1); s2 = ld(ob + 2);       // ob = 0: columns 0, 1, 2 (+ + +); ob = 1: columns 1, 2, 3 (+ - -)
+                const float* f0 = &s0.x; const float* f1 = &s1.x; const float* f2 = &s2.x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) y[arow][4 * r4 + q] = (ob == 0 ? f0[q] + f1[q] + f2[q] : f0[q] - f1[q] - f2[q]) * ysc;
+            }
+    }
+
+    if (MODE == 0) {
+        // rows = tiles of m-tile mt (tile row 4 mt + (r >> 2), tile column 4 hk + (r & 3)), columns (lanes) = couts; output column 2 tx + ob
+        const int n = n0 + nt * 32 + li;
+        const float sh = a.shift[n];
+        const size_t img = (size_t)a.H * a.W * a.Cout;
+        const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img), 0, (int)(img * 4), 0x00020000);
+        const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual ? a.residual + (size_t)b * img : a.out), 0, a.residual ? (int)(img * 4) : 0, 0x00020000);
+        const int mt_u = __builtin_amdgcn_readfirstlane(mt), ob_u = __builtin_amdgcn_readfirstlane(ob);
+        const uint32_t kOob = 0x80000000u;
+        uint32_t vsel[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + ob_u);
+            const int xl = a.dil * 8 * hk;
+            vsel[c] = (xs0 + xl < a.W) ? (uint32_t)((xl * a.Cout + n) * 4) : kOob;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ty = mt_u * 4 + (r >> 2), c = r & 3;
+            const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + ob_u);
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + aa);
+                if (yy >= a.H) continue;                             // wave-uniform
+                const uint32_t soff = (uint32_t)((yy * a.W + xs0) * a.Cout * 4);
+                float v = y[aa][r] + sh;
+                v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vsel[c], soff, 0));   // zero-record descriptor without a residual
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, act_apply(v, a.act)), o_rsrc, vsel[c], soff, 0);
+            }
+        }
+    } else {
+        // rows = couts n0 + 32 nt + (r & 3) + 8 (r >> 2) + 4 hk, columns (lanes) = tiles of m-tile mt (tile = 32 mt + li); output column ob
+        float z[2] = {0.f, 0.f};
+        float shv[16], wv[16];
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int co = n0 + nt * 32 + 8 * g4 + 4 * hk;
+            const float4 s4 = *reinterpret_cast<const float4*>(a.shift + co), w4 = *reinterpret_cast<const float4*>(a.w2 + co);
+            shv[4 * g4] = s4.x; shv[4 * g4 + 1] = s4.y; shv[4 * g4 + 2] = s4.z; shv[4 * g4 + 3] = s4.w;
+            wv[4 * g4] = w4.x; wv[4 * g4 + 1] = w4.y; wv[4 * g4 + 2] = w4.z; wv[4 * g4 + 3] = w4.w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o) z[o] += fmaxf(y[o][r] + shv[r], 0.f) * wv[r];
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) z[o] += __shfl_xor(z[o], 32, 64);
+        __syncthreads();                                             // every wave has read its exchange data
+        float* red = reinterpret_cast<float*>(smem);                 // [nt][tile][output row][output column]
+        if (hk == 0) {
+            red[((nt * NTILE + mt * 32 + li) * 2 + 0) * 2 + ob] = z[0];
+            red[((nt * NTILE + mt * 32 + li) * 2 + 1) * 2 + ob] = z[1];
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int tile = tid >> 2, q = tid & 3;                  // q = 2 * output row + output column
+            const int uy = by * 2 * TB + 2 * (tile >> 3) + (q >> 1), ux = bx * 2 * TB + 2 * (tile & 7) + (q & 1);
+            const int yy = ry + a.dil * uy, xx = rx + a.dil * ux;
+            if (yy < a.H && xx < a.W) {
+                const float zz = red[tile * 4 + q] + red[(NTILE + tile) * 4 + q] + a.b2[0];
+                a.out[((int64_t)b * a.H + yy) * a.W + xx] = 1.0f / (1.0f + expf(-zz));
+            }
+        }
+    }
+}
+
+
 // (Measured and dropped in round 3: the same block on SIXTEEN waves of 128 registers — wave = 2 positions x 64 tiles x 32 couts, every
 // slot all 1 024 threads share the transform (item = tile x channel pair x one V row), eight waves multiply.  Correct on the first
 // run and 5-10 % slower than this kernel on every shape: 4, 8 and 16 waves all land at ~5 000 cycles per chunk, with MFMA 32 %,
@@ -974,8 +1399,8 @@ void wino8_kernel(ws_args a)
 template <int MODE, bool BF16>
 int launch_ws(const ws_args& a, hipStream_t s)
 {
-    static int w8 = -1;                                              // AWSEG_WINO8=0: the four-wave kernel of round 2 (A/B measurements)
-    if (w8 < 0) { const char* e = getenv("AWSEG_WINO8"); w8 = e ? atoi(e) : 1; }
+    static int w8 = -1;                                              // AWSEG_WINO8=0: the four-wave kernel of round 2, 1: eight waves with alternating roles, 2: symmetric slots (A/B measurements)
+    if (w8 < 0) { const char* e = getenv("AWSEG_WINO8"); w8 = e ? atoi(e) : 2; }
     const int64_t tiles = (int64_t)a.nbx * a.dil * a.nby * a.dil * a.batch;
     const int64_t nblocks = ((tiles + 7) / 8) * a.ngroups * 8;
     if (nblocks >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
@@ -988,7 +1413,7 @@ int launch_ws(const ws_args& a, hipStream_t s)
         if (span > tiles_x) span = (int)tiles_x;
         while (tiles_x % span) --span;                                   // whole spans only (the grid stays a rectangle)
         a8.span = span;
-        auto k8 = wino8_kernel<MODE, BF16>;
+        auto k8 = w8 == 2 ? wino8s_kernel<MODE, BF16> : wino8_kernel<MODE, BF16>;
         constexpr int LDS8 = (LDS_BYTES > X_BYTES ? LDS_BYTES : X_BYTES);
         hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
         if (e8 != hipSuccess) return (int)e8;

@@ -45,6 +45,7 @@ static void run(int B, int H, int W, int cin, int cout, int dil, bool head)
         if (m > 0) printf("  8-wave kernel, block 0 wave %d (%s rows): per chunk: slot A work %.0f | barrier A %.0f | slot B work %.0f | barrier B %.0f | total %.0f (%.0f chunks)\n",
                           4 * g, g ? "odd: A = DMA + U + transform, B = MFMA" : "even: A = MFMA, B = U + transform", w8[g][0] / m, w8[g][1] / m, w8[g][2] / m, w8[g][3] / m,
                           (w8[g][0] + w8[g][1] + w8[g][2] + w8[g][3]) / m, m);
+        if (m > 0 && w8[g][5]) printf("      symmetric kernel, slot A in detail: %s %.0f | patch DMA issue %.0f\n", g ? "(waves 4-7) DMA issue" : "(waves 0-3) MFMAs + U fetch", w8[g][5] / m, w8[g][6] / m);
     }
     unsigned long long z2[2][8]; memset(z2, 0, sizeof z2);
     hipMemcpyToSymbol(HIP_SYMBOL(g_w8_stamp), z2, sizeof z2);

@@ -995,6 +995,13 @@ void wino8_kernel(ws_args a)
 //   * U: the two rows' fragments are re-fetched right behind the MFMAs that consumed them (for the next chunk): 4 loads per slot;
 //   * epilogue: the inverse transform over the V rows happens in registers (a wave holds all four rows of its column), the
 //     columns meet through LDS: wave (nt, j) finishes m-tile j >> 1, output COLUMN j & 1, both output rows.
+// Stamps: 3 700 cycles per chunk (wino8_kernel: 4 950), both slots ~1 500-1 900 with ~150 at each barrier; the clock under the
+// kernel drops with it (2.13 -> 1.77 GHz from time / cycles), so the launch times fall by 7-10 %, not 25 %.
+// (Measured and dropped: (1) issuing the slot's LDS reads for BOTH jobs up front — 256 registers, 3-4 spilled, 2 % slower;
+// (2) ONE instruction stream per slot, a piece of the transform pinned behind each MFMA with scheduling barriers — an MFMA leaves
+// the issue port after 8 of its 32 cycles, so the vector work would ride for free: needs ~270 registers next to 128 accumulators
+// and 32 of U; hipcc spills whole accumulators of the rows the slot does not touch and the kernel runs 2x slower.  It fits the
+// bf16 variant (236 registers) only.)
 template <int MODE, bool BF16>
 __global__ __launch_bounds__(W8T, 2)
 void wino8s_kernel(ws_args a)

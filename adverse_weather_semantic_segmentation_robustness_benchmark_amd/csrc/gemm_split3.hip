@@ -75,6 +75,7 @@ struct g3_args {
     const unsigned* trailer;               // {max|w| bits, weight exponent ew, 0, 0}
     int64_t M; int N, K, act, ntm, ntm8, ntn;
     int rot;                               // measurement switch (AWSEG_G3_ROT): block b starts its K loop at K tile (b * rot) % nkt
+    int stagger;                           // AWSEG_G3_STAGGER (default 1): waves 4-7 issue their LDS-DMA between the two 16-deep steps of a K tile
     // CONV: x is an NHWC image batch [B, cH, cW, cC] (cC % 32 == 0: a K tile lies inside one tap) and row m = (b, oy, ox) of the
     // A operand is gathered from it by the LDS-DMA's per-lane source address — column k = (ky * ckw + kx) * cC + c is
     // x[b, oy * cs - cp + ky * cd, ox * cs - cp + kx * cd, c], zero outside (awseg_conv_gemm_split_bias_act)
@@ -235,11 +236,16 @@ void gemm_split3_kernel(g3_args a)
             if (t == 0 && stores_pending) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G3_TRANSPOSED ? 32 : 63) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (t + 1 < nkt && ABL != 1) issue(ktile(t + 1), st ^ 1);     // (the next output tile's first K tile is issued behind the guard check)
+            // (the next output tile's first K tile is issued behind the guard check.)  Issuing its eight LDS-DMA instructions keeps a
+            // wave away from its MFMAs for ~800 cycles (tools/probe_wino_stamps.hip: ~100 per instruction): waves 0-3 do it here, their
+            // SIMD partners 4-7 between the two 16-deep steps, so a SIMD always has one wave multiplying (AWSEG_G3_STAGGER=0: all here)
+            const bool issue_late = a.stagger && wave_u >= 4;
+            if (t + 1 < nkt && ABL != 1 && !issue_late) issue(ktile(t + 1), st ^ 1);
             if (t == 0 && tid == 0) sMax[par ^ 1] = 0u;
             const unsigned char* sa = smem + st * G3_STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1 && t + 1 < nkt && ABL != 1 && issue_late) issue(ktile(t + 1), st ^ 1);
                 f32x4 p, q;
                 if (ABL == 4) { p = f32x4{(float)t, 1.f, 2.f, 3.f}; q = f32x4{(float)ks, 1.f, 2.f, 3.f}; }
                 else {
@@ -485,6 +491,9 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     static int rot = -1;
     if (rot < 0) { const char* e = getenv("AWSEG_G3_ROT"); rot = e ? atoi(e) : 0; }
     a.rot = rot;
+    static int stagger = -1;
+    if (stagger < 0) { const char* e = getenv("AWSEG_G3_STAGGER"); stagger = e ? atoi(e) : 1; }
+    a.stagger = stagger;
     a.x = x; a.w3 = w3; a.bias = bias; a.residual = residual; a.out = out; a.trailer = trailer;
     a.M = m; a.N = n; a.K = k; a.act = act;
     const int64_t ntm = (m + G3M - 1) / G3M;

@@ -70,6 +70,15 @@ __device__ __forceinline__ void split2(float a, float b, float s, unsigned& hi, 
         : "=&v"(hi), "=&v"(lo) : "v"(a), "v"(b), "s"(s));
 }
 
+#ifdef AWSEG_G3_STAMP
+// tools/scratch/g3_stamps.py: s_memtime stamps of block 0, waves 0 and 4, summed over K tiles:
+// [wait + barrier, DMA issue at the top, first 16-deep step, (late DMA issue +) second step, K tiles, whole tile loop incl. epilogue]
+__device__ unsigned long long g_g3_stamp[2][8];
+#define G3_T(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define G3_T(v)
+#endif
+
 struct g3_args {
     const float* x; const uint16_t* w3; const float* bias; const float* residual; float* out;
     const unsigned* trailer;               // {max|w| bits, weight exponent ew, 0, 0}
@@ -210,6 +219,10 @@ void gemm_split3_kernel(g3_args a)
     int g = 0;                                                    // running K-tile counter: stage = g & 1 across output tiles
     const int kt0 = a.rot ? (int)(((unsigned)blockIdx.x * (unsigned)a.rot) % (unsigned)nkt) : 0;
     auto ktile = [&](int t) { const int u = t + kt0; return u >= nkt ? u - nkt : u; };
+#ifdef AWSEG_G3_STAMP
+    unsigned long long g3s[6] = {0, 0, 0, 0, 0, 0};
+    G3_T(sb0);
+#endif
     point(m0, n0);
     issue(ktile(0), 0);
 
@@ -233,6 +246,7 @@ void gemm_split3_kernel(g3_args a)
             // (first K tile behind an epilogue: the epilogue's stores — 128, or 32 in the transposed form — are the youngest
             // vector-memory operations and the 8 LDS-DMA of this K tile are older than all of them: "at most 63 (32)
             // outstanding" means the DMA have landed, without waiting out the stores' write latency)
+            G3_T(s0);
             if (t == 0 && stores_pending) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G3_TRANSPOSED ? 32 : 63) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -240,11 +254,16 @@ void gemm_split3_kernel(g3_args a)
             // wave away from its MFMAs for ~800 cycles (tools/probe_wino_stamps.hip: ~100 per instruction): waves 0-3 do it here, their
             // SIMD partners 4-7 between the two 16-deep steps, so a SIMD always has one wave multiplying (AWSEG_G3_STAGGER=0: all here)
             const bool issue_late = a.stagger && wave_u >= 4;
+            G3_T(s1);
             if (t + 1 < nkt && ABL != 1 && !issue_late) issue(ktile(t + 1), st ^ 1);
+            G3_T(s2);
             if (t == 0 && tid == 0) sMax[par ^ 1] = 0u;
             const unsigned char* sa = smem + st * G3_STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+#ifdef AWSEG_G3_STAMP
+                if (ks == 1) { G3_T(s3); g3s[2] += s3 - s2; g3s[5] = s3; }
+#endif
                 if (ks == 1 && t + 1 < nkt && ABL != 1 && issue_late) issue(ktile(t + 1), st ^ 1);
                 f32x4 p, q;
                 if (ABL == 4) { p = f32x4{(float)t, 1.f, 2.f, 3.f}; q = f32x4{(float)ks, 1.f, 2.f, 3.f}; }
@@ -295,6 +314,9 @@ void gemm_split3_kernel(g3_args a)
                     }
                 }
             }
+#ifdef AWSEG_G3_STAMP
+            { G3_T(s4); g3s[0] += s1 - s0; g3s[1] += s2 - s1; g3s[3] += s4 - g3s[5]; g3s[4] += 1; }
+#endif
         }
 
         // ---- range guard (gemm_split.hip): the block's max|x| of this pass, through LDS
@@ -409,6 +431,13 @@ void gemm_split3_kernel(g3_args a)
         scaled = false; sx = kActScale0; xe = kActExp0;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef AWSEG_G3_STAMP
+    if (blockIdx.x == 0 && (tid == 0 || tid == 256)) {
+        G3_T(sb1);
+        for (int i = 0; i < 5; ++i) g_g3_stamp[tid >> 8][i] += g3s[i];
+        g_g3_stamp[tid >> 8][5] += sb1 - sb0;
+    }
+#endif
 }
 
 // weights float32 [N][K] (normalised by 2^-e, the trailer's exponent) -> the k-blocked image [N/256][KB][256][32 hi | 32 lo],
@@ -535,3 +564,12 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef AWSEG_G3_STAMP
+AWSEG_API int awseg_debug_g3_stamps(unsigned long long* out16, int reset)
+{
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_g3_stamp), sizeof(unsigned long long) * 16);
+    if (e == hipSuccess && reset) { unsigned long long z[16] = {}; e = hipMemcpyToSymbol(HIP_SYMBOL(g_g3_stamp), z, sizeof z); }
+    return (int)e;
+}
+#endif

@@ -402,16 +402,27 @@ void gemm_split3_kernel(g3_args a)
             const int voff = ((wave * 32 + 4 * hk) * a.N + li) * 4;
             const float relu_floor = a.act == 1 ? 0.f : -__builtin_inff();
             const int rowb = a.N * 4;                              // bytes per output row
+            const bool has_res = a.residual != nullptr;           // without one the 16 residual loads per column tile are not issued (-3 % at K = 256)
+            // (Measured and dropped: the tile through this wave's 8 KB of the free stage to FULL-ROW 16-byte stores — a quarter of the
+            // store instructions, whole 128-byte lines per instruction: 5-25 % SLOWER on every epilogue-heavy shape (K = 64: 0.47 ->
+            // 0.59 ms).  The stamps put ~23 k cycles of a 56 k-cycle K = 256 tile into the epilogue: that is 256 KB at the ~10 B/clk a CU
+            // gets of the HBM write rate when every CU writes, drained inside the next tile's first two K-tile waits — vmcnt counts
+            // loads and stores together on gfx9, so a wave cannot wait for its LDS-DMA without waiting for its stores.)
 #pragma unroll
             for (int j = 0; j < NT; ++j) {
                 const float bvj = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, (j * 32 + li) * 4, 0, 0));
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
                     float rv[8];
+                    if (has_res) {                                  // block-uniform (dword accesses: none of the 16-byte store hazards of DESIGN.md 10a)
 #pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
-                        rv[r8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, voff + j * 128, rowc * rowb, 0));
+                        for (int r8 = 0; r8 < 8; ++r8) {
+                            const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
+                            rv[r8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, voff + j * 128, rowc * rowb, 0));
+                        }
+                    } else {
+#pragma unroll
+                        for (int r8 = 0; r8 < 8; ++r8) rv[r8] = 0.f;
                     }
 #pragma unroll
                     for (int r8 = 0; r8 < 8; ++r8) {

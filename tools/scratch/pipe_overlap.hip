@@ -46,6 +46,32 @@ __device__ __forceinline__ void valu_kind_chain(float (&r)[4], float c, int iter
     r[3] += p0.x + p1.y + p2.x + p3.y + (float)(u0 + u1 + u2 + u3);
 }
 
+// ONE wave doing both jobs in one stream: an MFMA (rotating over four accumulators), then a transform piece — 4 plain vector ops,
+// a v_cvt_pkrtz and 2 v_fma_mix — with an operand ds_read_b128 every third and a ds_write_b64 every second step
+__device__ __forceinline__ void fused_like_chain(f16v (&acc)[4], float (&r)[4], unsigned addr, h8 b, int iters)
+{
+    h8 v0 = b, v1 = b;
+    unsigned u0 = 1, u1 = 2;
+    for (int it = 0; it < iters; ++it) {
+        REP8(asm volatile("v_mfma_f32_32x32x16_f16 %0, %4, %6, %0\n\tv_fma_f32 %7, %7, %11, %11\n\tv_fma_f32 %8, %8, %11, %11\n\tv_fma_f32 %9, %9, %11, %11\n\tv_fma_f32 %10, %10, %11, %11\n\t"
+                          "v_cvt_pkrtz_f16_f32 %12, %7, %8\n\tv_fma_mixlo_f16 %13, %7, 1.0, -%12 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %13, %8, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                          "ds_read_b128 %5, %14 offset:4096\n\t"
+                          "v_mfma_f32_32x32x16_f16 %1, %4, %6, %1\n\tv_fma_f32 %7, %7, %11, %11\n\tv_fma_f32 %8, %8, %11, %11\n\tv_fma_f32 %9, %9, %11, %11\n\tv_fma_f32 %10, %10, %11, %11\n\t"
+                          "v_cvt_pkrtz_f16_f32 %12, %9, %10\n\tv_fma_mixlo_f16 %13, %9, 1.0, -%12 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %13, %10, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                          "ds_write_b64 %14, %15 offset:16384\n\t"
+                          "s_waitcnt lgkmcnt(1)\n\t"
+                          "v_mfma_f32_32x32x16_f16 %2, %5, %6, %2\n\tv_fma_f32 %7, %7, %11, %11\n\tv_fma_f32 %8, %8, %11, %11\n\tv_fma_f32 %9, %9, %11, %11\n\tv_fma_f32 %10, %10, %11, %11\n\t"
+                          "v_cvt_pkrtz_f16_f32 %12, %7, %8\n\tv_fma_mixlo_f16 %13, %7, 1.0, -%12 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %13, %8, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                          "ds_read_b128 %4, %14\n\t"
+                          "v_mfma_f32_32x32x16_f16 %3, %5, %6, %3\n\tv_fma_f32 %7, %7, %11, %11\n\tv_fma_f32 %8, %8, %11, %11\n\tv_fma_f32 %9, %9, %11, %11\n\tv_fma_f32 %10, %10, %11, %11\n\t"
+                          "v_cvt_pkrtz_f16_f32 %12, %9, %10\n\tv_fma_mixlo_f16 %13, %9, 1.0, -%12 op_sel_hi:[0,0,1]\n\tv_fma_mixhi_f16 %13, %10, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+                          "ds_write_b64 %14, %15 offset:20480\n\t"
+                          "s_waitcnt lgkmcnt(1)"
+                          : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(v0), "+v"(v1)
+                          : "v"(b), "v"(r[0]), "v"(r[1]), "v"(r[2]), "v"(r[3]), "v"(1.0001f), "v"(u0), "v"(u1), "v"(addr), "v"(*reinterpret_cast<unsigned long long*>(&r[0])) : "memory");)
+    }
+}
+
 // MFMA chain on ONE accumulator: every MFMA waits for its predecessor's result (SrcC)
 __device__ __forceinline__ void mfma_dep_chain(f16v& acc, h8 a, h8 b)
 {
@@ -123,6 +149,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, const float4* 
     else if (role == 1) valu_chain(r, 1.0001f, valu_iters);
     else if (role == 2) lds_chain(q, (threadIdx.x & 63) * 16, lds_iters);
     else if (role == 4) mfma_dep_chain(acc[0], a, b);
+    else if (role == 13) fused_like_chain(acc, r, (threadIdx.x & 63) * 16, b, 128);
     else if (role == 9) valu_kind_chain<0>(r, 1.0001f, valu_iters);
     else if (role == 10) valu_kind_chain<1>(r, 1.0001f, valu_iters);
     else if (role == 11) valu_kind_chain<2>(r, 1.0001f, valu_iters);
@@ -138,7 +165,7 @@ __global__ __launch_bounds__(512) void k(unsigned long long* out, const float4* 
     if (s == 12345.678f) out[63] = 1;
 }
 
-static const char* NAMES[] = {"MFMA", "VALU", "LDS", "idle", "MFMA1", "Mlike", "Malt", "Tlike", "Tvmem", "pkadd", "fmamix", "cvtrtz", "max3"};
+static const char* NAMES[] = {"MFMA", "VALU", "LDS", "idle", "MFMA1", "Mlike", "Malt", "Tlike", "Tvmem", "pkadd", "fmamix", "cvtrtz", "max3", "fused"};
 static const float4* G;
 static void run(unsigned long long* d, int ra, int rb, int by_half, int vi, int li)
 {
@@ -169,6 +196,8 @@ int main()
     for (int m : {4, 5, 6}) run(d, m, 3, 1, vi, li);
     for (int t : {7, 8}) run(d, t, 3, 1, vi, li);
     for (int m : {0, 4, 5, 6}) for (int t : {1, 7, 8}) run(d, m, t, 1, vi, li);
+    run(d, 13, 3, 1, vi, li);            // one wave per SIMD, both jobs in one stream: 4 096 MFMAs, each followed by 7 vector ops
+    run(d, 13, 13, 1, vi, li);           // two such waves per SIMD
     for (int t : {9, 10, 11, 12}) { run(d, t, 3, 1, vi, li); run(d, 0, t, 1, vi, li); run(d, 5, t, 1, vi, li); }
     return 0;
 }

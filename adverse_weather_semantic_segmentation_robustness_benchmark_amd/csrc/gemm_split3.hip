@@ -84,7 +84,7 @@ struct g3_args {
     const unsigned* trailer;               // {max|w| bits, weight exponent ew, 0, 0}
     int64_t M; int N, K, act, ntm, ntm8, ntn;
     int rot;                               // measurement switch (AWSEG_G3_ROT): block b starts its K loop at K tile (b * rot) % nkt
-    int prio;                              // AWSEG_G3_PRIO (default 1): waves 4-7 at raised priority during the first 16-deep step of a K tile
+    int prio;                              // AWSEG_G3_PRIO (default 0): waves 4-7 at raised priority during the first 16-deep step of a K tile
     int stagger;                           // AWSEG_G3_STAGGER (default 1): waves 4-7 issue their LDS-DMA between the two 16-deep steps of a K tile
     // CONV: x is an NHWC image batch [B, cH, cW, cC] (cC % 32 == 0: a K tile lies inside one tap) and row m = (b, oy, ox) of the
     // A operand is gathered from it by the LDS-DMA's per-lane source address — column k = (ky * ckw + kx) * cC + c is
@@ -264,7 +264,8 @@ void gemm_split3_kernel(g3_args a)
             for (int ks = 0; ks < 2; ++ks) {
                 // The arbiter favours the older wave of a SIMD: the stamps show waves 0-3 done with a K tile after 2 400 cycles and waiting
                 // 1 100 at the barrier for their partners, which finish the last third alone (one wave cannot keep the matrix pipe
-                // busy).  Waves 4-7 therefore run the FIRST 16-deep step at raised priority (AWSEG_G3_PRIO, default 1).
+                // busy).  AWSEG_G3_PRIO=1 runs the FIRST 16-deep step of waves 4-7 at raised priority: 1-4 % on the long-K shapes in
+                // isolation (l4 conv1 0.381 -> 0.367 ms), -0.3 % on the whole step in an A/B on one box: off by default.
                 if (a.prio && wave_u >= 4) { if (ks == 0) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #ifdef AWSEG_G3_STAMP
                 if (ks == 1) { G3_T(s3); g3s[2] += s3 - s2; g3s[5] = s3; }
@@ -540,7 +541,7 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     if (stagger < 0) { const char* e = getenv("AWSEG_G3_STAGGER"); stagger = e ? atoi(e) : 1; }
     a.stagger = stagger;
     static int prio = -1;
-    if (prio < 0) { const char* e = getenv("AWSEG_G3_PRIO"); prio = e ? atoi(e) : 1; }
+    if (prio < 0) { const char* e = getenv("AWSEG_G3_PRIO"); prio = e ? atoi(e) : 0; }
     a.prio = prio;
     a.x = x; a.w3 = w3; a.bias = bias; a.residual = residual; a.out = out; a.trailer = trailer;
     a.M = m; a.N = n; a.K = k; a.act = act;

@@ -180,8 +180,8 @@ def algorithmic_work(name, B, H, W, C, info):
 DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
                  "awseg_conv3x3_winograd_split_nhwc": ("wino8s_kernel<0, false>", "wino8s_kernel<1, false>", "wino8_kernel<0, false>", "wino8_kernel<1, false>", "wino_split_kernel<0, false>", "wino_split_kernel<1, false>"),
                  "awseg_conv3x3_winograd_bf16_nhwc": ("wino8s_kernel<0, true>", "wino8s_kernel<1, true>", "wino8_kernel<0, true>", "wino8_kernel<1, true>", "wino_split_kernel<0, true>", "wino_split_kernel<1, true>"),
-                 "awseg_gemm_split_bias_act": ("gemm_split3_kernel<false, 0, false>", "gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false", "gemm_split_kernel<2, 2, 4, 2, false, false, true", "gemm_split_kernel<2, 2, 4, 2, true, false, true"),
-                 "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true>", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
+                 "awseg_gemm_split_bias_act": ("gemm_split3_kernel<false, 0, false", "gemm_split3_kernel<true, 0, false", "gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false", "gemm_split_kernel<2, 2, 4, 2, false, false, true", "gemm_split_kernel<2, 2, 4, 2, true, false, true"),
+                 "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
                  "awseg_attention_d32_split": "attention_d32_split_kernel",
                  "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0", "awseg_combine_confusion_stats": "ensemble_stats_kernel<",
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_walk_kernel"}
@@ -191,7 +191,10 @@ TRAFFIC_TABLES = ["r03_bench_step_stats_and_traffic.csv", "r02_bench_step_stats_
                   "r01_kernel_bench_v4_stats_and_traffic.csv"]   # first match wins
 
 
-def pmc_traffic(name):
+B5_TRAFFIC_TABLE = "r03_bench_b5_step_stats_and_traffic.csv"     # the same passes of `bench.py --model b5_r101`
+
+
+def pmc_traffic(name, b5=False):
     """(HBM bytes per launch of `name`, source) from the committed PMC passes (profiles/: separate rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
     wide coalesced reads).  The first table is from THIS command (bench.py, mean over the launches of a
@@ -204,7 +207,7 @@ def pmc_traffic(name):
         return None, None
     if isinstance(keys, str):
         keys = (keys,)
-    for fname in TRAFFIC_TABLES:
+    for fname in ([B5_TRAFFIC_TABLE] if b5 else []) + TRAFFIC_TABLES:
         path = ROOT / "profiles" / fname
         if not path.exists():
             continue
@@ -214,7 +217,7 @@ def pmc_traffic(name):
         if hit:
             calls = sum(float(r["calls"]) for r in hit)
             kb = sum(float(r["calls"]) * (2.0 * float(r["FETCH_SIZE_KB"]) + float(r["WRITE_SIZE_KB"])) for r in hit) / calls
-            what = ("this command under rocprofv3, mean over a step's launches" if "bench_step" in fname
+            what = ("this command under rocprofv3, mean over a step's launches" if ("bench_step" in fname or fname == B5_TRAFFIC_TABLE)
                     else "tools/kernel_bench.py, median per dispatch of its shapes")
             return int(kb * 1024), f"profiles/{fname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes; {what})"
     return None, None
@@ -773,7 +776,7 @@ def main():
     roofline = None
     if kernels:
         k0 = kernels[0]
-        traffic, tsrc = pmc_traffic(k0["kernel"])
+        traffic, tsrc = pmc_traffic(k0["kernel"], b5=bf16)
         roofline = {"kernel": k0["kernel"], "bound": ("mfma" if k0["bound"].startswith("mfma") else "hbm"), "achieved": k0["achieved"],
                     "peak": k0["peak"], "unit": k0["unit"], "frac": k0["frac"], "traffic": traffic, "traffic_source": tsrc,
                     "measured": f"HIP events around each launch on the launching stream, {args.kernel_steps} untimed steps after the timed region"}
@@ -782,7 +785,8 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             try:
-                cpu = cpu_baseline(model, H, W, C)
+                # B5 + R101 on the host: the forward on a quarter of the pixels, time x 4 (keeps the sample inside ~30 s)
+                cpu = cpu_baseline(model, H, W, C, fwd_div=2 if bf16 else 1)
             except Exception as e:  # noqa: BLE001
                 cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         split = ops.split_state()
@@ -805,7 +809,8 @@ def main():
                                   else "none (frames resident in HBM)"),
                        "include_depth": not args.no_depth, "eval_stats_in_step": with_stats,
                        "weather_rng": "philox (in-kernel), keyed by global frame index", "ensemble_logits_materialised": False,
-                       "split_operand_kernels": split,
+                       "split_operand_kernels": (None if bf16 else split),
+                       "bf16_mfma_kernels": (["awseg_gemm_bf16_bias_act", "awseg_conv3x3_winograd_bf16_nhwc", "awseg_attention_d32_bf16"] if bf16 else None),
                        "weights": "random init (no checkpoints offline)",
                        "parallelism": f"batch-sharded x{world}, one counter all-reduce (int64 confusion + ECE bins + AUROC histogram)",
                        "dist_backend": backend},

@@ -185,12 +185,19 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
     lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(ra, rb));
 }
 // the same without scaling the residual: for values whose low part is a normal (or harmlessly subnormal) f16 as is
+// Three instructions (wino_split.hip): v_cvt_pkrtz_f16_f32, then one mixed-precision FMA per value — x * 1.0 + (-hi) with the f16
+// source widened and the sum taken in float32 (exact), rounded to f16 into one half of the destination.  (The plain form is six:
+// two v_cvt_f32_f16, two subtracts, a second pack; the loop is bound by its vector instruction count: -1.6 % on stage 1.)
+// Only the probabilities use it.  Q, K and V keep the x 2048 low parts: unscaled ones are subnormal below |x| = 2^-3, an ABSOLUTE
+// 2^-25 that the tests with a small q against one large k (flat softmax) and with whole tensors at 1e-5 (tiny operands: 5e-6
+// RELATIVE) do not allow — both were tried.
 __device__ __forceinline__ void split_pair_unscaled(float a, float b, unsigned& hi, unsigned& lo)
 {
-    const auto hp = __builtin_amdgcn_cvt_pkrtz(a, b);
-    const h2 hh = __builtin_bit_cast(h2, hp);
-    hi = __builtin_bit_cast(unsigned, hp);
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a - (float)hh.x, b - (float)hh.y));
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(a, b));
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%3 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %2, 1.0, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"          // the low parts go straight into an MFMA operand register: two wait states hipcc does not pad behind inline asm
+        : "=&v"(lo) : "v"(a), "v"(b), "v"(hi));
 }
 __device__ __forceinline__ void split8_unscaled(const float* x, h8& hi, h8& lo)
 {

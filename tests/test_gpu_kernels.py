@@ -610,6 +610,32 @@ def test_conv3x3_winograd_split_float32_grade(ops, shape, xscale, wscale):
         assert got.shape == (B, H, W) and (got.double() - want).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("dil", [1, 2])
+def test_conv3x3_winograd_split_range_guard_sees_every_input_element(ops, dil):
+    """The symmetric eight-wave kernel takes max|x| once per input row of the 4x4 tiles (row 1 by the threads that build V row 1,
+    row 3 by V row 3's, rows 0 and 2 by V row 0's): ONE out-of-range activation anywhere — block corners, tile seams, the halo
+    rows / columns a block shares with its neighbours, the image border, any channel chunk — must send its block through the
+    rescaled pass.  Unnoticed, a 3e5 input saturates the f16 high part and the output is off by orders of magnitude."""
+    B, H, W, Cin, Cout = 1, 40, 52, 48, 64
+    g = torch.Generator(device="cuda").manual_seed(101 + dil)
+    wt = torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (3.0 * Cin ** 0.5)
+    shift = torch.randn(Cout, device="cuda", generator=g)
+    us = ops.winograd_split_weights(wt, None)
+    base = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    spots = [(0, 0, 0), (H - 1, W - 1, Cin - 1), (15, 15, 5), (15, 16, 17), (16, 15, 31), (16, 16, 32), (17, 17, 47), (14, 31, 16), (31, 32, 15),
+             (33, 1, 20), (2, 49, 40), (39, 0, 3), (0, 51, 44), (20, 20, 0)]
+    spots += [(int(y), int(x), int(c)) for y, x, c in zip(torch.randint(0, H, (10,), generator=torch.Generator().manual_seed(5)).tolist(),
+                                                          torch.randint(0, W, (10,), generator=torch.Generator().manual_seed(6)).tolist(),
+                                                          torch.randint(0, Cin, (10,), generator=torch.Generator().manual_seed(7)).tolist())]
+    for (y, x, c) in spots:
+        xin = base.clone()
+        xin[0, y, x, c] = 3.0e5
+        ref = torch.nn.functional.conv2d(xin.permute(0, 3, 1, 2).double(), wt.double(), None, 1, dil, dil).permute(0, 2, 3, 1) + shift.double()
+        got = ops.conv3x3_winograd_split(xin, us, Cout, shift, act=0, dilation=dil)
+        err = (got.double() - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-5, f"spot {(y, x, c)} dilation {dil}: relative error {err:.3e}"
+
+
 def test_conv3x3_winograd_split_abi_checks(ops, native):
     N = native
     sh = torch.zeros(64, device="cuda")

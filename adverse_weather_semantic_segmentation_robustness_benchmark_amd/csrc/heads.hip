@@ -1135,6 +1135,150 @@ void upconv3x3_adjoint_kernel(const float* __restrict__ dz, int h, int w, int H,
         }
     }
 }
+// The same walk with a lane per (rate, column, channel quad) that goes through ALL row classes of its rate one after the other — every
+// lane visits each of the h input rows exactly once (h x 3 loads, h stores), the nine filter taps are loaded once per lane (in the
+// kernel above a lane lives for one class: 1-2 loop iterations behind 9 weight loads and the index arithmetic — half of its load
+// instructions were weights).  Same expressions in the same order per output: bit-identical.  AWSEG_ASPP_ROWS=0 selects the kernel above.
+__global__ __launch_bounds__(kThreads)
+void aspp_dw3_rows_kernel(const float* __restrict__ x, int64_t batch, int h, int w, int C,
+                          const float* __restrict__ wdw, int r0, int r1, int r2, float* __restrict__ out,
+                          int n_units, int blocks_per_unit, int slice_q)
+{
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int unit = (jb / blocks_per_unit) * 8 + xcd, blk = jb % blocks_per_unit;
+    if (unit >= n_units) return;
+    const int slices = (C / 4) / slice_q;
+    const int b = unit / slices, sl = unit - b * slices;
+    const int item = blk * kThreads + threadIdx.x;                 // (rate, column, quad within the slice)
+    const int q = item % slice_q, t = item / slice_q;
+    const int xx = t % w, r = t / w;
+    if (r >= 3) return;
+    const int d = r == 0 ? r0 : (r == 1 ? r1 : r2);
+    const int ncl = d < h ? d : h;
+    const int c = (sl * slice_q + q) * 4;
+    const float* xb = x + (int64_t)b * h * w * C + c;
+    float* ob = out + (int64_t)r * (batch * (int64_t)h * w * C) + (int64_t)b * h * w * C + c;
+    float4 k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = *reinterpret_cast<const float4*>(wdw + ((int64_t)r * 9 + i) * C + c);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool okl = xx - d >= 0, okr = xx + d < w;
+    auto row = [&](int s, float4* v) {
+        const float* p = xb + ((int64_t)s * w + xx) * C;
+        v[0] = okl ? *reinterpret_cast<const float4*>(p - (int64_t)d * C) : zero;
+        v[1] = *reinterpret_cast<const float4*>(p);
+        v[2] = okr ? *reinterpret_cast<const float4*>(p + (int64_t)d * C) : zero;
+    };
+    auto hsum = [&](int ky, const float4* v) {
+        float4 a;
+        a.x = v[0].x * k[ky * 3].x; a.y = v[0].y * k[ky * 3].y; a.z = v[0].z * k[ky * 3].z; a.w = v[0].w * k[ky * 3].w;
+        a.x = fmaf(v[1].x, k[ky * 3 + 1].x, a.x); a.y = fmaf(v[1].y, k[ky * 3 + 1].y, a.y);
+        a.z = fmaf(v[1].z, k[ky * 3 + 1].z, a.z); a.w = fmaf(v[1].w, k[ky * 3 + 1].w, a.w);
+        a.x = fmaf(v[2].x, k[ky * 3 + 2].x, a.x); a.y = fmaf(v[2].y, k[ky * 3 + 2].y, a.y);
+        a.z = fmaf(v[2].z, k[ky * 3 + 2].z, a.z); a.w = fmaf(v[2].w, k[ky * 3 + 2].w, a.w);
+        return a;
+    };
+    for (int j = 0; j < ncl; ++j) {
+        float4 accA = zero, accB = zero;
+        for (int s0 = j; s0 < h; s0 += 3 * d) {
+            float4 v[3][3];
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                if (s0 + g * d < h) row(s0 + g * d, v[g]);
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+                const int s = s0 + g * d;
+                if (s >= h) break;
+                const float4 h0 = hsum(0, v[g]), h1 = hsum(1, v[g]), h2 = hsum(2, v[g]);
+                if (s != j)
+                    st_stream(ob + ((int64_t)(s - d) * w + xx) * C, make_float4(accA.x + h2.x, accA.y + h2.y, accA.z + h2.z, accA.w + h2.w));
+                accA = make_float4(accB.x + h1.x, accB.y + h1.y, accB.z + h1.z, accB.w + h1.w);
+                accB = h0;
+                if (s + d >= h) st_stream(ob + ((int64_t)s * w + xx) * C, accA);
+            }
+        }
+    }
+}
+
+// The walk with the input row staged in LDS.  The kernels above fetch every input element three times per rate from L2 (the three
+// column taps are three different lanes): 4.8 GB of L2 -> CU loads + 1.6 GB of stores per launch at 8 x 64 x 128 x 2048, and the
+// launch takes exactly what the ~8 TB/s L2 <-> CU path allows (0.8 ms) whatever the unit size.  Here a block of w x 8 threads is one
+// (image, 32-channel slice, rate): thread = (column, channel quad); per step of the class walk every thread loads ITS pixel's quad
+// of input row s (one full 128-byte line per pixel), the row goes through LDS (two buffers, one barrier per row), and the taps at
+// columns x - d and x + d come from there — each input element crosses L2 -> CU once per rate: 1.6 GB + 1.6 GB.  The three rates
+// of a unit are consecutive blocks of one XCD.  Same expressions in the same order per output: bit-identical to the kernels above.
+// 0.88 -> 0.68 ms at 8 x 64 x 128 x 2048 (39 % of the HBM rate for the 0.54 GB in + 1.6 GB out).  What is left is the write pattern the
+// NHWC layout forces on a channel-sliced kernel: 128 contiguous bytes per pixel, 8 KB apart (slice widths of 32-256 channels all
+// land within 5 % of each other; the 512-byte-per-pixel writes of awseg_upconv3x3_bn_relu reach 5.7 TB/s).
+constexpr int kAsppLdsQuads = 8;                                     // quads per slice: 128 bytes per pixel
+template <int AHEAD, bool NT>
+__global__ __launch_bounds__(1024)
+void aspp_dw3_lds_kernel(const float* __restrict__ x, int64_t batch, int h, int w, int C,
+                         const float* __restrict__ wdw, int r0, int r1, int r2, float* __restrict__ out, int n_units)
+{
+    extern __shared__ __attribute__((aligned(16))) float4 srow[];    // [2][w][8]
+    const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int unit = (jb / 3) * 8 + xcd, r = jb % 3;
+    if (unit >= n_units) return;
+    const int slices = (C / 4) / kAsppLdsQuads;
+    const int b = unit / slices, sl = unit - b * slices;
+    const int q = threadIdx.x % kAsppLdsQuads, xx = threadIdx.x / kAsppLdsQuads;     // blockDim.x == w * 8
+    const int d = r == 0 ? r0 : (r == 1 ? r1 : r2);
+    const int ncl = d < h ? d : h;
+    const int c = (sl * kAsppLdsQuads + q) * 4;
+    const float* xb = x + (int64_t)b * h * w * C + c + (int64_t)xx * C;
+    float* ob = out + (int64_t)r * (batch * (int64_t)h * w * C) + (int64_t)b * h * w * C + c + (int64_t)xx * C;
+    float4 k[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) k[i] = *reinterpret_cast<const float4*>(wdw + ((int64_t)r * 9 + i) * C + c);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool okl = xx - d >= 0, okr = xx + d < w;
+    const int il = (xx - d) * kAsppLdsQuads + q, ir = (xx + d) * kAsppLdsQuads + q, rowq = w * kAsppLdsQuads;
+    auto hsum = [&](int ky, const float4& v0, const float4& v1, const float4& v2) {
+        float4 a;
+        a.x = v0.x * k[ky * 3].x; a.y = v0.y * k[ky * 3].y; a.z = v0.z * k[ky * 3].z; a.w = v0.w * k[ky * 3].w;
+        a.x = fmaf(v1.x, k[ky * 3 + 1].x, a.x); a.y = fmaf(v1.y, k[ky * 3 + 1].y, a.y);
+        a.z = fmaf(v1.z, k[ky * 3 + 1].z, a.z); a.w = fmaf(v1.w, k[ky * 3 + 1].w, a.w);
+        a.x = fmaf(v2.x, k[ky * 3 + 2].x, a.x); a.y = fmaf(v2.y, k[ky * 3 + 2].y, a.y);
+        a.z = fmaf(v2.z, k[ky * 3 + 2].z, a.z); a.w = fmaf(v2.w, k[ky * 3 + 2].w, a.w);
+        return a;
+    };
+    // the rows in walk order: class 0: 0, d, 2d, ...; class 1: 1, 1 + d, ...  (every row of the map once).  A block sees one row at a
+    // time, so the loads run AHEAD rows ahead of the arithmetic (one row ahead left the block waiting a memory round trip per row)
+    auto put = [&](float* p, float4 v) { if (NT) st_stream(p, v); else *reinterpret_cast<float4*>(p) = v; };
+    auto step = [&](int& ss, int& jj) { ss += d; if (ss >= h) { ++jj; ss = jj; } };
+    float4 ring[AHEAD];
+    int ls = 0, lj = 0;                                           // the row the next load fetches
+#pragma unroll
+    for (int i = 0; i < AHEAD; ++i) {
+        ring[i] = lj < ncl ? *reinterpret_cast<const float4*>(xb + (int64_t)ls * w * C) : zero;
+        step(ls, lj);
+    }
+    int j = 0, s = 0, buf = 0;
+    float4 accA = zero, accB = zero;
+    while (j < ncl) {
+#pragma unroll
+        for (int i = 0; i < AHEAD; ++i) {                         // (unrolled so that the ring stays in registers)
+            if (j >= ncl) break;
+            const float4 cur = ring[i];
+            ring[i] = lj < ncl ? *reinterpret_cast<const float4*>(xb + (int64_t)ls * w * C) : zero;
+            step(ls, lj);
+            srow[buf * rowq + threadIdx.x] = cur;
+            __syncthreads();
+            const float4 vl = okl ? srow[buf * rowq + il] : zero;
+            const float4 vr = okr ? srow[buf * rowq + ir] : zero;
+            const float4 h0 = hsum(0, vl, cur, vr), h1 = hsum(1, vl, cur, vr), h2 = hsum(2, vl, cur, vr);
+            if (s != j)
+                put(ob + (int64_t)(s - d) * w * C, make_float4(accA.x + h2.x, accA.y + h2.y, accA.z + h2.z, accA.w + h2.w));
+            accA = make_float4(accB.x + h1.x, accB.y + h1.y, accB.z + h1.z, accB.w + h1.w);
+            accB = h0;
+            if (s + d >= h) { put(ob + (int64_t)s * w * C, accA); accA = zero; accB = zero; }
+            step(s, j);
+            buf ^= 1;
+        }
+    }
+}
+
 }  // namespace
 
 AWSEG_API int awseg_upconv3x3_adjoint(const float* dz, int64_t batch, int cmid, int h, int w, int height, int width,
@@ -1162,6 +1306,33 @@ AWSEG_API int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w,
     if (rate0 < 1 || rate1 < 1 || rate2 < 1) return AWSEG_EINVAL;
     const int64_t ncls = (int64_t)(rate0 < h ? rate0 : h) + (rate1 < h ? rate1 : h) + (rate2 < h ? rate2 : h);
     static const int slice_q = getenv("AWSEG_ASPP_SLICE") ? atoi(getenv("AWSEG_ASPP_SLICE")) : kAsppSlice;
+    // the LDS-staged walk: a block is (image, 32-channel slice, rate) with w x 8 threads (AWSEG_ASPP_LDS=0: the kernels below)
+    static const bool lds = !(getenv("AWSEG_ASPP_LDS") && atoi(getenv("AWSEG_ASPP_LDS")) == 0);
+    if (lds && !flat && !taps && (channels / 4) % kAsppLdsQuads == 0 && w * kAsppLdsQuads <= 1024 && w * kAsppLdsQuads >= 64) {
+        const int n_units = (int)batch * ((channels / 4) / kAsppLdsQuads);
+        const int64_t grid = (int64_t)((n_units + 7) / 8) * 3 * 8;
+        if (grid < ((int64_t)1 << 31)) {
+            const size_t lds_bytes = (size_t)2 * w * kAsppLdsQuads * sizeof(float4);
+            // (measured: 4 rows of loads ahead 0.68 ms, 1 row 0.78, 8 rows 0.84, 12 rows 1.26; plain instead of non-temporal stores +2 %)
+            auto kern = aspp_dw3_lds_kernel<4, true>;
+            hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)(w * kAsppLdsQuads)), lds_bytes, awseg_s(stream), x, batch, h, w,
+                               channels, wdw, rate0, rate1, rate2, out, n_units);
+            AWSEG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
+    static const bool rows = !(getenv("AWSEG_ASPP_ROWS") && atoi(getenv("AWSEG_ASPP_ROWS")) == 0);
+    if (rows && !flat && !taps && slice_q >= 1 && (channels / 4) % slice_q == 0 && (int64_t)3 * w * slice_q < ((int64_t)1 << 30)) {
+        const int n_units = (int)batch * ((channels / 4) / slice_q);
+        const int bpu = (int)(((int64_t)3 * w * slice_q + kThreads - 1) / kThreads);
+        const int64_t grid = (int64_t)((n_units + 7) / 8) * bpu * 8;
+        if (grid < ((int64_t)1 << 31)) {
+            hipLaunchKernelGGL(aspp_dw3_rows_kernel, dim3((unsigned)grid), dim3(kThreads), 0, awseg_s(stream), x, batch, h, w, channels,
+                               wdw, rate0, rate1, rate2, out, n_units, bpu, slice_q);
+            AWSEG_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if (!flat && !taps && slice_q >= 1 && (channels / 4) % slice_q == 0 && ncls * w * slice_q < ((int64_t)1 << 30)) {
         const int n_units = (int)batch * ((channels / 4) / slice_q);
         const int bpu = (int)((ncls * w * slice_q + kThreads - 1) / kThreads);

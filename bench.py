@@ -184,7 +184,7 @@ DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
                  "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
                  "awseg_attention_d32_split": "attention_d32_split_kernel",
                  "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0", "awseg_combine_confusion_stats": "ensemble_stats_kernel<",
-                 "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": "aspp_dw3_walk_kernel"}
+                 "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": ("aspp_dw3_lds_kernel", "aspp_dw3_rows_kernel", "aspp_dw3_walk_kernel")}
 
 
 TRAFFIC_TABLES = ["r03_bench_step_stats_and_traffic.csv", "r02_bench_step_stats_and_traffic.csv", "r02_kernel_bench_stats_and_traffic.csv",

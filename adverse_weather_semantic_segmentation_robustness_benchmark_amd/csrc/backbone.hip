@@ -15,10 +15,28 @@ namespace {
 
 constexpr int kThreads = 256;
 
+// erf to 1.5e-7 absolute (Abramowitz & Stegun 7.1.26: 1 - (a1 t + ... + a5 t^5) exp(-x^2), t = 1 / (1 + p |x|)) with the hardware
+// reciprocal and exp2: 14 vector instructions, two of them transcendental.  The library erff is ~40 (two range branches, both
+// evaluated and selected): the depthwise 3x3 + GELU kernel spent 160 of its ~200 instructions per output quad there and was
+// bound by them, not by memory.  GELU error <= 0.5 |x| x 3e-7: two orders inside the 1e-4 gate (AWSEG_GELU_EXACT=1: erff).
+__device__ __forceinline__ float erf_as(float x)
+{
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = fmaf(-p, e, 1.0f);
+    return __builtin_copysignf(r, x);
+}
 __device__ __forceinline__ float act1(float v, int act)
 {
     if (act == 1) return v > 0.f ? v : 0.f;
-    if (act == 2) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // torch GELU (erf form)
+    if (act == 2) return 0.5f * v * (1.0f + erf_as(v * 0.70710678118654752440f));   // torch GELU (erf form), fast erf
+    if (act == 3) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));     // the same with the library erff
     return v;
 }
 __device__ __forceinline__ float4 act4(float4 v, int act)
@@ -694,6 +712,8 @@ AWSEG_API int awseg_dwconv3x3_nhwc(const float* x, int64_t batch, int height, in
 {
     if (!x || !w9 || !out || batch < 1 || height < 1 || width < 1 || channels < 4 || (channels & 3) || dilation < 1) return AWSEG_EINVAL;
     if (act < 0 || act > 2 || x == out) return AWSEG_EINVAL;
+    static const bool gelu_exact = getenv("AWSEG_GELU_EXACT") && atoi(getenv("AWSEG_GELU_EXACT")) != 0;
+    if (act == 2 && gelu_exact) act = 3;                          // library erff instead of the 14-instruction erf (act1)
     if (((uintptr_t)x & 15) || ((uintptr_t)w9 & 15) || ((uintptr_t)out & 15) || (bias && ((uintptr_t)bias & 15))) return AWSEG_EALIGN;
     static const bool one_row = getenv("AWSEG_DW_ONE_ROW") != nullptr;
     if (dilation == 1 && width >= 8 && height >= 2 && !one_row) {
@@ -723,6 +743,8 @@ AWSEG_API int awseg_bias_act_nhwc(float* x, int64_t n_pixels, int channels, cons
                                   int act, awseg_stream_t stream)
 {
     if (!x || n_pixels < 1 || channels < 4 || (channels & 3) || act < 0 || act > 2) return AWSEG_EINVAL;
+    static const bool gelu_exact = getenv("AWSEG_GELU_EXACT") && atoi(getenv("AWSEG_GELU_EXACT")) != 0;
+    if (act == 2 && gelu_exact) act = 3;
     if (((uintptr_t)x & 15) || (bias && ((uintptr_t)bias & 15)) || (residual && ((uintptr_t)residual & 15))) return AWSEG_EALIGN;
     const int64_t total = n_pixels * (channels / 4);
     hipLaunchKernelGGL(bias_act_nhwc_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, n_pixels,

@@ -25,6 +25,7 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python bench.py --mode train --steps 3 --warmup 2 > gpurun_out/${R}_bench_line_train_1024x2048_bs8.json 2> gpurun_out/${R}_bench_line_train.err; echo "bench train exit $?"
 du -sh $O/${R}_prof_* | tail -8
 # Afterwards, in the repo (CPU is enough):
+#   bash tools/make_round_profiles.sh        # or, step by step:
 #   python tools/make_profiles.py step gpurun_out/r03_prof_step ensemble_stats_kernel profiles/r03_bench_step_kernels.csv "<header>"
 #        (marker = a kernel that runs once per step: the one-pass confusion + statistics kernel)
 #   python tools/make_profiles.py kernel-table gpurun_out/r03_prof_step gpurun_out/r03_prof_step_fetch gpurun_out/r03_prof_step_write \

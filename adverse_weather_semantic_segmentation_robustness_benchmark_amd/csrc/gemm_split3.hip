@@ -414,31 +414,50 @@ void gemm_split3_kernel(g3_args a)
             // 0.59 ms).  The stamps put ~23 k cycles of a 56 k-cycle K = 256 tile into the epilogue: that is 256 KB at the ~10 B/clk a CU
             // gets of the HBM write rate when every CU writes, drained inside the next tile's first two K-tile waits — vmcnt counts
             // loads and stores together on gfx9, so a wave cannot wait for its LDS-DMA without waiting for its stores.)
+            // gfx9's vmcnt counts loads and stores in ONE in-order counter: a load whose value is needed after some stores were issued
+            // makes the wave wait for those stores' write acknowledgements.  The first build fetched the bias of a column tile behind
+            // the previous tile's 16 stores (eight such waits per output tile) — all NT bias values are fetched before the first
+            // store now, and handed on through an asm move so that hipcc stops tying later uses to the load; the residual of row
+            // group g + 1 is requested BEFORE the stores of group g, so its wait covers loads only.
+            float bv[NT], bld[NT];
 #pragma unroll
-            for (int j = 0; j < NT; ++j) {
-                const float bvj = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, (j * 32 + li) * 4, 0, 0));
+            for (int j = 0; j < NT; ++j) bld[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(b_rsrc, (j * 32 + li) * 4, 0, 0));
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    float rv[8];
-                    if (has_res) {                                  // block-uniform (dword accesses: none of the 16-byte store hazards of DESIGN.md 10a)
+            for (int j = 0; j < NT; ++j) asm volatile("v_mov_b32 %0, %1" : "=v"(bv[j]) : "v"(bld[j]));
+            auto res_load = [&](int g, float (&rv)[8]) {             // row group g = (column tile g >> 1, rows 8 (g & 1) .. + 7 of the register file)
+                const int j = g >> 1, half = g & 1;
 #pragma unroll
-                        for (int r8 = 0; r8 < 8; ++r8) {
-                            const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
-                            rv[r8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, voff + j * 128, rowc * rowb, 0));
-                        }
-                    } else {
-#pragma unroll
-                        for (int r8 = 0; r8 < 8; ++r8) rv[r8] = 0.f;
-                    }
-#pragma unroll
-                    for (int r8 = 0; r8 < 8; ++r8) {
-                        const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
-                        float vv = acc[j][r] * os1 * os2;
-                        vv = vv + bvj + rv[r8];
-                        vv = __builtin_fmaxf(vv, relu_floor);
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, voff + j * 128, rowc * rowb, 0);
-                    }
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
+                    rv[r8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, voff + j * 128, rowc * rowb, 0));
                 }
+            };
+            auto group_store = [&](int g, const float (&rv)[8], bool with_res) {
+                const int j = g >> 1, half = g & 1;
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
+                    float vv = acc[j][r] * os1 * os2;
+                    vv = vv + bv[j];
+                    if (with_res) vv = vv + rv[r8];
+                    vv = __builtin_fmaxf(vv, relu_floor);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, voff + j * 128, rowc * rowb, 0);
+                }
+            };
+            if (has_res) {                                          // block-uniform (dword accesses: none of the 16-byte store hazards of DESIGN.md 10a)
+                float rva[8], rvb[8];
+                res_load(0, rva);
+#pragma unroll
+                for (int g = 0; g < 2 * NT; g += 2) {
+                    res_load(g + 1, rvb);
+                    group_store(g, rva, true);
+                    if (g + 2 < 2 * NT) res_load(g + 2, rva);
+                    group_store(g + 1, rvb, true);
+                }
+            } else {
+                const float none[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int g = 0; g < 2 * NT; ++g) group_store(g, none, false);
             }
         }
 #endif

@@ -1002,10 +1002,17 @@ void wino8_kernel(ws_args a)
 // the issue port after 8 of its 32 cycles, so the vector work would ride for free: needs ~270 registers next to 128 accumulators
 // and 32 of U; hipcc spills whole accumulators of the rows the slot does not touch and the kernel runs 2x slower.  It fits the
 // bf16 variant (236 registers) only.)
+#ifdef AWSEG_WS_STAMP
+__device__ unsigned long long g_w8s_block[8];                         // block 0, wave 0: [prologue, chunk loop, epilogue, blocks] of the block in the middle of the grid
+#endif
 template <int MODE, bool BF16>
 __global__ __launch_bounds__(W8T, 2)
 void wino8s_kernel(ws_args a)
 {
+#ifdef AWSEG_WS_STAMP
+    const unsigned long long w8b0 = __builtin_readcyclecounter();
+    unsigned long long w8b1 = 0, w8b2 = 0;
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sV = smem;
     unsigned char* sP = smem + V_BYTES;
@@ -1059,6 +1066,8 @@ void wino8s_kernel(ws_args a)
         constexpr int N = decltype(NC)::value;
         if (three) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 2) : "memory");
     };
+
+    auto vm_wait_keep = [&](auto NC) { constexpr int N = decltype(NC)::value; asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); };
 
     // ---- transform item: (tile, channel quad) x ONE V row per slot (the thread's half of the block picks the row)
     const int it = tid & 255;
@@ -1201,10 +1210,11 @@ void wino8s_kernel(ws_args a)
                 for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
         // ---- prologue: patches 0 and 1 in flight, U of chunk 0, patch 0 landed; every thread builds its row (0 | 2) of chunk 0
         glds_patch(0, 0);
-        glds_patch(1, 1);
+        if (nchunks > 1) glds_patch(1, 1);
         u_fetch2(0, 0);
         u_fetch2(0, 1);
-        vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});            // patch 0: everything but patch 1 and the U fragments behind it
+        if (nchunks > 1) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});   // patch 0: everything but patch 1 and the U fragments behind it
+        else vm_wait_keep(awseg_int<BF16 ? 4 : 8>{});
         __syncthreads();                                             // (also orders sMax[0] = 0 and the previous pass's V reads)
         transform(0, awseg_true{});
         __syncthreads();
@@ -1218,24 +1228,30 @@ void wino8s_kernel(ws_args a)
 #define W8_ACC(t0, t1, t2, t3, t4)
 #define W8_FINE(t0, t1, t2)
 #endif
+#ifdef AWSEG_WS_STAMP
+        if (!SCALED) w8b1 = __builtin_readcyclecounter();
+#endif
         for (int c = 0; c < nchunks; ++c) {
             const bool more = c + 1 < nchunks;
             W8_T(q0);
             // slot A: MFMAs on rows {0, 2} of chunk c | patch c -> rows {1, 3} of chunk c | DMA of patch c + 2 (its ring slot held patch
             // c - 1, last read in slot A of chunk c - 1).  At the end patch c + 1 (DMA issued a chunk ago) has landed: behind it this
             // wave issued, in program order, the U loads counted below and one patch's DMA instructions.
+            // (no DMA past the last chunk: the two clamped re-fetches per block were 43 KB of wasted reads and a memory round trip
+            // in front of the epilogue; the wait then counts the U loads only)
+            const bool dma = c + 2 < nchunks;
             if (grp == 0) {
                 mma2(0);
                 if (more) u_fetch2(c + 1, 0);
                 W8_T(qa);
-                glds_patch(c + 2, (c + 2) % 3);
+                if (dma) glds_patch(c + 2, (c + 2) % 3);
                 W8_T(qb);
                 transform(c % 3, awseg_false{});
                 W8_FINE(q0, qa, qb)
-                if (more) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});      // U rows {1, 3} of chunk c (slot B), rows {0, 2} of chunk c + 1
+                if (more) { if (dma) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{}); else vm_wait_keep(awseg_int<BF16 ? 4 : 8>{}); }   // U rows {1, 3} of chunk c (slot B), rows {0, 2} of chunk c + 1
             } else {
                 W8_T(qa);
-                glds_patch(c + 2, (c + 2) % 3);
+                if (dma) glds_patch(c + 2, (c + 2) % 3);
                 W8_T(qb);
                 transform(c % 3, awseg_false{});
                 W8_T(qc);
@@ -1243,7 +1259,7 @@ void wino8s_kernel(ws_args a)
                 mma2(0);
                 if (more) {
                     u_fetch2(c + 1, 0);
-                    vm_wait_keep_patch_and(awseg_int<BF16 ? 6 : 12>{});           // U rows {0, 2} and {1, 3} of chunk c, rows {0, 2} of chunk c + 1
+                    if (dma) vm_wait_keep_patch_and(awseg_int<BF16 ? 6 : 12>{}); else vm_wait_keep(awseg_int<BF16 ? 6 : 12>{});            // U rows {0, 2} and {1, 3} of chunk c, rows {0, 2} of chunk c + 1
                 }
             }
             W8_T(q1);
@@ -1263,6 +1279,9 @@ void wino8s_kernel(ws_args a)
             W8_T(q4);
             W8_ACC(q0, q1, q2, q3, q4)
         }
+#ifdef AWSEG_WS_STAMP
+        if (!SCALED) w8b2 = __builtin_readcyclecounter();
+#endif
         vm_wait_all();
 #ifdef AWSEG_WS_STAMP
         if (blockIdx.x == 0 && (tid == 0 || tid == 256)) { for (int i = 0; i < 5; ++i) g_w8_stamp[tid >> 8][i] += w8s[i]; g_w8_stamp[tid >> 8][5] += w8f[0]; g_w8_stamp[tid >> 8][6] += w8f[1]; }
@@ -1274,7 +1293,10 @@ void wino8s_kernel(ws_args a)
 
     run(awseg_false{});
     if (!BF16) {
-        if (amax > 0.f) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, amax));
+        // (the stamps put 5 k cycles here: 512 lanes' LDS atomics on ONE word serialise — reduce over the wave first, one atomic per wave)
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, o, 64));
+        if (lane == 0 && amax > 0.f) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, amax));
         __syncthreads();
         const unsigned mx = sMax[0];
         const int ex = (int)(mx >> 23) & 0xff;
@@ -1287,6 +1309,9 @@ void wino8s_kernel(ws_args a)
         }
     }
 
+#ifdef AWSEG_WS_STAMP
+    const unsigned long long w8e1 = __builtin_readcyclecounter();
+#endif
     // ---- output transform.  This wave holds M[0..3][vcol]; Y = A^T M A:
     //   C_0 = M_0j + M_1j + M_2j, C_1 = M_1j - M_2j - M_3j (row factor, in registers), then over the V columns j
     //   Y[a][0] = C_a(0) + C_a(1) + C_a(2),  Y[a][1] = C_a(1) - C_a(2) - C_a(3)  — through LDS.
@@ -1311,6 +1336,9 @@ void wino8s_kernel(ws_args a)
             }
     }
     __syncthreads();
+#ifdef AWSEG_WS_STAMP
+    const unsigned long long w8e2 = __builtin_readcyclecounter();
+#endif
     const int mt = vcol >> 1, ob = vcol & 1;                          // this wave finishes m-tile mt, output column ob
     const float ysc = uscale * pow2f(-sx);
     f32x16 y[2];                                                      // [output row a]
@@ -1330,10 +1358,21 @@ void wino8s_kernel(ws_args a)
             }
     }
 
+#ifdef AWSEG_WS_STAMP
+    const unsigned long long w8e3 = __builtin_readcyclecounter();
+#endif
     if (MODE == 0) {
         // rows = tiles of m-tile mt (tile row 4 mt + (r >> 2), tile column 4 hk + (r & 3)), columns (lanes) = couts; output column 2 tx + ob
         const int n = n0 + nt * 32 + li;
-        const float sh = a.shift[n];
+        float sh;
+        {
+            // the shift arrives through a vector-memory load; hipcc's wait insertion re-arms `s_waitcnt vmcnt(0)` for it in every
+            // basic block of the branchy store loop below — which on gfx9 also waits for the previous STORE.  Passing the value
+            // through one asm move ends the dependence on the load here.
+            const float sh_ld = a.shift[n];
+            asm volatile("v_mov_b32 %0, %1" : "=v"(sh) : "v"(sh_ld));
+        }
+        const bool relu = a.act == AWSEG_ACT_RELU;
         const size_t img = (size_t)a.H * a.W * a.Cout;
         const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img), 0, (int)(img * 4), 0x00020000);
         const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual ? a.residual + (size_t)b * img : a.out), 0, a.residual ? (int)(img * 4) : 0, 0x00020000);
@@ -1346,20 +1385,41 @@ void wino8s_kernel(ws_args a)
             const int xl = a.dil * 8 * hk;
             vsel[c] = (xs0 + xl < a.W) ? (uint32_t)((xl * a.Cout + n) * 4) : kOob;
         }
+        // The stamps put 10-11 k cycles of an 18 k-cycle epilogue into these 32 stores per wave: gfx9's vmcnt counts loads AND stores,
+        // so a residual load in front of every store (through a zero-record descriptor when there is no residual) made each store
+        // wait for the previous one's write acknowledgement.  Two separate code paths: without a residual — every 3x3 of the ResNet
+        // bottlenecks — no load is issued and nothing waits; with one, all 32 loads go out first.
+        auto store_all = [&](auto HR) {
+            constexpr bool HAS_RES = decltype(HR)::value;
+            float rv[16][2];
+            if (HAS_RES) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ty = mt_u * 4 + (r >> 2), c = r & 3;
-            const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + ob_u);
+                for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int aa = 0; aa < 2; ++aa) {
-                const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + aa);
-                if (yy >= a.H) continue;                             // wave-uniform
-                const uint32_t soff = (uint32_t)((yy * a.W + xs0) * a.Cout * 4);
-                float v = y[aa][r] + sh;
-                v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vsel[c], soff, 0));   // zero-record descriptor without a residual
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, act_apply(v, a.act)), o_rsrc, vsel[c], soff, 0);
+                    for (int aa = 0; aa < 2; ++aa) {
+                        const int ty = mt_u * 4 + (r >> 2), c = r & 3;
+                        const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + ob_u);
+                        const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + aa);
+                        const uint32_t soff = (uint32_t)((yy * a.W + xs0) * a.Cout * 4);
+                        rv[r][aa] = yy < a.H ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vsel[c], soff, 0)) : 0.f;
+                    }
             }
-        }
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa) {
+                    const int ty = mt_u * 4 + (r >> 2), c = r & 3;
+                    const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + ob_u);
+                    const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + aa);
+                    if (yy >= a.H) continue;                         // wave-uniform
+                    const uint32_t soff = (uint32_t)((yy * a.W + xs0) * a.Cout * 4);
+                    float v = y[aa][r] + sh;
+                    if (HAS_RES) v += rv[r][aa];
+                    if (relu) asm("v_max_f32 %0, 0, %0" : "+v"(v));
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), o_rsrc, vsel[c], soff, 0);
+                }
+        };
+        if (a.residual) store_all(awseg_true{}); else store_all(awseg_false{});      // block-uniform; dword accesses: no 16-byte store hazard
     } else {
         // rows = couts n0 + 32 nt + (r & 3) + 8 (r >> 2) + 4 hk, columns (lanes) = tiles of m-tile mt (tile = 32 mt + li); output column ob
         float z[2] = {0.f, 0.f};
@@ -1395,6 +1455,9 @@ void wino8s_kernel(ws_args a)
             }
         }
     }
+#ifdef AWSEG_WS_STAMP
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) { const unsigned long long w8b3 = __builtin_readcyclecounter(); g_w8s_block[0] += w8b1 - w8b0; g_w8s_block[1] += w8b2 - w8b1; g_w8s_block[2] += w8b3 - w8b2; g_w8s_block[3] += 1; g_w8s_block[4] += w8e1 - w8b2; g_w8s_block[5] += w8e2 - w8e1; g_w8s_block[6] += w8e3 - w8e2; g_w8s_block[7] += w8b3 - w8e3; }
+#endif
 }
 
 

@@ -1003,7 +1003,7 @@ void wino8_kernel(ws_args a)
 // and 32 of U; hipcc spills whole accumulators of the rows the slot does not touch and the kernel runs 2x slower.  It fits the
 // bf16 variant (236 registers) only.)
 #ifdef AWSEG_WS_STAMP
-__device__ unsigned long long g_w8s_block[8];                         // block 0, wave 0: [prologue, chunk loop, epilogue, blocks] of the block in the middle of the grid
+__device__ unsigned long long g_w8s_block[16];                         // block 0, wave 0: [prologue, chunk loop, epilogue, blocks] of the block in the middle of the grid
 #endif
 template <int MODE, bool BF16>
 __global__ __launch_bounds__(W8T, 2)
@@ -1011,7 +1011,7 @@ void wino8s_kernel(ws_args a)
 {
 #ifdef AWSEG_WS_STAMP
     const unsigned long long w8b0 = __builtin_readcyclecounter();
-    unsigned long long w8b1 = 0, w8b2 = 0;
+    unsigned long long w8b1 = 0, w8b2 = 0, w8p[5] = {0, 0, 0, 0, 0};
 #endif
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sV = smem;
@@ -1022,15 +1022,31 @@ void wino8s_kernel(ws_args a)
     const int grp = wave >> 2;                                       // 0: multiply, then transform; 1: transform, then multiply
     const int nt = wave & 1, vcol = wave >> 1;                       // cout half, V column
     const int xcd = blockIdx.x & 7, jj = blockIdx.x >> 3;
-    const int per = a.span * a.ngroups, sg = jj / per, rr = jj - sg * per;
-    const int ng = rr / a.span, t = (sg * a.span + (rr - ng * a.span)) * 8 + xcd;
-    const int gx = a.nbx * a.dil, gy = a.nby * a.dil;
-    if (t >= gx * gy * a.batch) return;
-    const int b = t / (gx * gy), txy = t - b * (gx * gy), tyy = txy / gx, txx = txy - tyy * gx;
-    const int bx = txx % a.nbx, rx = txx / a.nbx;
-    const int by = tyy % a.nby, ry = tyy / a.nby;
-    const int Hs = (a.H - ry + a.dil - 1) / a.dil, Ws = (a.W - rx + a.dil - 1) / a.dil;
-    if (by * 2 * TB >= Hs || bx * 2 * TB >= Ws) return;
+    int ng, b, bx, by, rx, ry;
+    if (a.dil == 1 && a.span == 1) {
+        // the common case with three integer divisions instead of ten (the stamps put 1 900 cycles of a block's 6 700-cycle prologue
+        // into the index arithmetic in front of the first DMA request)
+        const int sg = jj / a.ngroups;
+        ng = jj - sg * a.ngroups;
+        const int t = sg * 8 + xcd, per_img = a.nbx * a.nby;
+        if (t >= per_img * a.batch) return;
+        b = t / per_img;
+        const int txy = t - b * per_img;
+        by = txy / a.nbx; bx = txy - by * a.nbx; rx = 0; ry = 0;
+        if (by * 2 * TB >= a.H || bx * 2 * TB >= a.W) return;
+    } else {
+        const int per = a.span * a.ngroups, sg = jj / per, rr = jj - sg * per;
+        ng = rr / a.span;
+        const int t = (sg * a.span + (rr - ng * a.span)) * 8 + xcd;
+        const int gx = a.nbx * a.dil, gy = a.nby * a.dil;
+        if (t >= gx * gy * a.batch) return;
+        b = t / (gx * gy);
+        const int txy = t - b * (gx * gy), tyy = txy / gx, txx = txy - tyy * gx;
+        bx = txx % a.nbx; rx = txx / a.nbx;
+        by = tyy % a.nby; ry = tyy / a.nby;
+        const int Hs = (a.H - ry + a.dil - 1) / a.dil, Ws = (a.W - rx + a.dil - 1) / a.dil;
+        if (by * 2 * TB >= Hs || bx * 2 * TB >= Ws) return;
+    }
     const float* xb = a.x + (int64_t)b * a.H * a.W * a.Cin;
     const int n0 = ng * NB;
     const int nchunks = a.Cin / KC;
@@ -1202,21 +1218,37 @@ void wino8s_kernel(ws_args a)
                     }
         };
 
+        // ---- prologue: patches 0 and 1 in flight, U of chunk 0, patch 0 landed; every thread builds its row (0 | 2) of chunk 0
+#ifdef AWSEG_WS_STAMP
+        if (!SCALED) w8p[0] = __builtin_readcyclecounter();
+#endif
+        glds_patch(0, 0);
+        if (nchunks > 1) glds_patch(1, 1);
+        u_fetch2(0, 0);
+        u_fetch2(0, 1);
+#ifdef AWSEG_WS_STAMP
+        if (!SCALED) w8p[1] = __builtin_readcyclecounter();
+#endif
+        asm volatile("" ::: "memory");                               // (the 128 accumulator moves go BEHIND the requests: the round trip hides them)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
-        // ---- prologue: patches 0 and 1 in flight, U of chunk 0, patch 0 landed; every thread builds its row (0 | 2) of chunk 0
-        glds_patch(0, 0);
-        if (nchunks > 1) glds_patch(1, 1);
-        u_fetch2(0, 0);
-        u_fetch2(0, 1);
         if (nchunks > 1) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});   // patch 0: everything but patch 1 and the U fragments behind it
         else vm_wait_keep(awseg_int<BF16 ? 4 : 8>{});
+#ifdef AWSEG_WS_STAMP
+        if (!SCALED) w8p[2] = __builtin_readcyclecounter();
+#endif
         __syncthreads();                                             // (also orders sMax[0] = 0 and the previous pass's V reads)
+#ifdef AWSEG_WS_STAMP
+        if (!SCALED) w8p[3] = __builtin_readcyclecounter();
+#endif
         transform(0, awseg_true{});
+#ifdef AWSEG_WS_STAMP
+        if (!SCALED) w8p[4] = __builtin_readcyclecounter();
+#endif
         __syncthreads();
 #ifdef AWSEG_WS_STAMP
         unsigned long long w8s[5] = {0, 0, 0, 0, 0}, w8f[2] = {0, 0};
@@ -1456,7 +1488,7 @@ void wino8s_kernel(ws_args a)
         }
     }
 #ifdef AWSEG_WS_STAMP
-    if (blockIdx.x == gridDim.x / 2 && tid == 0) { const unsigned long long w8b3 = __builtin_readcyclecounter(); g_w8s_block[0] += w8b1 - w8b0; g_w8s_block[1] += w8b2 - w8b1; g_w8s_block[2] += w8b3 - w8b2; g_w8s_block[3] += 1; g_w8s_block[4] += w8e1 - w8b2; g_w8s_block[5] += w8e2 - w8e1; g_w8s_block[6] += w8e3 - w8e2; g_w8s_block[7] += w8b3 - w8e3; }
+    if (blockIdx.x == gridDim.x / 2 && tid == 0) { const unsigned long long w8b3 = __builtin_readcyclecounter(); g_w8s_block[0] += w8b1 - w8b0; g_w8s_block[1] += w8b2 - w8b1; g_w8s_block[2] += w8b3 - w8b2; g_w8s_block[3] += 1; g_w8s_block[4] += w8e1 - w8b2; g_w8s_block[5] += w8e2 - w8e1; g_w8s_block[6] += w8e3 - w8e2; g_w8s_block[7] += w8b3 - w8e3; g_w8s_block[8] += w8p[0] - w8b0; g_w8s_block[9] += w8p[1] - w8p[0]; g_w8s_block[10] += w8p[2] - w8p[1]; g_w8s_block[11] += w8p[3] - w8p[2]; g_w8s_block[12] += w8p[4] - w8p[3]; g_w8s_block[13] += w8b1 - w8p[4]; }
 #endif
 }
 

@@ -47,11 +47,12 @@ static void run(int B, int H, int W, int cin, int cout, int dil, bool head)
                           (w8[g][0] + w8[g][1] + w8[g][2] + w8[g][3]) / m, m);
         if (m > 0 && w8[g][5]) printf("      symmetric kernel, slot A in detail: %s %.0f | patch DMA issue %.0f\n", g ? "(waves 4-7) DMA issue" : "(waves 0-3) MFMAs + U fetch", w8[g][5] / m, w8[g][6] / m);
     }
-    unsigned long long wb[8];
+    unsigned long long wb[16];
     hipMemcpyFromSymbol(wb, HIP_SYMBOL(g_w8s_block), sizeof wb);
     if (wb[3]) printf("  symmetric kernel, middle block of the grid: prologue %llu | chunk loop %llu | guard + epilogue %llu cycles\n", wb[0] / wb[3], wb[1] / wb[3], wb[2] / wb[3]);
+    if (wb[3]) printf("      prologue: index arithmetic %llu | DMA + U requests %llu | accumulators zeroed + patch 0 landed %llu | barrier %llu | first V row %llu | barrier %llu\n", wb[8] / wb[3], wb[9] / wb[3], wb[10] / wb[3], wb[11] / wb[3], wb[12] / wb[3], wb[13] / wb[3]);
     if (wb[3]) printf("      epilogue: range guard %llu | exchange written + barrier %llu | read back + inverse transform %llu | bias / act / stores (head: 1x1 + sigmoid) %llu\n", wb[4] / wb[3], wb[5] / wb[3], wb[6] / wb[3], wb[7] / wb[3]);
-    unsigned long long zb[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long zb[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     hipMemcpyToSymbol(HIP_SYMBOL(g_w8s_block), zb, sizeof zb);
     unsigned long long z2[2][8]; memset(z2, 0, sizeof z2);
     hipMemcpyToSymbol(HIP_SYMBOL(g_w8_stamp), z2, sizeof z2);

@@ -56,6 +56,7 @@ struct ws_args {
     const float* x; const uint16_t* U; const float* shift; const float* residual; const float* w2; const float* b2;
     float* out;
     int H, W, Cin, Cout, dil, act, nbx, nby, ngroups, batch;
+    int nblocks, tpb;                      // wino8p_kernel: linear block indices in all, tiles per (persistent) block
     int span;                              // wino8_kernel: spatial tiles of one XCD that run the same cout group back to back (block order)
     int64_t u_halfs;                       // halfs of U in front of the trailer {2^eu as float}
 };
@@ -1493,6 +1494,492 @@ void wino8s_kernel(ws_args a)
 }
 
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// wino8s_kernel as a PERSISTENT block: a.tpb tiles per block (linear block indices blockIdx.x, + gridDim.x, ...).  One block fits a
+// CU (the 128 KB exchange buffer of the epilogue), so the prologue of every tile — ~6.5 k cycles whose critical path is the first
+// patch's memory round trip — and its epilogue (~8 k) are dead time for the matrix pipe: 30 % of a 4-chunk block, 25 % of the
+// depth head's 8-chunk blocks (block-level stamps).  Here chunk 0 of every tile lives in a FOURTH patch slot behind
+// the exchange buffer, and a block requests the next tile's first patch in front of its own epilogue's stores: the round trip is
+// covered by the epilogue and the next tile's index arithmetic.  Everything else is wino8s_kernel (same arithmetic, same order).
+constexpr int LDS8P_BYTES = X_BYTES + P_BYTES + 64;
+template <int MODE, bool BF16>
+__global__ __launch_bounds__(W8T, 2)
+void wino8p_kernel(ws_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* sV = smem;
+    unsigned* sMax = reinterpret_cast<unsigned*>(smem + X_BYTES + P_BYTES);      // behind the fourth patch slot (the exchange buffer covers everything below X_BYTES)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int grp = wave >> 2;                                       // 0: multiply, then transform; 1: transform, then multiply
+    const int nt = wave & 1, vcol = wave >> 1;                       // cout half, V column
+    // tile of linear block index bidx (the order of wino8s_kernel); false: nothing to do there
+    auto decode = [&](int bidx, int& ng, int& b, int& bx, int& by, int& rx, int& ry) -> bool {
+        if (bidx >= a.nblocks) return false;
+        const int xcd = bidx & 7, jj = bidx >> 3;
+        if (a.dil == 1 && a.span == 1) {
+            // the common case with three integer divisions instead of ten (the stamps put 1 900 cycles of a block's 6 700-cycle prologue
+            // into the index arithmetic in front of the first DMA request)
+            const int sg = jj / a.ngroups;
+            ng = jj - sg * a.ngroups;
+            const int t = sg * 8 + xcd, per_img = a.nbx * a.nby;
+            if (t >= per_img * a.batch) return false;
+            b = t / per_img;
+            const int txy = t - b * per_img;
+            by = txy / a.nbx; bx = txy - by * a.nbx; rx = 0; ry = 0;
+            if (by * 2 * TB >= a.H || bx * 2 * TB >= a.W) return false;
+        } else {
+            const int per = a.span * a.ngroups, sg = jj / per, rr = jj - sg * per;
+            ng = rr / a.span;
+            const int t = (sg * a.span + (rr - ng * a.span)) * 8 + xcd;
+            const int gx = a.nbx * a.dil, gy = a.nby * a.dil;
+            if (t >= gx * gy * a.batch) return false;
+            b = t / (gx * gy);
+            const int txy = t - b * (gx * gy), tyy = txy / gx, txx = txy - tyy * gx;
+            bx = txx % a.nbx; rx = txx / a.nbx;
+            by = tyy % a.nby; ry = tyy / a.nby;
+            const int Hs = (a.H - ry + a.dil - 1) / a.dil, Ws = (a.W - rx + a.dil - 1) / a.dil;
+            if (by * 2 * TB >= Hs || bx * 2 * TB >= Ws) return false;
+        }
+        return true;
+    };
+    int ng = 0, b = 0, bx = 0, by = 0, rx = 0, ry = 0, n0 = 0;                 // the current tile
+    const int nchunks = a.Cin / KC;
+
+    // ---- patch LDS-DMA: the 21 wave-wide instructions of a patch are dealt over ALL eight waves (instruction wave + 8 k: three for
+    // waves 0-4, two for 5-7) — issuing one costs a wave ~100 cycles, and the six per wave of wino8_kernel made slot A 700 cycles
+    // longer for the issuing group than for its partners.  Layout as in wino8_kernel.
+    __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, 0, 0x00020000);
+    uint32_t pvoff[3] = {0x80000000u, 0x80000000u, 0x80000000u};
+    auto patch_addr = [&](int tb, int tbx, int tby, int trx, int try_, __amdgpu_buffer_rsrc_t& rsrc, uint32_t (&pv)[3]) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + (int64_t)tb * a.H * a.W * a.Cin), 0, (int)((size_t)a.H * a.W * a.Cin * 4), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = (wave + 8 * j) * 64 + lane;
+            const int g = q >> 2, h = q & 3;
+            const int py = g / PW, pos = g - py * PW;
+            const int px = pos < PW / 2 ? 2 * pos : 2 * (pos - PW / 2) + 1;
+            const int sy = tby * 2 * TB - 1 + py, sx = tbx * 2 * TB - 1 + px;
+            const int y = try_ + a.dil * sy, x = trx + a.dil * sx;
+            const bool ok = g < NPIX && sy >= 0 && sx >= 0 && y < a.H && x < a.W;
+            pv[j] = ok ? (uint32_t)(((y * a.W + x) * a.Cin + h * 4) * 4) : 0x80000000u;
+        }
+    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const bool three = wave_u < P_INSTR - 16;                        // this wave issues three (else two) instructions per patch
+    // patch slots 0-2 behind V as in wino8s_kernel; slot 3 — chunk 0 of every tile — behind the exchange buffer, so that the NEXT
+    // tile's first patch can travel while this tile's epilogue uses everything below X_BYTES
+    auto slot_off = [](int slot) { return slot < 3 ? V_BYTES + slot * P_BYTES : X_BYTES; };
+    auto pslot = [](int chunk) { return chunk == 0 ? 3 : chunk % 3; };
+    const uint32_t p_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + (uint32_t)wave_u * 1024u;
+    auto glds_patch_of = [&](const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t (&pv)[3], int chunk, int slot) {
+        const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((chunk < nchunks ? chunk : nchunks - 1) * KC * 4);
+        const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p_lds + (uint32_t)slot_off(slot)));
+        bufdma16(rsrc, pv[0], soff, base);
+        bufdma16(rsrc, pv[1], soff, base + 8192u);
+        if (three) bufdma16(rsrc, pv[2], soff, base + 16384u);
+    };
+    auto glds_patch = [&](int chunk, int slot) { glds_patch_of(x_rsrc, pvoff, chunk, slot); };
+    // s_waitcnt vmcnt(n + 2 | n + 3): everything but this wave's youngest n register loads and ONE patch's DMA instructions
+    auto vm_wait_keep_patch_and = [&](auto NC) {
+        constexpr int N = decltype(NC)::value;
+        if (three) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 2) : "memory");
+    };
+
+    auto vm_wait_keep = [&](auto NC) { constexpr int N = decltype(NC)::value; asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); };
+
+    // ---- transform item: (tile, channel quad) x ONE V row per slot (the thread's half of the block picks the row)
+    const int it = tid & 255;
+    const int xtile = it >> 2, xq = it & 3;
+    const int xty = xtile >> 3, xtx = xtile & 7;
+    const int prd = (2 * xty * PW + xtx) * 64 + xq * 16;
+    const int xsw = (xtile >> 2) & 3;
+    const int vw_hi = xtile * 64 + (((xq >> 1) ^ xsw) * 16) + (xq & 1) * 8;
+    const int vw_lo = xtile * 64 + (((2 + (xq >> 1)) ^ xsw) * 16) + (xq & 1) * 8;
+
+    // ---- MFMA operands
+    int a_hi[2], a_lo[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int tile = m * 32 + li, sw = (tile >> 2) & 3;
+        a_hi[m] = tile * 64 + ((hk ^ sw) * 16);
+        a_lo[m] = tile * 64 + (((2 + hk) ^ sw) * 16);
+    }
+    const int ncb = a.Cout / 32;
+    const __amdgpu_buffer_rsrc_t u_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.U, 0, (int)(a.u_halfs * 2), 0x00020000);
+    const uint32_t ulane = (uint32_t)(hk * 512 + li * 16);
+    const uint32_t u_p = (uint32_t)ncb * 2048u, u_c = 16u * u_p;
+    uint32_t u_w = 0;                                              // per tile: V column and cout block of this wave
+    const float uscale = *reinterpret_cast<const float*>(a.U + a.u_halfs);
+
+    f32x16 acc[4][2];                                                // [V row][m-tile]
+    float amax = 0.f, xs = 1.0f;
+    int sx = 0;
+    bool patch0_requested = false;
+
+    auto run = [&](auto SC) {
+        constexpr bool SCALED = decltype(SC)::value;
+        h8 uh[4], ul[4];                                             // [V row]
+        auto u_fetch2 = [&](int c, int r0) {                         // rows r0 and r0 + 2 of chunk c
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int i = r0 + 2 * e;
+                const uint32_t so = (uint32_t)c * u_c + u_w + (uint32_t)(4 * i) * u_p;
+                uh[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane, so, 0));
+                if (!BF16) ul[i] = __builtin_bit_cast(h8, __builtin_amdgcn_raw_buffer_load_b128(u_rsrc, ulane + 1024u, so, 0));
+            }
+        };
+        // patch `slot` -> ONE V row.  B^T rows:  0: d0 - d2   1: d1 + d2   2: d2 - d1   3: d1 - d3.  PHASE 0 (slot A): threads 0-255 build
+        // row 1, 256-511 row 3 (input rows 1, 2 | 1, 3); PHASE 1 (slot B, next chunk's patch): row 0 | row 2 (input rows 0, 2 | 2, 1).
+        // max|x| is taken once per input row and block: d1 by the row-1 threads, d3 by row 3, d0 and d2 by row 0.
+        auto transform = [&](int slot, auto PH) {
+            constexpr int PHASE = decltype(PH)::value ? 1 : 0;
+            const unsigned char* pp = smem + slot_off(slot) + prd;
+            // scalar float32 arithmetic on purpose: v_pk_add_f32 waits for the matrix pipe (see the header of this kernel)
+            auto load_row = [&](int i, bool track, float (&d)[4][4]) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float4 q = *reinterpret_cast<const float4*>(pp + (i * PW + (j & 1) * (PW / 2) + (j >> 1)) * 64);
+                    d[j][0] = q.x; d[j][1] = q.y; d[j][2] = q.z; d[j][3] = q.w;
+                    if (BF16) {
+                    } else if (!SCALED) {
+                        if (track) {
+                            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(q.x)), __builtin_fabsf(q.y));
+                            amax = __builtin_fmaxf(__builtin_fmaxf(amax, __builtin_fabsf(q.z)), __builtin_fabsf(q.w));
+                        }
+                    } else {
+#pragma unroll
+                        for (int ch = 0; ch < 4; ++ch) d[j][ch] *= xs;
+                    }
+                }
+            };
+            auto cols_store = [&](int vr, const float (&tt)[4][4]) {   // row vr of (B^T d) -> positions 4 vr .. 4 vr + 3, split, stored
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float o[4];
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch)
+                        o[ch] = j == 0 ? tt[0][ch] - tt[2][ch] : j == 1 ? tt[1][ch] + tt[2][ch] : j == 2 ? tt[2][ch] - tt[1][ch] : tt[1][ch] - tt[3][ch];
+                    const v2f va = {o[0], o[1]}, vb = {o[2], o[3]};
+                    u32x2 H, L; unsigned h, l;
+                    if (BF16) {
+                        H[0] = pack_bf16(va); H[1] = pack_bf16(vb);
+                        *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_hi) = H;
+                        continue;
+                    }
+                    split_pair(va, h, l); H[0] = h; L[0] = l;
+                    split_pair(vb, h, l); H[1] = h; L[1] = l;
+                    *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_hi) = H;
+                    *reinterpret_cast<u32x2*>(sV + (vr * 4 + j) * V_POS + vw_lo) = L;
+                }
+            };
+            float p[4][4], q[4][4];
+            auto combine = [&](bool plus) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) p[j][ch] = plus ? p[j][ch] + q[j][ch] : p[j][ch] - q[j][ch];
+            };
+            if (PHASE == 0) {
+                if (grp == 0) { load_row(1, true, p); load_row(2, false, q); combine(true); cols_store(1, p); }     // row 1: d1 + d2
+                else { load_row(1, false, p); load_row(3, true, q); combine(false); cols_store(3, p); }             // row 3: d1 - d3
+            } else {
+                if (grp == 0) { load_row(0, true, p); load_row(2, true, q); combine(false); cols_store(0, p); }     // row 0: d0 - d2
+                else { load_row(2, false, p); load_row(1, false, q); combine(false); cols_store(2, p); }            // row 2: d2 - d1
+            }
+        };
+        // 12 MFMAs on V rows r0 and r0 + 2 of this wave's column: the three product terms, each over the four accumulators
+        auto mma2 = [&](int r0) {
+            h8 vh[2][2], vl[2][2];
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const unsigned char* vp = sV + (4 * (r0 + 2 * e)) * V_POS + vcol * V_POS;
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    vh[e][m] = *reinterpret_cast<const h8*>(vp + a_hi[m]);
+                    if (!BF16) vl[e][m] = *reinterpret_cast<const h8*>(vp + a_lo[m]);
+                }
+            }
+#pragma unroll
+            for (int term = 0; term < (BF16 ? 1 : 3); ++term)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const int i = r0 + 2 * e;
+                        f32x16 z = acc[i][m];
+                        if (BF16) {
+                            if (MODE == 1) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, uh[i]), __builtin_bit_cast(bf8, vh[e][m]), z, 0, 0, 0);
+                            else z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, vh[e][m]), __builtin_bit_cast(bf8, uh[i]), z, 0, 0, 0);
+                        } else {
+                            const h8 va = term == 2 ? vl[e][m] : vh[e][m];
+                            const h8 ua = term == 1 ? ul[i] : uh[i];
+                            if (MODE == 1) z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua, va, z, 0, 0, 0);
+                            else z = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, ua, z, 0, 0, 0);
+                        }
+                        acc[i][m] = z;
+                    }
+        };
+
+        // ---- prologue: patches 0 and 1 in flight, U of chunk 0, patch 0 landed; every thread builds its row (0 | 2) of chunk 0
+        if (!patch0_requested) glds_patch(0, 3);                     // (a persistent block requests it before the previous tile's epilogue)
+        patch0_requested = false;
+        if (nchunks > 1) glds_patch(1, 1);
+        u_fetch2(0, 0);
+        u_fetch2(0, 1);
+        asm volatile("" ::: "memory");                               // (the 128 accumulator moves go BEHIND the requests: the round trip hides them)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
+        if (nchunks > 1) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});   // patch 0: everything but patch 1 and the U fragments behind it
+        else vm_wait_keep(awseg_int<BF16 ? 4 : 8>{});
+        __syncthreads();                                             // (also orders sMax[0] = 0 and the previous pass's V reads)
+        transform(pslot(0), awseg_true{});
+        __syncthreads();
+#define W8_T(v)
+#define W8_ACC(t0, t1, t2, t3, t4)
+#define W8_FINE(t0, t1, t2)
+        for (int c = 0; c < nchunks; ++c) {
+            const bool more = c + 1 < nchunks;
+            W8_T(q0);
+            // slot A: MFMAs on rows {0, 2} of chunk c | patch c -> rows {1, 3} of chunk c | DMA of patch c + 2 (its ring slot held patch
+            // c - 1, last read in slot A of chunk c - 1).  At the end patch c + 1 (DMA issued a chunk ago) has landed: behind it this
+            // wave issued, in program order, the U loads counted below and one patch's DMA instructions.
+            // (no DMA past the last chunk: the two clamped re-fetches per block were 43 KB of wasted reads and a memory round trip
+            // in front of the epilogue; the wait then counts the U loads only)
+            const bool dma = c + 2 < nchunks;
+            if (grp == 0) {
+                mma2(0);
+                if (more) u_fetch2(c + 1, 0);
+                W8_T(qa);
+                if (dma) glds_patch(c + 2, (c + 2) % 3);
+                W8_T(qb);
+                transform(pslot(c), awseg_false{});
+                W8_FINE(q0, qa, qb)
+                if (more) { if (dma) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{}); else vm_wait_keep(awseg_int<BF16 ? 4 : 8>{}); }   // U rows {1, 3} of chunk c (slot B), rows {0, 2} of chunk c + 1
+            } else {
+                W8_T(qa);
+                if (dma) glds_patch(c + 2, (c + 2) % 3);
+                W8_T(qb);
+                transform(pslot(c), awseg_false{});
+                W8_T(qc);
+                W8_FINE(qa, qb, qc)
+                mma2(0);
+                if (more) {
+                    u_fetch2(c + 1, 0);
+                    if (dma) vm_wait_keep_patch_and(awseg_int<BF16 ? 6 : 12>{}); else vm_wait_keep(awseg_int<BF16 ? 6 : 12>{});            // U rows {0, 2} and {1, 3} of chunk c, rows {0, 2} of chunk c + 1
+                }
+            }
+            W8_T(q1);
+            __syncthreads();
+            W8_T(q2);
+            // slot B: MFMAs on rows {1, 3} of chunk c | patch c + 1 -> rows {0, 2} of chunk c + 1
+            if (grp == 0) {
+                mma2(1);
+                if (more) { u_fetch2(c + 1, 1); transform(pslot(c + 1), awseg_true{}); }
+            } else {
+                if (more) transform(pslot(c + 1), awseg_true{});
+                mma2(1);
+                if (more) u_fetch2(c + 1, 1);
+            }
+            W8_T(q3);
+            __syncthreads();
+            W8_T(q4);
+            W8_ACC(q0, q1, q2, q3, q4)
+        }
+        vm_wait_all();
+#undef W8_T
+#undef W8_ACC
+#undef W8_FINE
+    };
+
+    // ---- the tiles of this block: linear block indices blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8: same XCD)
+    int bidx = blockIdx.x;
+    bool have = decode(bidx, ng, b, bx, by, rx, ry);
+    if (have) patch_addr(b, bx, by, rx, ry, x_rsrc, pvoff);
+    for (int iter = 0; iter < a.tpb; ++iter) {
+        // the next tile, decoded now so that its first patch can be requested in front of this tile's epilogue
+        int n_ng = 0, n_b = 0, n_bx = 0, n_by = 0, n_rx = 0, n_ry = 0;
+        const int nbidx = bidx + (int)gridDim.x;
+        const bool nhave = iter + 1 < a.tpb && decode(nbidx, n_ng, n_b, n_bx, n_by, n_rx, n_ry);
+        __amdgpu_buffer_rsrc_t n_rsrc = x_rsrc;
+        uint32_t n_pv[3] = {0x80000000u, 0x80000000u, 0x80000000u};
+        if (nhave) patch_addr(n_b, n_bx, n_by, n_rx, n_ry, n_rsrc, n_pv);
+        if (have) {
+        n0 = ng * NB;
+        u_w = (uint32_t)(__builtin_amdgcn_readfirstlane(vcol) * (int)u_p + __builtin_amdgcn_readfirstlane((n0 >> 5) + nt) * 2048);
+        amax = 0.f; xs = 1.0f; sx = 0;
+        if (tid == 0) sMax[0] = 0u;                                  // (ordered by the prologue's first barrier)
+        run(awseg_false{});
+        if (!BF16) {
+            // (the stamps put 5 k cycles here: 512 lanes' LDS atomics on ONE word serialise — reduce over the wave first, one atomic per wave)
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) amax = __builtin_fmaxf(amax, __shfl_xor(amax, o, 64));
+            if (lane == 0 && amax > 0.f) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, amax));
+            __syncthreads();
+            const unsigned mx = sMax[0];
+            const int ex = (int)(mx >> 23) & 0xff;
+            const float mf = __builtin_bit_cast(float, mx);
+            if (!(mx == 0u || ex == 0xff || (mf < 8192.0f && mf >= 0.0625f))) {
+                sx = 11 - (ex - 127);
+                sx = sx > 126 ? 126 : sx;
+                xs = pow2f(sx);
+                run(awseg_true{});
+            }
+        }
+
+        // ---- output transform.  This wave holds M[0..3][vcol]; Y = A^T M A:
+        //   C_0 = M_0j + M_1j + M_2j, C_1 = M_1j - M_2j - M_3j (row factor, in registers), then over the V columns j
+        //   Y[a][0] = C_a(0) + C_a(1) + C_a(2),  Y[a][1] = C_a(1) - C_a(2) - C_a(3)  — through LDS.
+        // exchange layout: float4 [nt][V column][m][a][r >> 2][lane]
+        float* xch = reinterpret_cast<float*>(smem);
+        {
+            float* dst = xch + ((size_t)(nt * 4 + vcol) * 16 * 64 + lane) * 4;
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    float4 q0, q1;
+                    float* p0 = &q0.x; float* p1 = &q1.x;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int r = 4 * r4 + q;
+                        p0[q] = acc[0][m][r] + acc[1][m][r] + acc[2][m][r];
+                        p1[q] = acc[1][m][r] - acc[2][m][r] - acc[3][m][r];
+                    }
+                    *reinterpret_cast<float4*>(dst + ((m * 2 + 0) * 4 + r4) * 64 * 4) = q0;
+                    *reinterpret_cast<float4*>(dst + ((m * 2 + 1) * 4 + r4) * 64 * 4) = q1;
+                }
+        }
+        __syncthreads();
+        const int mt = vcol >> 1, ob = vcol & 1;                          // this wave finishes m-tile mt, output column ob
+        const float ysc = uscale * pow2f(-sx);
+        f32x16 y[2];                                                      // [output row a]
+        {
+#pragma unroll
+            for (int arow = 0; arow < 2; ++arow)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    float4 s0, s1, s2;
+                    auto ld = [&](int j) {
+                        return *reinterpret_cast<const float4*>(xch + (((size_t)(nt * 4 + j) * 16 + (mt * 2 + arow) * 4 + r4) * 64 + lane) * 4);
+                    };
+                    s0 = ld(ob); s1 = ld(ob + 1); s2 = ld(ob + 2);       // ob = 0: columns 0, 1, 2 (+ + +); ob = 1: columns 1, 2, 3 (+ - -)
+                    const float* f0 = &s0.x; const float* f1 = &s1.x; const float* f2 = &s2.x;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) y[arow][4 * r4 + q] = (ob == 0 ? f0[q] + f1[q] + f2[q] : f0[q] - f1[q] - f2[q]) * ysc;
+                }
+        }
+
+        if (MODE == 0) {
+            // rows = tiles of m-tile mt (tile row 4 mt + (r >> 2), tile column 4 hk + (r & 3)), columns (lanes) = couts; output column 2 tx + ob
+            const int n = n0 + nt * 32 + li;
+            float sh;
+            {
+                // the shift arrives through a vector-memory load; hipcc's wait insertion re-arms `s_waitcnt vmcnt(0)` for it in every
+                // basic block of the branchy store loop below — which on gfx9 also waits for the previous STORE.  Passing the value
+                // through one asm move ends the dependence on the load here.
+                const float sh_ld = a.shift[n];
+                asm volatile("v_mov_b32 %0, %1" : "=v"(sh) : "v"(sh_ld));
+            }
+            if (nhave) { glds_patch_of(n_rsrc, n_pv, 0, 3); patch0_requested = true; }   // behind the last load this epilogue waits for: nothing below waits on vmcnt
+        const bool relu = a.act == AWSEG_ACT_RELU;
+            const size_t img = (size_t)a.H * a.W * a.Cout;
+            const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + (size_t)b * img), 0, (int)(img * 4), 0x00020000);
+            const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.residual ? a.residual + (size_t)b * img : a.out), 0, a.residual ? (int)(img * 4) : 0, 0x00020000);
+            const int mt_u = __builtin_amdgcn_readfirstlane(mt), ob_u = __builtin_amdgcn_readfirstlane(ob);
+            const uint32_t kOob = 0x80000000u;
+            uint32_t vsel[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + ob_u);
+                const int xl = a.dil * 8 * hk;
+                vsel[c] = (xs0 + xl < a.W) ? (uint32_t)((xl * a.Cout + n) * 4) : kOob;
+            }
+            // The stamps put 10-11 k cycles of an 18 k-cycle epilogue into these 32 stores per wave: gfx9's vmcnt counts loads AND stores,
+            // so a residual load in front of every store (through a zero-record descriptor when there is no residual) made each store
+            // wait for the previous one's write acknowledgement.  Two separate code paths: without a residual — every 3x3 of the ResNet
+            // bottlenecks — no load is issued and nothing waits; with one, all 32 loads go out first.
+            auto store_all = [&](auto HR) {
+                constexpr bool HAS_RES = decltype(HR)::value;
+                float rv[16][2];
+                if (HAS_RES) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+#pragma unroll
+                        for (int aa = 0; aa < 2; ++aa) {
+                            const int ty = mt_u * 4 + (r >> 2), c = r & 3;
+                            const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + ob_u);
+                            const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + aa);
+                            const uint32_t soff = (uint32_t)((yy * a.W + xs0) * a.Cout * 4);
+                            rv[r][aa] = yy < a.H ? __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vsel[c], soff, 0)) : 0.f;
+                        }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+#pragma unroll
+                    for (int aa = 0; aa < 2; ++aa) {
+                        const int ty = mt_u * 4 + (r >> 2), c = r & 3;
+                        const int xs0 = rx + a.dil * (bx * 2 * TB + 2 * c + ob_u);
+                        const int yy = ry + a.dil * (by * 2 * TB + 2 * ty + aa);
+                        if (yy >= a.H) continue;                         // wave-uniform
+                        const uint32_t soff = (uint32_t)((yy * a.W + xs0) * a.Cout * 4);
+                        float v = y[aa][r] + sh;
+                        if (HAS_RES) v += rv[r][aa];
+                        if (relu) asm("v_max_f32 %0, 0, %0" : "+v"(v));
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), o_rsrc, vsel[c], soff, 0);
+                    }
+            };
+            if (a.residual) store_all(awseg_true{}); else store_all(awseg_false{});      // block-uniform; dword accesses: no 16-byte store hazard
+        } else {
+            // rows = couts n0 + 32 nt + (r & 3) + 8 (r >> 2) + 4 hk, columns (lanes) = tiles of m-tile mt (tile = 32 mt + li); output column ob
+            float z[2] = {0.f, 0.f};
+            float shv[16], wv[16];
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int co = n0 + nt * 32 + 8 * g4 + 4 * hk;
+                const float4 s4 = *reinterpret_cast<const float4*>(a.shift + co), w4 = *reinterpret_cast<const float4*>(a.w2 + co);
+                shv[4 * g4] = s4.x; shv[4 * g4 + 1] = s4.y; shv[4 * g4 + 2] = s4.z; shv[4 * g4 + 3] = s4.w;
+                wv[4 * g4] = w4.x; wv[4 * g4 + 1] = w4.y; wv[4 * g4 + 2] = w4.z; wv[4 * g4 + 3] = w4.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                for (int o = 0; o < 2; ++o) z[o] += fmaxf(y[o][r] + shv[r], 0.f) * wv[r];
+            }
+        if (nhave) { glds_patch_of(n_rsrc, n_pv, 0, 3); patch0_requested = true; }   // (shift and w2 have arrived: nothing below waits on vmcnt)
+#pragma unroll
+            for (int o = 0; o < 2; ++o) z[o] += __shfl_xor(z[o], 32, 64);
+            __syncthreads();                                             // every wave has read its exchange data
+            float* red = reinterpret_cast<float*>(smem);                 // [nt][tile][output row][output column]
+            if (hk == 0) {
+                red[((nt * NTILE + mt * 32 + li) * 2 + 0) * 2 + ob] = z[0];
+                red[((nt * NTILE + mt * 32 + li) * 2 + 1) * 2 + ob] = z[1];
+            }
+            __syncthreads();
+            if (tid < 256) {
+                const int tile = tid >> 2, q = tid & 3;                  // q = 2 * output row + output column
+                const int uy = by * 2 * TB + 2 * (tile >> 3) + (q >> 1), ux = bx * 2 * TB + 2 * (tile & 7) + (q & 1);
+                const int yy = ry + a.dil * uy, xx = rx + a.dil * ux;
+                if (yy < a.H && xx < a.W) {
+                    const float zz = red[tile * 4 + q] + red[(NTILE + tile) * 4 + q] + a.b2[0];
+                    a.out[((int64_t)b * a.H + yy) * a.W + xx] = 1.0f / (1.0f + expf(-zz));
+                }
+            }
+        }
+
+        }   // have
+        __syncthreads();                                             // every wave is done with the exchange buffer / the reduction scratch
+        bidx = nbidx; have = nhave;
+        ng = n_ng; b = n_b; bx = n_bx; by = n_by; rx = n_rx; ry = n_ry;
+        x_rsrc = n_rsrc; pvoff[0] = n_pv[0]; pvoff[1] = n_pv[1]; pvoff[2] = n_pv[2];
+    }
+}
+
+
 // (Measured and dropped in round 3: the same block on SIXTEEN waves of 128 registers — wave = 2 positions x 64 tiles x 32 couts, every
 // slot all 1 024 threads share the transform (item = tile x channel pair x one V row), eight waves multiply.  Correct on the first
 // run and 5-10 % slower than this kernel on every shape: 4, 8 and 16 waves all land at ~5 000 cycles per chunk, with MFMA 32 %,
@@ -1501,8 +1988,8 @@ void wino8s_kernel(ws_args a)
 template <int MODE, bool BF16>
 int launch_ws(const ws_args& a, hipStream_t s)
 {
-    static int w8 = -1;                                              // AWSEG_WINO8=0: the four-wave kernel of round 2, 1: eight waves with alternating roles, 2: symmetric slots (A/B measurements)
-    if (w8 < 0) { const char* e = getenv("AWSEG_WINO8"); w8 = e ? atoi(e) : 2; }
+    static int w8 = -1;                                              // AWSEG_WINO8=0: the four-wave kernel of round 2, 1: eight waves with alternating roles, 2: symmetric slots, 3: symmetric slots in persistent blocks (A/B measurements)
+    if (w8 < 0) { const char* e = getenv("AWSEG_WINO8"); w8 = e ? atoi(e) : 3; }
     const int64_t tiles = (int64_t)a.nbx * a.dil * a.nby * a.dil * a.batch;
     const int64_t nblocks = ((tiles + 7) / 8) * a.ngroups * 8;
     if (nblocks >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
@@ -1515,7 +2002,24 @@ int launch_ws(const ws_args& a, hipStream_t s)
         if (span > tiles_x) span = (int)tiles_x;
         while (tiles_x % span) --span;                                   // whole spans only (the grid stays a rectangle)
         a8.span = span;
-        auto k8 = w8 == 2 ? wino8s_kernel<MODE, BF16> : wino8_kernel<MODE, BF16>;
+        static int tpb_env = -1;
+        if (tpb_env < 0) { const char* e = getenv("AWSEG_WINO8_TPB"); tpb_env = e ? atoi(e) : 0; }
+        // two persistent blocks per CU in sequence where the map has that many tiles (measured flat from 2 to 4 per CU, and
+        // 1.7x slower once the grid no longer covers the 256 CUs); at most 64 tiles a block.  A map of <= 512 blocks gains
+        // nothing from persistence and runs the plain kernel.
+        int tpb = tpb_env > 0 ? tpb_env : (int)((nblocks + 511) / 512);
+        tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
+        if (w8 == 3 && tpb > 1) {
+            a8.nblocks = (int)nblocks; a8.tpb = tpb;
+            const int64_t grid = ((nblocks + tpb - 1) / tpb + 7) / 8 * 8;
+            auto kp = wino8p_kernel<MODE, BF16>;
+            hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8P_BYTES);
+            if (ep != hipSuccess) return (int)ep;
+            hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(W8T), LDS8P_BYTES, s, a8);
+            AWSEG_LAUNCH_CHECK();
+            return 0;
+        }
+        auto k8 = w8 >= 2 ? wino8s_kernel<MODE, BF16> : wino8_kernel<MODE, BF16>;
         constexpr int LDS8 = (LDS_BYTES > X_BYTES ? LDS_BYTES : X_BYTES);
         hipError_t e8 = hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
         if (e8 != hipSuccess) return (int)e8;
@@ -1560,7 +2064,7 @@ int ws_entry(bool bf16, const float* x, int batch, int height, int width, int ci
     const int hs = (height + dilation - 1) / dilation, ws = (width + dilation - 1) / dilation;
     a.nbx = (ws + 2 * TB - 1) / (2 * TB); a.nby = (hs + 2 * TB - 1) / (2 * TB); a.ngroups = cout / NB; a.batch = batch;
     a.u_halfs = (int64_t)16 * cin * cout * 2;
-    a.span = 1;
+    a.span = 1; a.nblocks = 0; a.tpb = 1;
     if (bf16) return w2 ? launch_ws<1, true>(a, awseg_s(stream)) : launch_ws<0, true>(a, awseg_s(stream));
     return w2 ? launch_ws<1, false>(a, awseg_s(stream)) : launch_ws<0, false>(a, awseg_s(stream));
 }

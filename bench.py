@@ -178,8 +178,8 @@ def algorithmic_work(name, B, H, W, C, info):
 
 # device-function names of the C-ABI launchers' dominant kernels (for the PMC traffic lookup)
 DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
-                 "awseg_conv3x3_winograd_split_nhwc": ("wino8s_kernel<0, false>", "wino8s_kernel<1, false>", "wino8_kernel<0, false>", "wino8_kernel<1, false>", "wino_split_kernel<0, false>", "wino_split_kernel<1, false>"),
-                 "awseg_conv3x3_winograd_bf16_nhwc": ("wino8s_kernel<0, true>", "wino8s_kernel<1, true>", "wino8_kernel<0, true>", "wino8_kernel<1, true>", "wino_split_kernel<0, true>", "wino_split_kernel<1, true>"),
+                 "awseg_conv3x3_winograd_split_nhwc": ("wino8p_kernel<0, false>", "wino8p_kernel<1, false>", "wino8s_kernel<0, false>", "wino8s_kernel<1, false>", "wino8_kernel<0, false>", "wino8_kernel<1, false>", "wino_split_kernel<0, false>", "wino_split_kernel<1, false>"),
+                 "awseg_conv3x3_winograd_bf16_nhwc": ("wino8p_kernel<0, true>", "wino8p_kernel<1, true>", "wino8s_kernel<0, true>", "wino8s_kernel<1, true>", "wino8_kernel<0, true>", "wino8_kernel<1, true>", "wino_split_kernel<0, true>", "wino_split_kernel<1, true>"),
                  "awseg_gemm_split_bias_act": ("gemm_split3_kernel<false, 0, false", "gemm_split3_kernel<true, 0, false", "gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false", "gemm_split_kernel<2, 2, 4, 2, false, false, true", "gemm_split_kernel<2, 2, 4, 2, true, false, true"),
                  "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
                  "awseg_attention_d32_split": "attention_d32_split_kernel",

@@ -411,8 +411,10 @@ __global__ void ece_fold_kernel(const ece_cell* __restrict__ partial, int blocks
 // rules (torch's argmax update, ignore_index, the reference's uint8 index wrap, out-of-range count) into per-block partials that
 // fold_partials_kernel folds — the separate awseg_combine_argmax_confusion pass over the two logit maps (2.55 GB per batch of 8
 // at 1024 x 2048) is not needed when neither the ensemble logits nor the prediction map are asked for.
-template <int MODE, int LDT, bool CONF>
-__global__ __launch_bounds__(kThreads)
+// TH threads x PX pixels per lane: the block's 64 KB score histogram allows two blocks per CU, so 256 threads are two waves per SIMD
+// whatever the register count; 512 threads with 2 pixels per lane (2 x 19 x 2 logits: < 128 registers) are four.
+template <int MODE, int LDT, bool CONF, int TH, int PX>
+__global__ __launch_bounds__(TH, TH / 128)   // waves per SIMD of two resident blocks
 void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restrict__ seg2, int64_t hw,
                            const float* __restrict__ weights, const float* __restrict__ temperature,
                            const void* __restrict__ label, const float* __restrict__ edges, int n_bins,
@@ -422,7 +424,7 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
 {
     constexpr int C = 19;
     __shared__ uint32_t s_conf[CONF ? C * C : 1];
-    if (CONF) { for (int i = threadIdx.x; i < C * C; i += kThreads) s_conf[i] = 0u; }
+    if (CONF) { for (int i = threadIdx.x; i < C * C; i += TH) s_conf[i] = 0u; }
     __shared__ uint32_t s_cnt[64], s_cor[64];
     __shared__ unsigned long long s_sum[64];
     __shared__ float s_edges[65];
@@ -430,9 +432,9 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
     // have similar scores, so counting straight into global memory is same-address atomic traffic
     // (measured 45 ms per batch); the block flushes only its non-zero bins at the end.
     extern __shared__ uint32_t s_hist[];
-    for (int i = threadIdx.x; i < 2 * n_hist; i += kThreads) s_hist[i] = 0u;
-    for (int i = threadIdx.x; i < n_bins; i += kThreads) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0ull; }
-    for (int i = threadIdx.x; i <= n_bins; i += kThreads) s_edges[i] = edges[i];
+    for (int i = threadIdx.x; i < 2 * n_hist; i += TH) s_hist[i] = 0u;
+    for (int i = threadIdx.x; i < n_bins; i += TH) { s_cnt[i] = 0; s_cor[i] = 0; s_sum[i] = 0ull; }
+    for (int i = threadIdx.x; i <= n_bins; i += TH) s_edges[i] = edges[i];
     __syncthreads();
     const int64_t img = blockIdx.y;
     const float* a = seg1 + img * C * hw;
@@ -441,19 +443,20 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
     const bool has_t = (temperature != nullptr);
     if (MODE == 0) { w0 = weights[0]; w1 = weights[1]; }
     if (has_t) T = temperature[0];
-    const int64_t nvec = hw / 4;
-    for (int64_t v = (int64_t)blockIdx.x * kThreads + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * kThreads) {
-        const int64_t p = v * 4;
-        float x[C][4], y[C][4];
+    const int64_t nvec = hw / PX;
+    typedef float lvec __attribute__((ext_vector_type(PX)));
+    for (int64_t v = (int64_t)blockIdx.x * TH + threadIdx.x; v < nvec; v += (int64_t)gridDim.x * TH) {
+        const int64_t p = v * PX;
+        float x[C][PX], y[C][PX];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            const float4 xv = *reinterpret_cast<const float4*>(a + (int64_t)c * hw + p);
-            const float4 yv = *reinterpret_cast<const float4*>(d + (int64_t)c * hw + p);
-            x[c][0] = xv.x; x[c][1] = xv.y; x[c][2] = xv.z; x[c][3] = xv.w;
-            y[c][0] = yv.x; y[c][1] = yv.y; y[c][2] = yv.z; y[c][3] = yv.w;
+            const lvec xv = *reinterpret_cast<const lvec*>(a + (int64_t)c * hw + p);
+            const lvec yv = *reinterpret_cast<const lvec*>(d + (int64_t)c * hw + p);
+#pragma unroll
+            for (int k = 0; k < PX; ++k) { x[c][k] = xv[k]; y[c][k] = yv[k]; }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < PX; ++k) {
             const int64_t t = awseg_ld_label<LDT>(label, img * hw + p + k);
             if (!CONF && t == 255) continue;                      // metrics.py:170, :426
             // ensemble logits r, their max / argmax / sum-exp for the calibration part
@@ -516,14 +519,14 @@ void ensemble_stats_kernel(const float* __restrict__ seg1, const float* __restri
     }
     __syncthreads();
     ece_cell* dst = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * n_bins;
-    for (int i = threadIdx.x; i < n_bins; i += kThreads) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = s_sum[i]; }
-    for (int i = threadIdx.x; i < 2 * n_hist; i += kThreads) {
+    for (int i = threadIdx.x; i < n_bins; i += TH) { dst[i].cnt = s_cnt[i]; dst[i].correct = s_cor[i]; dst[i].sum_conf = s_sum[i]; }
+    for (int i = threadIdx.x; i < 2 * n_hist; i += TH) {
         const uint32_t v = s_hist[i];
         if (v) atomicAdd(&hist[i], (unsigned long long)v);
     }
     if (CONF) {
         uint32_t* cd = conf_partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (C * C);
-        for (int i = threadIdx.x; i < C * C; i += kThreads) cd[i] = s_conf[i];
+        for (int i = threadIdx.x; i < C * C; i += TH) cd[i] = s_conf[i];
     }
 }
 
@@ -723,21 +726,25 @@ static int stats_impl(const float* seg1, const float* seg2, int64_t batch, int n
     int bpi = blocks_per_image(hw, batch, 1);
     const int cap = (int)((AWSEG_CUS * 2 + batch - 1) / batch);   // 64 KB of LDS per block: two blocks per CU
     if (bpi > cap) bpi = cap < 1 ? 1 : cap;
-    dim3 grid(bpi, (unsigned)batch), block(kThreads);
+    dim3 grid(bpi, (unsigned)batch);
+    static int wide = -1;                                           // AWSEG_STATS_WIDE=0: 256 threads x 4 pixels per lane (A/B measurements)
+    if (wide < 0) { const char* e = getenv("AWSEG_STATS_WIDE"); wide = e ? atoi(e) : 1; }
     const float scale = (float)n_hist / (hist_hi - hist_lo);
     const size_t lds = (size_t)2 * n_hist * sizeof(uint32_t);
     unsigned long long* hist = (unsigned long long*)auroc_hist;
     // workspace: [batch][bpi][n_bins] ECE cells, then (conf) [batch][bpi][19 x 19] uint32 histogram partials
     uint32_t* conf_partial = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(workspace) + (size_t)batch * bpi * 64 * sizeof(ece_cell));
-#define AWSEG_ES(M, L, CF) { \
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ensemble_stats_kernel<M, L, CF>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AWSEG_EINVAL; \
-        hipLaunchKernelGGL((ensemble_stats_kernel<M, L, CF>), grid, block, lds, s, seg1, seg2, hw, weights, temperature, label, \
+#define AWSEG_ES_K(M, L, CF, TH, PX) { \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(ensemble_stats_kernel<M, L, CF, TH, PX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return AWSEG_EINVAL; \
+        hipLaunchKernelGGL((ensemble_stats_kernel<M, L, CF, TH, PX>), grid, dim3(TH), lds, s, seg1, seg2, hw, weights, temperature, label, \
                            edges, n_bins, (ece_cell*)workspace, hist, n_hist, hist_lo, scale, ignore_index, wrap, conf_partial, oob); }
+#define AWSEG_ES(M, L, CF) { if (wide == 1) AWSEG_ES_K(M, L, CF, 512, 2) else if (wide == 2) AWSEG_ES_K(M, L, CF, 384, 2) else AWSEG_ES_K(M, L, CF, kThreads, 4) }
 #define AWSEG_ES2(M, L) { if (conf) AWSEG_ES(M, L, true) else AWSEG_ES(M, L, false) }
     if (mode == AWSEG_COMBINE_WEIGHTED) { if (label_dtype == AWSEG_U8) AWSEG_ES2(0, AWSEG_U8) else if (label_dtype == AWSEG_I64) AWSEG_ES2(0, AWSEG_I64) else return AWSEG_EINVAL; }
     else { if (label_dtype == AWSEG_U8) AWSEG_ES2(2, AWSEG_U8) else if (label_dtype == AWSEG_I64) AWSEG_ES2(2, AWSEG_I64) else return AWSEG_EINVAL; }
 #undef AWSEG_ES2
 #undef AWSEG_ES
+#undef AWSEG_ES_K
     AWSEG_LAUNCH_CHECK();
     hipLaunchKernelGGL(ece_fold_kernel, dim3((unsigned)batch), dim3(64), 0, s, (const ece_cell*)workspace, bpi, n_bins, cond,
                        n_slots, (ece_out*)ece_bins);

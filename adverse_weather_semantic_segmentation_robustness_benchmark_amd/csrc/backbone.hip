@@ -309,6 +309,8 @@ void dwconv3x3_upcat_strip_kernel(const float* __restrict__ a, int h, int w, int
 // two 16-byte LDS reads per tap row at a computed address (lane stride 16 B: conflict-free) and one horizontal blend.
 // (The strip kernel above reloads its 12 corner values behind a data-dependent branch inside the serial column loop —
 // nothing can be prefetched across it: 18 % of the HBM roof.)  Same expressions, same order: bit-identical results.
+// (Measured and dropped in round 3: the staging loop in batches of five cells per thread, all ten loads in flight before the
+// first blend — 118 registers, 0.646 -> 0.689 ms: the staging round trips are not what bounds a block.)
 constexpr int kUpTile = 32, kUpQuads = 64;
 template <int SX>
 __global__ __launch_bounds__(kThreads)
@@ -334,35 +336,17 @@ void dwconv3x3_upcat_lds_kernel(const float* __restrict__ a, int h, int w, int C
     }
     const int jbase = (int)(rx * (float)(x0 > 0 ? x0 - 1 : 0));
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-    // staging in batches of kUpBatch cells per thread: all 2 kUpBatch loads of a batch are in flight before the first blend (one
-    // memory round trip per batch; the plain loop made one per cell — nine in a row at x4 — and a block writes only 32 KB)
-    constexpr int kUpBatch = 5;
-    const int n_cell = n_src * 3 * kUpQuads;
-    for (int i0 = threadIdx.x; i0 < n_cell; i0 += kUpBatch * kThreads) {
-        float4 v0[kUpBatch], v1[kUpBatch];
-#pragma unroll
-        for (int u = 0; u < kUpBatch; ++u) {
-            const int i = i0 + u * kThreads;
-            if (i < n_cell) {
-                const int iq = i % kUpQuads, t = i / kUpQuads;
-                const int ky = t % 3;
-                int j = jbase + t / 3;
-                if (j > w - 1) j = w - 1;
-                const float* p = a + (int64_t)b * h * w * Ca + (g * kUpQuads + iq) * 4;
-                const int ra = ky == 0 ? r0[0] : (ky == 1 ? r0[1] : r0[2]), rb = ky == 0 ? r1[0] : (ky == 1 ? r1[1] : r1[2]);
-                v0[u] = *reinterpret_cast<const float4*>(p + ((int64_t)ra * w + j) * Ca);
-                v1[u] = *reinterpret_cast<const float4*>(p + ((int64_t)rb * w + j) * Ca);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kUpBatch; ++u) {
-            const int i = i0 + u * kThreads;
-            if (i < n_cell) {
-                const int ky = (i / kUpQuads) % 3;
-                const float la = ky == 0 ? l0[0] : (ky == 1 ? l0[1] : l0[2]), lb = ky == 0 ? l1[0] : (ky == 1 ? l1[1] : l1[2]);
-                s_cell[i] = make_float4(la * v0[u].x + lb * v1[u].x, la * v0[u].y + lb * v1[u].y, la * v0[u].z + lb * v1[u].z, la * v0[u].w + lb * v1[u].w);
-            }
-        }
+    for (int i = threadIdx.x; i < n_src * 3 * kUpQuads; i += kThreads) {
+        const int iq = i % kUpQuads, t = i / kUpQuads;
+        const int ky = t % 3;
+        int j = jbase + t / 3;
+        if (j > w - 1) j = w - 1;
+        const float* p = a + (int64_t)b * h * w * Ca + (g * kUpQuads + iq) * 4;
+        const int ra = ky == 0 ? r0[0] : (ky == 1 ? r0[1] : r0[2]), rb = ky == 0 ? r1[0] : (ky == 1 ? r1[1] : r1[2]);
+        const float la = ky == 0 ? l0[0] : (ky == 1 ? l0[1] : l0[2]), lb = ky == 0 ? l1[0] : (ky == 1 ? l1[1] : l1[2]);
+        const float4 v0 = *reinterpret_cast<const float4*>(p + ((int64_t)ra * w + j) * Ca);
+        const float4 v1 = *reinterpret_cast<const float4*>(p + ((int64_t)rb * w + j) * Ca);
+        s_cell[i] = make_float4(la * v0.x + lb * v1.x, la * v0.y + lb * v1.y, la * v0.z + lb * v1.z, la * v0.w + lb * v1.w);
     }
     float4 k[9];
 #pragma unroll

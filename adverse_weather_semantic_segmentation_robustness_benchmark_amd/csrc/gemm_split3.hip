@@ -32,11 +32,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int G3T = 512;                   // 8 waves
-constexpr int G3M = 256, G3N = 256, G3K = 32;
-constexpr int G3_STAGE = 32768;            // bytes of one operand's stage: 256 rows x 128 B
-constexpr int G3_A0 = 0, G3_B0 = 2 * G3_STAGE;                    // A stage s at s * 32768, B stage s at 65536 + s * 32768
-constexpr int G3_LDS = 4 * G3_STAGE + 64;                         // + sMax[2]
+constexpr int G3M_MAX = 256, G3K = 32;     // the tile has 32 WV rows (WV = 8 or 4 waves); one operand's stage: rows x 128 B
+constexpr int g3_lds(int wv) { return 4 * (32 * wv * 128) + 64; }   // two stages of two operands + sMax[2]
 constexpr float kActScale0 = 16.0f;        // optimistic-pass activation scale (gemm_split.hip: split_pair_unscaled)
 constexpr int kActExp0 = -4;
 constexpr float kSplitLimit3 = 2048.0f;
@@ -83,6 +80,7 @@ struct g3_args {
     const float* x; const uint16_t* w3; const float* bias; const float* residual; float* out;
     const unsigned* trailer;               // {max|w| bits, weight exponent ew, 0, 0}
     int64_t M; int N, K, act, ntm, ntm8, ntn;
+    int img_bn;                            // rows of an n-tile of the weight image (>= the block tile's width)
     int rot;                               // measurement switch (AWSEG_G3_ROT): block b starts its K loop at K tile (b * rot) % nkt
     int prio;                              // AWSEG_G3_PRIO (default 0): waves 4-7 at raised priority during the first 16-deep step of a K tile
     int stagger;                           // AWSEG_G3_STAGGER (default 1): waves 4-7 issue their LDS-DMA between the two 16-deep steps of a K tile
@@ -105,14 +103,20 @@ __device__ __forceinline__ unsigned pack_bf16_3(float x, float y) { return __bui
 
 // NT: MFMA tiles of 32 columns per wave: block tile 256 x (32 NT) — 8 for N % 256 == 0, 4 for N % 128 == 0, 2 for N % 64 == 0 (the
 // narrow tiles serve HBM-bound shapes: l1 / l2 conv1, MiT projections; the weight image is cut into n-tiles of the same width)
-template <bool CONV, int ABL = 0, bool BF16 = false, int NT = 8>
-__global__ __launch_bounds__(G3T, 2)
+// WV: waves of a block = 32-row strips of its tile.  8: the 256-row tile, one block per CU (128 KB of LDS).  4: a 128-row tile on
+// 64 KB — TWO blocks per CU, so that one block's epilogue (its stores leave a CU at ~15 B/clk: 17 k cycles for a 256 x 256 tile,
+// a third of a K = 256 tile's time) runs beside the other block's K loop; the price is NT <= 4 (every activation
+// fragment is split once per 128 columns instead of 256) and twice the weight traffic from L2 per product.
+template <bool CONV, int ABL = 0, bool BF16 = false, int NT = 8, int WV = 8>
+__global__ __launch_bounds__(64 * WV, 2)
 void gemm_split3_kernel(g3_args a)
 {
+    static_assert(NT <= WV, "a weight stage must fit an activation stage");
+    constexpr int G3M = 32 * WV, G3_STAGE = G3M * 128, G3_A0 = 0, G3_B0 = 2 * G3_STAGE;    // A stage s at s * G3_STAGE, B stage s at 2 G3_STAGE + s * G3_STAGE
     constexpr int BN = 32 * NT;
     constexpr int ROWB = BF16 ? 64 : 128;                          // bytes of a weight row in a K tile
     constexpr int NBI_ALL = BN * ROWB / 1024;                      // LDS-DMA instructions per weight K tile (1 KB each)
-    constexpr int NBI = NBI_ALL >= 8 ? NBI_ALL / 8 : 1;            // per wave (fewer than 8 in all: the first NBI_ALL waves issue one each)
+    constexpr int NBI = NBI_ALL >= WV ? NBI_ALL / WV : 1;          // per wave (fewer than WV in all: the first NBI_ALL waves issue one each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned* sMax = reinterpret_cast<unsigned*>(smem + 4 * G3_STAGE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -141,7 +145,9 @@ void gemm_split3_kernel(g3_args a)
         const int64_t xbytes = rows_left * (int64_t)K * 4;
         if (CONV) x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
         else x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * K), 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
-        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + (int64_t)n0 * kb * (ROWB / 2)), 0, BN * kb * ROWB, 0x00020000);   // n-tile n0 / BN: kb K tiles of BN rows
+        // the weight image is [n-tile of IB rows][kb K tiles][IB rows][ROWB bytes]; this block's BN rows start at row n0 % IB of n-tile n0 / IB
+        const int IB = a.img_bn, nr = n0 % IB;
+        w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + ((int64_t)(n0 - nr) * kb + nr) * (ROWB / 2)), 0, (IB * kb - nr) * ROWB, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int row = 8 * (4 * wave + j) + rl;
@@ -186,9 +192,9 @@ void gemm_split3_kernel(g3_args a)
         }
         {
             const uint32_t lbw = lds0 + (uint32_t)(G3_B0 + stage * G3_STAGE) + wave_u * (uint32_t)(NBI * 1024);
-            if (NBI_ALL >= 8 || (int)wave_u < NBI_ALL) {
+            if (NBI_ALL >= WV || (int)wave_u < NBI_ALL) {
 #pragma unroll
-                for (int j = 0; j < NBI; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * BN * ROWB), lbw + (uint32_t)(j * 1024));
+                for (int j = 0; j < NBI; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * a.img_bn * ROWB), lbw + (uint32_t)(j * 1024));
             }
         }
     };
@@ -539,7 +545,7 @@ bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const vo
 {
     if (awseg_gemm_split3_bn(n) == 0 || k % 8 || k < 64 || m < 1) return false;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) return false;
-    if ((int64_t)G3M * n * 4 > 0x7fffffff || (int64_t)G3M * (k + 32) * 4 > 0x7fffffff) return false;
+    if ((int64_t)G3M_MAX * n * 4 > 0x7fffffff || (int64_t)G3M_MAX * (k + 32) * 4 > 0x7fffffff) return false;
     return true;
 }
 
@@ -564,40 +570,57 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     a.prio = prio;
     a.x = x; a.w3 = w3; a.bias = bias; a.residual = residual; a.out = out; a.trailer = trailer;
     a.M = m; a.N = n; a.K = k; a.act = act;
-    const int64_t ntm = (m + G3M - 1) / G3M;
-    const int bn = awseg_gemm_split3_bn(n);
+    const int img_bn = awseg_gemm_split3_bn(n);
+    a.img_bn = img_bn;
+    // half-height tiles, two blocks per CU (WV = 4): where a tile's epilogue weighs against its K loop and the narrower tile costs
+    // little — measured per shape (kernel_bench, one box, 256-row -> 128-row): K = 64 N = 256 0.498 -> 0.442 ms, K = 128 N = 512
+    // 0.269 -> 0.245, N = 64 K = 256 0.253 -> 0.238, N = 128 K = 512 0.152 -> 0.142; against it K = 256 / 304 N = 256 0.513 -> 0.59 /
+    // 0.625 -> 0.70 (the activation split per 128 instead of 256 columns and twice the weight reads outweigh the overlap) and every
+    // long-K shape (K = 2048: +20 %).  AWSEG_G3_HALF=0 turns it off, =2 forces it on every shape (tests).
+    static int half_mode = -1;
+    if (half_mode < 0) { const char* e = getenv("AWSEG_G3_HALF"); half_mode = e ? atoi(e) : 1; }
+    const int bn_half = img_bn >= 128 ? 128 : 64;
+    const bool half = !bf16 && (half_mode == 2 || (half_mode == 1 && (k <= 128 || (img_bn <= 128 && k <= 512)) &&
+                                                   ((m + 127) / 128) * (int64_t)(n / bn_half) >= 4 * (int64_t)cus));
+    const int rows = half ? 128 : 256;
+    const int bn = half ? bn_half : img_bn;
+    const int64_t ntm = (m + rows - 1) / rows;
     a.ntn = n / bn;
     const int64_t ntm8 = (ntm + 7) / 8 * 8;
     if (ntm8 * a.ntn > 0x7fffffff) return AWSEG_ERANGE;
     a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
     const int64_t slots = ntm8 * a.ntn;
-    int64_t blocks = (int64_t)cus / 8 * 8;
+    int64_t blocks = (int64_t)cus * (half ? 2 : 1) / 8 * 8;
     if (blocks < 8) blocks = 8;
     if (blocks > slots) blocks = slots;
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("AWSEG_G3_ABL"); abl = e ? atoi(e) : 0; }
     if (abl && !conv && !bf16 && bn == 256) {
-#define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a); break; }
+#define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds(8)); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(512), g3_lds(8), stream, a); break; }
         switch (abl) { G3_ABL(1) G3_ABL(2) G3_ABL(3) G3_ABL(4) G3_ABL(5) default: break; }
 #undef G3_ABL
         AWSEG_LAUNCH_CHECK();
         return 0;
     }
-#define G3_GO(CONV_, BF_, NT_)                                                                                                         \
+#define G3_GO(CONV_, BF_, NT_, WV_)                                                                                                    \
     do {                                                                                                                              \
-        auto kf = gemm_split3_kernel<CONV_, 0, BF_, NT_>;                                                                             \
+        auto kf = gemm_split3_kernel<CONV_, 0, BF_, NT_, WV_>;                                                                        \
         static bool attr = false;                                                                                                     \
         if (!attr) {                                                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds(WV_)); \
             if (e != hipSuccess) return (int)e;                                                                                       \
             attr = true;                                                                                                              \
         }                                                                                                                             \
-        hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(G3T), G3_LDS, stream, a);                                                 \
+        hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(64 * WV_), g3_lds(WV_), stream, a);                                       \
     } while (0)
-#define G3_BY_NT(CONV_, BF_) do { if (bn == 256) G3_GO(CONV_, BF_, 8); else if (bn == 128) G3_GO(CONV_, BF_, 4); else G3_GO(CONV_, BF_, 2); } while (0)
+#define G3_BY_NT(CONV_, BF_) do { if (bn == 256) G3_GO(CONV_, BF_, 8, 8); else if (bn == 128) G3_GO(CONV_, BF_, 4, 8); else G3_GO(CONV_, BF_, 2, 8); } while (0)
+#define G3_HALF(CONV_) do { if (bn == 128) G3_GO(CONV_, false, 4, 4); else G3_GO(CONV_, false, 2, 4); } while (0)
     if (bf16) G3_BY_NT(false, true);
+    else if (half && conv) G3_HALF(true);
+    else if (half) G3_HALF(false);
     else if (conv) G3_BY_NT(true, false);
     else G3_BY_NT(false, false);
+#undef G3_HALF
 #undef G3_BY_NT
 #undef G3_GO
     AWSEG_LAUNCH_CHECK();

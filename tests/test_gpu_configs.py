@@ -135,11 +135,11 @@ def test_c3_two_gpus_over_rccl_reproduce_the_single_gpu_miou(native):
     assert one["miou"] == two["miou"], "pooled mIoU dict differs between 1 and 2 GPUs"
 
 
-@pytest.mark.parametrize("env", [{"AWSEG_WINO8": "0"}, {"AWSEG_WINO8": "1"}, {"AWSEG_WINO8": "2"}, {"AWSEG_WINO8_TPB": "3"}, {"AWSEG_WINO8_TPB": "64"}, {"AWSEG_GEMM_SPLIT_V3": "0"}, {"AWSEG_G3_STAGGER": "0"},
+@pytest.mark.parametrize("env", [{"AWSEG_WINO8": "0"}, {"AWSEG_WINO8": "1"}, {"AWSEG_WINO8": "2"}, {"AWSEG_WINO8_TPB": "3"}, {"AWSEG_WINO8_TPB": "64"}, {"AWSEG_GEMM_SPLIT_V3": "0"}, {"AWSEG_G3_STAGGER": "0"}, {"AWSEG_G3_HALF": "0"}, {"AWSEG_G3_HALF": "2"},
                                  {"AWSEG_ASPP_LDS": "0"}, {"AWSEG_ASPP_LDS": "0", "AWSEG_ASPP_ROWS": "0"}, {"AWSEG_STATS_WIDE": "0"}])
 def test_round2_kernels_stay_selectable_and_correct(env):
     """The earlier kernels (four-wave, alternating-role and non-persistent symmetric Winograd; register-staged split GEMM; gemm_split3 without the staggered
-    DMA issue; the ASPP depthwise walk without LDS staging, one class or all classes per lane; the one-pass statistics on 256 threads x 4 pixels) remain behind environment switches, and AWSEG_WINO8_TPB forces the persistent Winograd blocks onto the small test maps (3 tiles a block: ragged last blocks; 64: blocks that own the whole map) for A/B measurements (tools/ab_kernel.sh): their own parity tests run in a
+    DMA issue, with 256-row tiles only and with 128-row tiles (two blocks per CU) on every shape; the ASPP depthwise walk without LDS staging, one class or all classes per lane; the one-pass statistics on 256 threads x 4 pixels) remain behind environment switches, and AWSEG_WINO8_TPB forces the persistent Winograd blocks onto the small test maps (3 tiles a block: ragged last blocks; 64: blocks that own the whole map) for A/B measurements (tools/ab_kernel.sh): their own parity tests run in a
     child process with the switch set (the launchers read it once per process)."""
     e = dict(os.environ, **env)
     r = subprocess.run([sys.executable, "-m", "pytest", str(ROOT / "tests" / "test_gpu_kernels.py"), str(ROOT / "tests" / "test_gpu_models.py"), "-q", "-x", "-m", "gpu", "-k",

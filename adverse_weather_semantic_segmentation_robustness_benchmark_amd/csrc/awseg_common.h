@@ -103,4 +103,5 @@ bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const vo
 int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned* trailer, const float* bias, const float* residual,
                              int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv = nullptr, bool bf16 = false);
 int awseg_gemm_split3_bn(int n);
+int64_t awseg_gemm_split3_image_rows(int n);
 int awseg_gemm_bf16_3_weights(const float* w, int n, int k, uint16_t* w3, hipStream_t stream);

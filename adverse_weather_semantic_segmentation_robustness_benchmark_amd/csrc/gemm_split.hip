@@ -494,7 +494,7 @@ AWSEG_API int64_t awseg_gemm_split_weight_halfs(int n, int k)
 {
     if (n < 1 || k < 1) return -1;
     const int64_t ne = (int64_t)n * k;
-    return 2 * ne + 8 + ((awseg_gemm_split3_bn(n) && k % 8 == 0) ? (int64_t)2 * n * ((k + 31) / 32 * 32) : 0);
+    return 2 * ne + 8 + ((awseg_gemm_split3_bn(n) && k % 8 == 0) ? 2 * awseg_gemm_split3_image_rows(n) * ((k + 31) / 32 * 32) : 0);
 }
 
 namespace {
@@ -526,7 +526,7 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     // round-2 bf16 kernel: 105.0 against 98.7 ms per step)
     if (v3_on && awseg_gemm_split3_eligible(m, n, k, cv ? nullptr : x, out, residual, bias) && !(bf16 && (cv || n % 256)) &&
         (!cv || (cv->C % 32 == 0 && (int64_t)cv->batch * cv->H * cv->W * cv->C * 4 <= 0x7fffffff)) &&
-        ((m + 255) / 256) * (int64_t)(n / awseg_gemm_split3_bn(n)) >= (int64_t)cus / 2) {
+        ((m + 255) / 256) * (int64_t)((n + awseg_gemm_split3_bn(n) - 1) / awseg_gemm_split3_bn(n)) >= (int64_t)cus / 2) {
         const int cdesc[10] = { cv ? cv->H : 0, cv ? cv->W : 0, cv ? cv->C : 0, cv ? cv->Ho : 0, cv ? cv->Wo : 0, cv ? cv->kw : 0,
                                 cv ? cv->stride : 0, cv ? cv->pad : 0, cv ? cv->dil : 0, cv ? (int)cv->batch : 0 };
         return awseg_gemm_split3_launch(x, w_split + 2 * (int64_t)n * k + 8, a.trailer, bias, residual, act, out, m, n, k, cus, awseg_s(stream),
@@ -631,7 +631,7 @@ AWSEG_API int awseg_gemm_bf16_weights(const float* w, int n, int k, uint16_t* w_
     hipLaunchKernelGGL(bf16_weights_kernel, dim3((unsigned)((ne / 2 + SWT) / SWT)), dim3(SWT), 0, awseg_s(stream), w, ne, w_bf16, trailer);
     AWSEG_LAUNCH_CHECK();
     // N % 256 == 0, K % 8 == 0: the k-blocked bf16 image of gemm_split3.hip behind the trailer (awseg_gemm_bf16_weight_halfs)
-    if (awseg_gemm_split3_bn(n) && k % 8 == 0) return awseg_gemm_bf16_3_weights(w, n, k, w_bf16 + 2 * ne + 8, awseg_s(stream));
+    if (n % 64 == 0 && k % 8 == 0) return awseg_gemm_bf16_3_weights(w, n, k, w_bf16 + 2 * ne + 8, awseg_s(stream));
     return 0;
 }
 
@@ -639,7 +639,7 @@ AWSEG_API int64_t awseg_gemm_bf16_weight_halfs(int n, int k)
 {
     if (n < 1 || k < 1) return -1;
     const int64_t ne = (int64_t)n * k;
-    return 2 * ne + 8 + ((awseg_gemm_split3_bn(n) && k % 8 == 0) ? (int64_t)n * ((k + 31) / 32 * 32) : 0);
+    return 2 * ne + 8 + ((n % 64 == 0 && k % 8 == 0) ? (int64_t)n * ((k + 31) / 32 * 32) : 0);
 }
 
 AWSEG_API int awseg_gemm_bf16_bias_act(const float* x, const uint16_t* w_bf16, const float* bias, const float* residual,

@@ -410,8 +410,12 @@ void gemm_split3_kernel(g3_args a)
             const int nrec = rem > 0x7fffffff ? 0x7fffffff : (int)rem;
             const __amdgpu_buffer_rsrc_t o_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.out + tile_off), 0, nrec, 0x00020000);
             const __amdgpu_buffer_rsrc_t r_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.residual ? a.residual : a.out) + tile_off), 0, a.residual ? nrec : 0, 0x00020000);
-            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.bias ? a.bias : a.out) + en0), 0, a.bias ? BN * 4 : 0, 0x00020000);
+            const int ncols = a.N - en0 < BN ? a.N - en0 : BN;     // columns of this tile inside the matrix (N < 64: fewer than BN)
+            const __amdgpu_buffer_rsrc_t b_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)((a.bias ? a.bias : a.out) + en0), 0, a.bias ? ncols * 4 : 0, 0x00020000);
             const int voff = ((wave * 32 + 4 * hk) * a.N + li) * 4;
+            int vcol[NT];                                          // a lane's column of tile j: past N -> an offset no descriptor covers (loads 0, stores dropped)
+#pragma unroll
+            for (int j = 0; j < NT; ++j) vcol[j] = j * 32 + li < ncols ? voff + j * 128 : (int)0x80000000;
             const float relu_floor = a.act == 1 ? 0.f : -__builtin_inff();
             const int rowb = a.N * 4;                              // bytes per output row
             const bool has_res = a.residual != nullptr;           // without one the 16 residual loads per column tile are not issued (-3 % at K = 256)
@@ -435,7 +439,7 @@ void gemm_split3_kernel(g3_args a)
 #pragma unroll
                 for (int r8 = 0; r8 < 8; ++r8) {
                     const int r = 8 * half + r8, rowc = (r & 3) + 8 * (r >> 2);
-                    rv[r8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, voff + j * 128, rowc * rowb, 0));
+                    rv[r8] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_rsrc, vcol[j], rowc * rowb, 0));
                 }
             };
             auto group_store = [&](int g, const float (&rv)[8], bool with_res) {
@@ -447,7 +451,7 @@ void gemm_split3_kernel(g3_args a)
                     vv = vv + bv[j];
                     if (with_res) vv = vv + rv[r8];
                     vv = __builtin_fmaxf(vv, relu_floor);
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, voff + j * 128, rowc * rowb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, vv), o_rsrc, vcol[j], rowc * rowb, 0);
                 }
             };
             if (has_res) {                                          // block-uniform (dword accesses: none of the 16-byte store hazards of DESIGN.md 10a)
@@ -520,7 +524,11 @@ void bf16_3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, i
 }  // namespace
 
 // width of the block tile (and of the weight image's n-tiles) for an N-column problem; 0: not served
-int awseg_gemm_split3_bn(int n) { return n % 256 == 0 ? 256 : (n % 128 == 0 ? 128 : (n % 64 == 0 ? 64 : 0)); }
+// (N < 64, N % 8 != ... any width from 8 up: ONE 64-column tile whose columns past N are never stored — the 48-channel skip projection
+// and the 19-class head of DeepLabV3+, MiT stage 1's 32-channel projections: HBM-bound launches of 10^6 rows)
+int awseg_gemm_split3_bn(int n) { return n % 256 == 0 ? 256 : (n % 128 == 0 ? 128 : (n % 64 == 0 ? 64 : ((n >= 8 && n < 64) ? 64 : 0))); }
+// rows of the weight image: N rounded up to whole n-tiles (the rows past N are zero)
+int64_t awseg_gemm_split3_image_rows(int n) { const int bn = awseg_gemm_split3_bn(n); return bn ? (int64_t)(n + bn - 1) / bn * bn : 0; }
 
 int awseg_gemm_bf16_3_weights(const float* w, int n, int k, uint16_t* w3, hipStream_t stream)
 {
@@ -536,6 +544,11 @@ int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const 
 {
     const int kb = (k + 31) / 32;
     const int64_t ne = (int64_t)n * kb * 32;
+    const int64_t rows = awseg_gemm_split3_image_rows(n);
+    if (rows != n) {                                               // a last n-tile with rows past N: they stay zero
+        hipError_t e = hipMemsetAsync(w3, 0, (size_t)rows * kb * 32 * 2 * sizeof(uint16_t), stream);
+        if (e != hipSuccess) return (int)e;
+    }
     hipLaunchKernelGGL(split3_weights_kernel, dim3((unsigned)((ne / 2 + 255) / 256)), dim3(256), 0, stream, w, n, k, kb, awseg_gemm_split3_bn(n), w3, trailer);
     AWSEG_LAUNCH_CHECK();
     return 0;
@@ -543,7 +556,7 @@ int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const 
 
 bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const void* out, const void* residual, const void* bias)
 {
-    if (awseg_gemm_split3_bn(n) == 0 || k % 8 || k < 64 || m < 1) return false;
+    if (awseg_gemm_split3_bn(n) == 0 || k % 8 || k < 32 || m < 1) return false;
     if (((uintptr_t)x | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)bias) & 15) return false;
     if ((int64_t)G3M_MAX * n * 4 > 0x7fffffff || (int64_t)G3M_MAX * (k + 32) * 4 > 0x7fffffff) return false;
     return true;
@@ -581,11 +594,11 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     if (half_mode < 0) { const char* e = getenv("AWSEG_G3_HALF"); half_mode = e ? atoi(e) : 1; }
     const int bn_half = img_bn >= 128 ? 128 : 64;
     const bool half = !bf16 && (half_mode == 2 || (half_mode == 1 && (k <= 128 || (img_bn <= 128 && k <= 512)) &&
-                                                   ((m + 127) / 128) * (int64_t)(n / bn_half) >= 4 * (int64_t)cus));
+                                                   ((m + 127) / 128) * (int64_t)((n + bn_half - 1) / bn_half) >= 4 * (int64_t)cus));
     const int rows = half ? 128 : 256;
     const int bn = half ? bn_half : img_bn;
     const int64_t ntm = (m + rows - 1) / rows;
-    a.ntn = n / bn;
+    a.ntn = (n + bn - 1) / bn;                                     // N < 64: one tile, its columns past N masked in the epilogue
     const int64_t ntm8 = (ntm + 7) / 8 * 8;
     if (ntm8 * a.ntn > 0x7fffffff) return AWSEG_ERANGE;
     a.ntm = (int)ntm; a.ntm8 = (int)ntm8;

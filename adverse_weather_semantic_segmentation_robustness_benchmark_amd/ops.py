@@ -626,8 +626,17 @@ GEMM_SPLIT_MIN_M, GEMM_SPLIT_MIN_N, GEMM_SPLIT_MIN_K = 128, 128, 64
 GEMM_SPLIT_N64 = os.environ.get("AWSEG_GEMM_SPLIT_N64", "1") != "0"
 
 
+GEMM_SPLIT_NARROW = os.environ.get("AWSEG_GEMM_SPLIT_NARROW", "1") != "0"
+
+
 def gemm_wants_split(m: int, n: int, k: int) -> bool:
-    if not GEMM_SPLIT or m < GEMM_SPLIT_MIN_M or k < GEMM_SPLIT_MIN_K or k % 8:
+    if not GEMM_SPLIT or k % 8:
+        return False
+    # N < 64 on 10^6 rows (DeepLabV3+'s 48-channel skip projection and 19-class head, MiT stage 1's 32-channel projections): one
+    # masked 64-column tile of the LDS-DMA kernel, 128 rows a block — these launches are bound by reading x once
+    if GEMM_SPLIT_NARROW and 8 <= n < 64 and k >= 32 and m >= (1 << 18):
+        return True
+    if m < GEMM_SPLIT_MIN_M or k < GEMM_SPLIT_MIN_K:
         return False
     # N = 64 (ResNet layer1 conv1, MiT stage-2 projections): only where the LDS-DMA kernel's 256 x 64 tiles fill the chip
     return n >= GEMM_SPLIT_MIN_N or (n == 64 and GEMM_SPLIT_N64 and ((m + 255) // 256) >= 128)

@@ -14,6 +14,7 @@ What changes relative to the module graphs (profiles/r01_bench_step_kernels_v1.c
 """
 from __future__ import annotations
 
+import os
 from typing import List
 
 import torch
@@ -307,11 +308,16 @@ def _ln(t, ln: nn.LayerNorm):
     return F.layer_norm(t, (c,), ln.weight, ln.bias, ln.eps)
 
 
+LINEAR_SPLIT = os.environ.get("AWSEG_LINEAR_SPLIT", "1") != "0"
+
+
 def _linear(x: torch.Tensor, lin: nn.Linear) -> torch.Tensor:
-    """lin(x) on the last dimension: torch's float32 GEMM, or — in bf16 mode — this repo's GEMM kernel on bf16 MFMA."""
+    """lin(x) on the last dimension: this repo's GEMM kernels where they take the shape (split-operand f16 MFMA; bf16 MFMA in bf16
+    mode), torch's float32 GEMM otherwise.  AWSEG_LINEAR_SPLIT=0: the q / k / v / fc1 projections stay on torch's GEMM as in round 2."""
     k = x.shape[-1]
     m = x.numel() // k
-    if lin.bias is not None and x.is_contiguous() and ops.gemm_wants_bf16(m, lin.out_features, k):
+    if lin.bias is not None and x.is_contiguous() and (ops.gemm_wants_bf16(m, lin.out_features, k) or
+                                                       (LINEAR_SPLIT and ops.gemm_wants_split(m, lin.out_features, k))):
         y = ops.gemm_bias_act(x.view(m, k), lin.weight, lin.bias, N.ACT_NONE, w_split=split_weights(lin, lin.weight, m))
         return y.view(*x.shape[:-1], lin.out_features)
     return F.linear(x, lin.weight, lin.bias)

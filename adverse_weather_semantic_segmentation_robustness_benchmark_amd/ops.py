@@ -636,6 +636,8 @@ def gemm_wants_split(m: int, n: int, k: int) -> bool:
     # masked 64-column tile of the LDS-DMA kernel, 128 rows a block — these launches are bound by reading x once
     if GEMM_SPLIT_NARROW and 8 <= n < 64 and k >= 32 and m >= (1 << 18):
         return True
+    if GEMM_SPLIT_NARROW and n % 64 == 0 and k == 32 and m >= (1 << 18):      # MiT stage 1's fc1 (32 -> 128): a single K tile
+        return True
     if m < GEMM_SPLIT_MIN_M or k < GEMM_SPLIT_MIN_K:
         return False
     # N = 64 (ResNet layer1 conv1, MiT stage-2 projections): only where the LDS-DMA kernel's 256 x 64 tiles fill the chip

@@ -498,7 +498,7 @@ AWSEG_API int64_t awseg_gemm_split_weight_halfs(int n, int k)
 }
 
 namespace {
-struct conv_desc { int H, W, C, Ho, Wo, kw, stride, pad, dil; int64_t batch; };
+struct conv_desc { int H, W, C, Ho, Wo, kw, stride, pad, dil; int64_t batch; int pitch = 0, padx = -1; };   // pitch / padx: the ROWS form of gemm_split3.hip
 
 int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float* bias, const float* residual,
                 int act, float* out, int64_t m, int n, int k, awseg_stream_t stream, const conv_desc* cv = nullptr)
@@ -525,13 +525,14 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     // (bf16: only the 256-wide tile — on B5 + R101's N = 64 / 128 / 320 projections the narrow tiles measured slower than the
     // round-2 bf16 kernel: 105.0 against 98.7 ms per step)
     if (v3_on && awseg_gemm_split3_eligible(m, n, k, cv ? nullptr : x, out, residual, bias) && !(bf16 && (cv || n % 256)) &&
-        (!cv || (cv->C % 32 == 0 && (int64_t)cv->batch * cv->H * cv->W * cv->C * 4 <= 0x7fffffff)) &&
+        (!cv || (cv->C % 32 == 0 && (int64_t)cv->batch * cv->H * cv->W * (cv->pitch > 0 ? cv->pitch : cv->C) * 4 <= 0x7fffffff)) &&
         ((m + 255) / 256) * (int64_t)((n + awseg_gemm_split3_bn(n) - 1) / awseg_gemm_split3_bn(n)) >= (int64_t)cus / 2) {
-        const int cdesc[10] = { cv ? cv->H : 0, cv ? cv->W : 0, cv ? cv->C : 0, cv ? cv->Ho : 0, cv ? cv->Wo : 0, cv ? cv->kw : 0,
-                                cv ? cv->stride : 0, cv ? cv->pad : 0, cv ? cv->dil : 0, cv ? (int)cv->batch : 0 };
+        const int cdesc[12] = { cv ? cv->H : 0, cv ? cv->W : 0, cv ? cv->C : 0, cv ? cv->Ho : 0, cv ? cv->Wo : 0, cv ? cv->kw : 0,
+                                cv ? cv->stride : 0, cv ? cv->pad : 0, cv ? cv->dil : 0, cv ? (int)cv->batch : 0, cv ? cv->pitch : 0, cv ? cv->padx : -1 };
         return awseg_gemm_split3_launch(x, w_split + 2 * (int64_t)n * k + 8, a.trailer, bias, residual, act, out, m, n, k, cus, awseg_s(stream),
                                         cv ? cdesc : nullptr, bf16);
     }
+    if (cv && cv->pitch > 0) return AWSEG_ERANGE;                // the ROWS form exists in the LDS-DMA kernel only
     static int tile_mode = -1;                                   // AWSEG_GEMM_SPLIT_TILE = 128 / 256 / 512 forces the block tile (measurements; 512 = 256 x 256)
     if (tile_mode < 0) { const char* e = getenv("AWSEG_GEMM_SPLIT_TILE"); tile_mode = !e ? 0 : (atoi(e) == 512 ? 3 : (atoi(e) == 256 ? 2 : (atoi(e) == 128 ? 1 : 0))); }
     // 256 x 256 (single accumulator) when N fills it and there is at least one tile per CU (AWSEG_GEMM_SPLIT_HUGE_MIN_TILES per CU); else the 128 x 256 tile when N
@@ -619,6 +620,23 @@ AWSEG_API int awseg_conv_gemm_split_bias_act(const float* x, int64_t batch, int 
     if (k > 0x7fffffff || batch * height > 0x7fffffff) return AWSEG_ERANGE;
     const conv_desc cv = { height, width, channels, ho, wo, kernel_w, stride, pad, dilation, batch };
     return gemm_launch(false, x, w_split, bias, residual, act, out, batch * ho * wo, n, (int)k, stream, &cv);
+}
+
+AWSEG_API int awseg_conv_rows_gemm_split_bias_act(const float* x, int64_t batch, int height, int width_padded, int pixel_floats,
+                                                  int kernel_h, int stride, int pad_y, int out_width, const uint16_t* w_split,
+                                                  const float* bias, const float* residual, int act, float* out, int n,
+                                                  awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (batch < 0 || height < 1 || width_padded < 8 || kernel_h < 1 || stride < 1 || pad_y < 0 || out_width < 1) return AWSEG_EINVAL;
+    if (pixel_floats < 4 || pixel_floats % 4 || 32 % pixel_floats) return AWSEG_ERANGE;     // 16-byte chunks of whole pixels, a run of 32 floats
+    // the last output column's run of 32 floats must end inside its (padded) image row
+    if ((int64_t)(out_width - 1) * stride * pixel_floats + 32 > (int64_t)width_padded * pixel_floats) return AWSEG_ERANGE;
+    const int ho = (height + 2 * pad_y - kernel_h) / stride + 1;
+    if (ho < 1 || batch * height > 0x7fffffff) return AWSEG_ERANGE;
+    conv_desc cv = { height, width_padded, 32, ho, out_width, 1, stride, pad_y, 1, batch };
+    cv.pitch = pixel_floats; cv.padx = 0;
+    return gemm_launch(false, x, w_split, bias, residual, act, out, batch * ho * out_width, n, kernel_h * 32, stream, &cv);
 }
 
 AWSEG_API int awseg_gemm_bf16_weights(const float* w, int n, int k, uint16_t* w_bf16, awseg_stream_t stream)

@@ -88,6 +88,10 @@ struct g3_args {
     // A operand is gathered from it by the LDS-DMA's per-lane source address — column k = (ky * ckw + kx) * cC + c is
     // x[b, oy * cs - cp + ky * cd, ox * cs - cp + kx * cd, c], zero outside (awseg_conv_gemm_split_bias_act)
     int cH, cW, cC, cHo, cWo, ckw, cs, cp, cd;
+    // ROWS form (awseg_conv_rows_gemm_split_bias_act: the 7x7 stems on 3 input channels): the image has cpitch floats a pixel
+    // (< cC), a 'tap' is a run of cC = 32 consecutive floats of one image row (8 pixels x 4 channels) starting at pixel
+    // ox * cs - cpx, one tap per kernel row (ckw = 1); the image is zero-padded on the left / right so that a run never leaves its row
+    int cpitch, cpx;
     int64_t x_bytes;
 };
 
@@ -170,7 +174,7 @@ void gemm_split3_kernel(g3_args a)
                 const int b = (int)(m / ((int64_t)a.cHo * a.cWo));
                 const int rem = (int)(m - (int64_t)b * a.cHo * a.cWo);
                 const int oy = rem / a.cWo, ox = rem - oy * a.cWo;
-                cby[j] = m < a.M ? b * a.cH : -1; cy0[j] = oy * a.cs - a.cp; cx0[j] = ox * a.cs - a.cp;
+                cby[j] = m < a.M ? b * a.cH : -1; cy0[j] = oy * a.cs - a.cp; cx0[j] = ox * a.cs - a.cpx;
             }
         }
     };
@@ -183,7 +187,7 @@ void gemm_split3_kernel(g3_args a)
             for (int j = 0; j < 4; ++j) {
                 const int iy = cy0[j] + ky * a.cd, ix = cx0[j] + kx * a.cd;
                 const bool ok = cby[j] >= 0 && (unsigned)iy < (unsigned)a.cH && (unsigned)ix < (unsigned)a.cW;
-                const uint32_t vo = ok ? (uint32_t)((((cby[j] + iy) * a.cW + ix) * a.cC + c0) * 4) + a_voff[j] : 0x80000000u;
+                const uint32_t vo = ok ? (uint32_t)((((cby[j] + iy) * a.cW + ix) * a.cpitch + c0) * 4) + a_voff[j] : 0x80000000u;
                 dma16(x_rsrc, vo, 0u, la + (uint32_t)(j * 1024));
             }
         } else {
@@ -566,10 +570,11 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
                              int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv, bool bf16)
 {
     g3_args a;
-    a.cH = a.cW = a.cC = a.cHo = a.cWo = a.ckw = a.cs = 1; a.cp = 0; a.cd = 1; a.x_bytes = 0;
-    if (conv) {                                                   // {H, W, C, Ho, Wo, kw, stride, pad, dil, batch}
+    a.cH = a.cW = a.cC = a.cHo = a.cWo = a.ckw = a.cs = 1; a.cp = 0; a.cd = 1; a.x_bytes = 0; a.cpitch = 1; a.cpx = 0;
+    if (conv) {                                                   // {H, W, C, Ho, Wo, kw, stride, pad, dil, batch, pixel pitch (0: C), pad x (-1: pad)}
         a.cH = conv[0]; a.cW = conv[1]; a.cC = conv[2]; a.cHo = conv[3]; a.cWo = conv[4]; a.ckw = conv[5]; a.cs = conv[6]; a.cp = conv[7]; a.cd = conv[8];
-        a.x_bytes = (int64_t)conv[9] * a.cH * a.cW * a.cC * 4;
+        a.cpitch = conv[10] > 0 ? conv[10] : a.cC; a.cpx = conv[11] >= 0 ? conv[11] : a.cp;
+        a.x_bytes = (int64_t)conv[9] * a.cH * a.cW * a.cpitch * 4;
         if (a.cC % G3K || a.x_bytes > 0x7fffffff) return AWSEG_ERANGE;    // checked by the caller (eligibility)
     }
     static int rot = -1;

@@ -14,6 +14,7 @@ What changes relative to the module graphs (profiles/r01_bench_step_kernels_v1.c
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List
 
@@ -248,6 +249,54 @@ def conv_bn_act(x: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d, act: int, 
     return y
 
 
+STEM_ROWS = os.environ.get("AWSEG_STEM_ROWS", "1") != "0"
+_stem_pad = {}
+_stem_scope = None
+
+
+@contextlib.contextmanager
+def stem_scope():
+    """Inside one ensemble forward both members read the same input: the zero-padded 4-channel image of `_stem_rows` is built by
+    the first stem and reused by the second (keyed on the input's storage; the scope ends with the forward, so a buffer that is
+    refilled in place for the next batch is padded again)."""
+    global _stem_scope
+    prev, _stem_scope = _stem_scope, {}
+    try:
+        yield
+    finally:
+        _stem_scope = prev
+
+
+def _stem_rows(x: torch.Tensor, conv: nn.Conv2d, w: torch.Tensor, bias: torch.Tensor = None):
+    """A 7x7 stem on <= 4 input channels (ResNet conv1: stride 2; MiT's first patch embedding: stride 4, 32 channels) as one
+    split-operand GEMM whose A operand is gathered row by row from a zero-padded [B, H, W + pads, 4] copy of the image
+    (ops.conv_rows_gemm_split) instead of MIOpen's float32 implicit GEMM (+ its separate bias kernel).  Returns the NHWC result
+    [B, Ho, Wo, N], or None when the shape is not a stem's / the kernel does not take it."""
+    st = conv.stride[0]
+    if not (STEM_ROWS and ops.GEMM_SPLIT and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (7, 7) and conv.stride in ((2, 2), (4, 4))
+            and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels <= 4
+            and (conv.out_channels % 64 == 0 or 8 <= conv.out_channels < 64) and ops.PRECISION != "bf16"):
+        return None
+    B, C, H, W = x.shape
+    wo = (W + 6 - 7) // st + 1
+    wp = max(W + 3, (wo - 1) * st + 8)                     # 3 zero columns on the left; the last run of 8 pixels ends inside the row
+    wp_any = max(W + 3, ((W + 6 - 7) // 2) * 2 + 8, ((W + 6 - 7) // 4) * 4 + 8)   # one image for both strides
+    skey = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
+    xp = _stem_scope.get(skey) if _stem_scope is not None else None
+    if xp is None:
+        key = (str(x.device), B, H, wp_any)
+        xp = _stem_pad.get(key)
+        if xp is None:
+            _stem_pad.clear()                                  # one shape at a time: 270 MB at 8 x 1024 x 2048
+            xp = _stem_pad[key] = torch.zeros(B, H, wp_any, 4, dtype=torch.float32, device=x.device)
+        xp[:, :, 3:3 + W, :C] = x.permute(0, 2, 3, 1)      # the padding columns / channel stay zero
+        if _stem_scope is not None:
+            _stem_scope[skey] = xp
+    assert wp <= wp_any
+    ws = cached(conv, "stemrows", [w], lambda: ops.gemm_split_weights(ops.stem_rows_weights(w)))
+    return ops.conv_rows_gemm_split(xp, ws, bias, N.ACT_NONE, 7, st, 3, wo)
+
+
 # --------------------------------------------------------------------------- ResNet encoder
 @torch.no_grad()
 def resnet_features(enc, x: torch.Tensor, stem_feature: bool = False) -> List[torch.Tensor]:
@@ -263,7 +312,8 @@ def resnet_features(enc, x: torch.Tensor, stem_feature: bool = False) -> List[to
         y = enc.maxpool(y)
     else:
         w, shift = folded_conv_bn(enc.conv1, enc.bn1)
-        y = F.conv2d(x, w, None, enc.conv1.stride, enc.conv1.padding)
+        y = _stem_rows(x, enc.conv1, w)
+        y = y.permute(0, 3, 1, 2) if y is not None else F.conv2d(x, w, None, enc.conv1.stride, enc.conv1.padding)
         mp = enc.maxpool
         if (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous(memory_format=CL) and y.shape[1] % 4 == 0
                 and _pair(mp.kernel_size) == (3, 3) and _pair(mp.stride) == (2, 2) and _pair(mp.padding) == (1, 1)
@@ -347,8 +397,10 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
             w2 = cached(pe.proj, "patch", [pe.proj.weight], lambda: patch_weights(pe.proj))
             y = conv_gemm_nhwc(nhwc_view(t), pe.proj, w2, pe.proj.bias, N.ACT_NONE)              # [B,H,W,C]
         else:
-            w = cached(pe.proj, "wcl", [pe.proj.weight], lambda: pe.proj.weight.contiguous(memory_format=CL))
-            y = nhwc_view(F.conv2d(t, w, pe.proj.bias, pe.proj.stride, pe.proj.padding))
+            y = _stem_rows(t, pe.proj, pe.proj.weight, pe.proj.bias) if pe.proj.bias is not None else None
+            if y is None:
+                w = cached(pe.proj, "wcl", [pe.proj.weight], lambda: pe.proj.weight.contiguous(memory_format=CL))
+                y = nhwc_view(F.conv2d(t, w, pe.proj.bias, pe.proj.stride, pe.proj.padding))
         tok = _ln(y, pe.layer_norm)                                          # [B,H,W,C]
         B, H, W, C = tok.shape
         for blk in st.blocks:

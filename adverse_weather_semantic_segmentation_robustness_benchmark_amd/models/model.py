@@ -329,10 +329,11 @@ class EnsembleModel(nn.Module):
         when nothing per-pixel is asked for (`self._stats_fused` tells the caller whether it happened)."""
         if x.is_cuda and x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
             x = x.contiguous(memory_format=torch.channels_last)    # both members start from NHWC memory: convert once, not once each
-        o1 = self.segformer(x)
         self.deeplabv3plus._defer_depth_upsample = self.include_depth
         try:
-            o2 = self.deeplabv3plus(x)
+            with fused.stem_scope():                               # the two 7x7 stems share one zero-padded copy of the input
+                o1 = self.segformer(x)
+                o2 = self.deeplabv3plus(x)
         finally:
             self.deeplabv3plus._defer_depth_upsample = False
         mode = _STRATEGY.get(self.ensemble_strategy, N.COMBINE_MEAN)

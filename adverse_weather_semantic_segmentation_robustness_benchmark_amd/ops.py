@@ -676,6 +676,35 @@ def gemm_split_bias_act(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[t
     return out
 
 
+def stem_rows_weights(w: torch.Tensor) -> torch.Tensor:
+    """[N, C <= 4, kh, kw <= 8] convolution weights -> the [N, kh * 32] matrix of awseg_conv_rows_gemm_split_bias_act
+    (column ky * 32 + kx * 4 + c, zeros elsewhere)."""
+    n, c, kh, kw = w.shape
+    if c > 4 or kw > 8:
+        raise N.AwsegError("stem_rows_weights: at most 4 input channels and 8 kernel columns")
+    m = torch.zeros(n, kh, 8, 4, dtype=torch.float32, device=w.device)
+    m[:, :, :kw, :c] = w.permute(0, 2, 3, 1)
+    return m.view(n, kh * 32)
+
+
+def conv_rows_gemm_split(x_padded: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], act: int, kernel_h: int,
+                         stride: int, pad_y: int, out_width: int) -> Optional[torch.Tensor]:
+    """The 7x7 stem as one split-operand GEMM (awseg_conv_rows_gemm_split_bias_act): x_padded float32 [B, H, W + pads, 4] with
+    zero padding columns / channel, w_split = gemm_split_weights(stem_rows_weights(w)).  Returns [B, Ho, out_width, N], or None
+    when the LDS-DMA kernel does not take the shape (the caller keeps its other path)."""
+    b, h, wp, pf = x_padded.shape
+    n, k = w_split.shape[1], w_split.shape[2]
+    if k != kernel_h * 32 or not x_padded.is_contiguous():
+        raise N.AwsegError("conv_rows_gemm_split: weights must be [N, kernel_h * 32] and the image contiguous")
+    if not _split_weights_intact(w_split, n, k):
+        raise N.AwsegError("w_split lost its 16-byte trailer (weight exponent): pass the tensor gemm_split_weights returned, not a copy")
+    ho = (h + 2 * pad_y - kernel_h) // stride + 1
+    out = torch.empty(b, ho, out_width, n, dtype=torch.float32, device=x_padded.device)
+    rc = N.try_call("awseg_conv_rows_gemm_split_bias_act", N.ptr(x_padded), b, h, wp, pf, kernel_h, stride, pad_y, out_width,
+                    N.ptr(w_split), N.ptr(bias), None, act, N.ptr(out), n, N.stream())
+    return out if rc == 0 else None
+
+
 # strided / patch convolutions: gather the A operand inside the split GEMM (default) or write the im2col matrix first (AWSEG_CONV_GATHER=0)
 CONV_GATHER = os.environ.get("AWSEG_CONV_GATHER", "1") != "0"
 

@@ -510,6 +510,20 @@ int awseg_conv_gemm_split_bias_act(const float* x, int64_t batch, int height, in
                                    const uint16_t* w_split, const float* bias, const float* residual, int act,
                                    float* out, int n, awseg_stream_t stream);
 
+/* The 7x7 stems on 3 input channels (the smp ResNet encoder's conv1: 7x7, stride 2, padding 3, behind PKG/models/model.py:262-268;
+ * the first SegFormer patch embedding: 7x7, stride 4, 32 channels, behind :160-166) as the same GEMM with a ROW-gathered A operand.  x float32 [batch, height, width_padded, pixel_floats]: the image with
+ * pixel_floats (4) floats a pixel — channels past the real ones zero — and zero columns on both sides: `pad` of them on the left,
+ * enough on the right for the last output column's run.  Row (b, oy, ox) of the A operand is, per kernel row ky, the run of 32
+ * consecutive floats (8 pixels) that starts at padded pixel ox * stride of image row oy * stride - pad_y + ky (zeros outside the
+ * image rows), K = kernel_h * 32; the weights are [n, kernel_h * 32] with column ky * 32 + kx * pixel_floats + c (zero where
+ * kx >= kernel_w or c is a padding channel), split by awseg_gemm_split_weights.  out float32 [batch * Ho * out_width, n] = NHWC.
+ * AWSEG_ERANGE when the shape does not fit the LDS-DMA kernel (n neither a multiple of 64 nor below it, too few tiles): the
+ * caller keeps its other path. */
+int awseg_conv_rows_gemm_split_bias_act(const float* x, int64_t batch, int height, int width_padded, int pixel_floats,
+                                        int kernel_h, int stride, int pad_y, int out_width, const uint16_t* w_split,
+                                        const float* bias, const float* residual, int act, float* out, int n,
+                                        awseg_stream_t stream);
+
 /* ------------------------------------------------------------------------- *
  *  BASELINE config 5: the bf16 MFMA path (SegFormer-B5 + DeepLabV3+-R101)
  * ------------------------------------------------------------------------- *

@@ -1074,6 +1074,33 @@ def test_gemm_split_float32_grade(ops, shape, res_act):
     assert e_split < 4 * e_lib + 1e-6
 
 
+@pytest.mark.parametrize("cfg", [(8, 512, 1024, 64), (3, 200, 328, 64), (2, 1024, 2048, 128)])
+def test_stem_rows_gemm_matches_conv7x7(ops, cfg):
+    """awseg_conv_rows_gemm_split_bias_act (the 7x7 / stride-2 / padding-3 stem on 3 channels, A operand gathered as runs of 8
+    padded pixels per kernel row) against torch's convolution in float64: odd sizes (the last run ends in the right padding),
+    bias + ReLU epilogue, an image border on every side."""
+    B, H, W, Nn = cfg
+    g = torch.Generator(device="cuda").manual_seed(sum(cfg))
+    x = torch.randn(B, 3, H, W, device="cuda", generator=g) * 2.0
+    wt = torch.randn(Nn, 3, 7, 7, device="cuda", generator=g) * 0.1
+    bias = torch.randn(Nn, device="cuda", generator=g)
+    wo = (W + 6 - 7) // 2 + 1
+    wp = max(W + 3, (wo - 1) * 2 + 8)
+    xp = torch.zeros(B, H, wp, 4, device="cuda")
+    xp[:, :, 3:3 + W, :3] = x.permute(0, 2, 3, 1)
+    ws = ops.gemm_split_weights(ops.stem_rows_weights(wt))
+    got = ops.conv_rows_gemm_split(xp, ws, bias, 1, 7, 2, 3, wo)
+    assert got is not None, "the LDS-DMA kernel declined a stem shape with thousands of tiles"
+    ref = torch.nn.functional.conv2d(x.double(), wt.double(), bias.double(), 2, 3).clamp_min(0).permute(0, 2, 3, 1)
+    assert got.shape == ref.shape
+    err = (got.double() - ref).abs().max().item()
+    print(f"stem rows {cfg}: max abs err {err:.3e} at magnitude {ref.abs().max().item():.1f}")
+    assert err < 1e-5 * max(1.0, ref.abs().max().item())
+    # a shape with too few tiles is declined (None), not computed some other way
+    small = torch.zeros(1, 16, 35, 4, device="cuda")
+    assert ops.conv_rows_gemm_split(small, ws, bias, 1, 7, 2, 3, 14) is None
+
+
 @pytest.mark.parametrize("cfg", [(2, 37, 53, 64, 128, 3, 3, 2, 1), (1, 64, 96, 32, 160, 2, 2, 2, 0), (3, 40, 40, 128, 256, 1, 1, 2, 0),
                                  (8, 128, 256, 128, 128, 3, 3, 2, 1), (2, 128, 256, 256, 512, 1, 1, 2, 0), (4, 256, 512, 64, 256, 3, 3, 2, 1)])
 def test_conv_gemm_split_equals_im2col_plus_gemm(ops, cfg):

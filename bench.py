@@ -111,6 +111,17 @@ def launch_work(name, args):
         # (x, w_split, bias, residual, act, out, m, n, k): three f16 MFMA products per float32-grade product, priced as issued
         m, n, k = args[6:9]
         return "mfma_f16", 3 * 2.0 * m * n * k
+    if name == "awseg_conv_gemm_split_bias_act":
+        # (x, batch, H, W, C, kh, kw, stride, pad, dil, w_split, bias, residual, act, out, n): the same GEMM, A operand gathered
+        _, b, h, w, c, kh, kw, st, pd, dl = args[:10]
+        ho, wo = (h + 2 * pd - dl * (kh - 1) - 1) // st + 1, (w + 2 * pd - dl * (kw - 1) - 1) // st + 1
+        return "mfma_f16", 3 * 2.0 * b * ho * wo * args[15] * kh * kw * c
+    if name == "awseg_conv_rows_gemm_split_bias_act":
+        # (x, batch, H, Wp, pixel_floats, kh, stride, pad_y, out_w, w_split, bias, residual, act, out, n): K = kh * 32 as issued
+        # (35 % of it multiplies zero weights: kx = 7, c = 3)
+        _, b, h, _, _, kh, st, pdy, wo = args[:9]
+        ho = (h + 2 * pdy - kh) // st + 1
+        return "mfma_f16", 3 * 2.0 * b * ho * wo * args[14] * kh * 32
     if name == "awseg_dwconv3x3_nhwc":
         # (x, batch, H, W, C, ...): read + write of the activation
         _, b, h, w, c = args[:5]
@@ -178,6 +189,7 @@ def algorithmic_work(name, B, H, W, C, info):
 
 # device-function names of the C-ABI launchers' dominant kernels (for the PMC traffic lookup)
 DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
+                 "awseg_conv_rows_gemm_split_bias_act": ("gemm_split3_kernel<true, 0, false, 2, 4", "gemm_split3_kernel<true, 0, false, 2, 8"),
                  "awseg_conv3x3_winograd_split_nhwc": ("wino8p_kernel<0, false>", "wino8p_kernel<1, false>", "wino8s_kernel<0, false>", "wino8s_kernel<1, false>", "wino8_kernel<0, false>", "wino8_kernel<1, false>", "wino_split_kernel<0, false>", "wino_split_kernel<1, false>"),
                  "awseg_conv3x3_winograd_bf16_nhwc": ("wino8p_kernel<0, true>", "wino8p_kernel<1, true>", "wino8s_kernel<0, true>", "wino8s_kernel<1, true>", "wino8_kernel<0, true>", "wino8_kernel<1, true>", "wino_split_kernel<0, true>", "wino_split_kernel<1, true>"),
                  "awseg_gemm_split_bias_act": ("gemm_split3_kernel<false, 0, false", "gemm_split3_kernel<true, 0, false", "gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false", "gemm_split_kernel<2, 2, 4, 2, false, false, true", "gemm_split_kernel<2, 2, 4, 2, true, false, true"),

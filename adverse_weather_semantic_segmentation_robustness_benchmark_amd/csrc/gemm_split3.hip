@@ -528,9 +528,10 @@ void bf16_3_weights_kernel(const float* __restrict__ w, int n_rows, int k_dim, i
 }  // namespace
 
 // width of the block tile (and of the weight image's n-tiles) for an N-column problem; 0: not served
-// (N < 64, N % 8 != ... any width from 8 up: ONE 64-column tile whose columns past N are never stored — the 48-channel skip projection
+// (N < 64, any width from 8 up: ONE 64-column tile whose columns past N are never stored — the 48-channel skip projection
 // and the 19-class head of DeepLabV3+, MiT stage 1's 32-channel projections: HBM-bound launches of 10^6 rows)
-int awseg_gemm_split3_bn(int n) { return n % 256 == 0 ? 256 : (n % 128 == 0 ? 128 : (n % 64 == 0 ? 64 : ((n >= 8 && n < 64) ? 64 : 0))); }
+// (any other N >= 8: 64-column tiles, the last one masked the same way — MiT stage 3's 160 channels are 2.5 tiles)
+int awseg_gemm_split3_bn(int n) { return n % 256 == 0 ? 256 : (n % 128 == 0 ? 128 : (n >= 8 ? 64 : 0)); }
 // rows of the weight image: N rounded up to whole n-tiles (the rows past N are zero)
 int64_t awseg_gemm_split3_image_rows(int n) { const int bn = awseg_gemm_split3_bn(n); return bn ? (int64_t)(n + bn - 1) / bn * bn : 0; }
 

@@ -526,7 +526,8 @@ int gemm_launch(bool bf16, const float* x, const uint16_t* w_split, const float*
     // round-2 bf16 kernel: 105.0 against 98.7 ms per step)
     if (v3_on && awseg_gemm_split3_eligible(m, n, k, cv ? nullptr : x, out, residual, bias) && !(bf16 && (cv || n % 256)) &&
         (!cv || (cv->C % 32 == 0 && (int64_t)cv->batch * cv->H * cv->W * (cv->pitch > 0 ? cv->pitch : cv->C) * 4 <= 0x7fffffff)) &&
-        ((m + 255) / 256) * (int64_t)((n + awseg_gemm_split3_bn(n) - 1) / awseg_gemm_split3_bn(n)) >= (int64_t)cus / 2) {
+        (((m + 255) / 256) * (int64_t)((n + awseg_gemm_split3_bn(n) - 1) / awseg_gemm_split3_bn(n)) >= (int64_t)cus / 2 ||
+         (!bf16 && ((m + 127) / 128) * (int64_t)((n + 127) / 128) >= (int64_t)cus / 2))) {     // few rows: 128-row tiles (gemm_split3.hip picks them)
         const int cdesc[12] = { cv ? cv->H : 0, cv ? cv->W : 0, cv ? cv->C : 0, cv ? cv->Ho : 0, cv ? cv->Wo : 0, cv ? cv->kw : 0,
                                 cv ? cv->stride : 0, cv ? cv->pad : 0, cv ? cv->dil : 0, cv ? (int)cv->batch : 0, cv ? cv->pitch : 0, cv ? cv->padx : -1 };
         return awseg_gemm_split3_launch(x, w_split + 2 * (int64_t)n * k + 8, a.trailer, bias, residual, act, out, m, n, k, cus, awseg_s(stream),

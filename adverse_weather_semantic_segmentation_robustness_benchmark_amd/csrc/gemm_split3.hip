@@ -599,8 +599,10 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     static int half_mode = -1;
     if (half_mode < 0) { const char* e = getenv("AWSEG_G3_HALF"); half_mode = e ? atoi(e) : 1; }
     const int bn_half = img_bn >= 128 ? 128 : 64;
-    const bool half = !bf16 && (half_mode == 2 || (half_mode == 1 && (k <= 128 || (img_bn <= 128 && k <= 512)) &&
-                                                   ((m + 127) / 128) * (int64_t)((n + bn_half - 1) / bn_half) >= 4 * (int64_t)cus));
+    // ... and, whatever K, where 256-row tiles would leave CUs without a block (M = 16 384: MiT stage 4, the key / value projections)
+    const bool few = ((m + 255) / 256) * (int64_t)((n + img_bn - 1) / img_bn) < (int64_t)cus;
+    const bool half = !bf16 && (half_mode == 2 || (half_mode == 1 && (few || ((k <= 128 || (img_bn <= 128 && k <= 512)) &&
+                                                   ((m + 127) / 128) * (int64_t)((n + bn_half - 1) / bn_half) >= 4 * (int64_t)cus))));
     const int rows = half ? 128 : 256;
     const int bn = half ? bn_half : img_bn;
     const int64_t ntm = (m + rows - 1) / rows;

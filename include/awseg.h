@@ -464,10 +464,11 @@ int awseg_gemm_tune(const float* x, const float* w, const float* bias, int has_r
  * layer4, ASPP, decoder; PKG/models/model.py:349), where it runs at several times the float32-input MFMA rate.
  * awseg_gemm_split_weights writes, from w float32 [N][K], once per weight: uint16 [2][N][K] (f16 bit patterns of the high
  * parts, then of the low parts scaled by 2^11, of w * 2^-ew, where ew brings max|w| — found on the device — into
- * [2^13, 2^14)), 8 trailing uint16 holding {max|w| bits, ew, 0, 0} as uint32, and — when N % 256 == 0 and K % 8 == 0 — a
- * second, k-blocked image uint16 [N/256][ceil(K/32)][256][32 high | 32 low (unscaled)] (zeros past K) that the LDS-DMA
+ * [2^13, 2^14)), 8 trailing uint16 holding {max|w| bits, ew, 0, 0} as uint32, and — when N >= 8 and K % 8 == 0 — a
+ * second, k-blocked image uint16 [N'/T][ceil(K/32)][T][32 high | 32 low (unscaled)] (T = 256, 128 or 64 rows a tile: the
+ * largest that divides N, else 64 with N' = N rounded up and zero rows behind N; zeros past K) that the LDS-DMA
  * kernel (csrc/gemm_split3.hip) streams into LDS without a staging pass.  awseg_gemm_split_weight_halfs(n, k) = the uint16
- * the buffer must hold (2NK + 8, plus 2 N ceil32(K) with the second image).  awseg_gemm_split_bias_act: x float32 [M][K], bias float32 [N] or NULL, residual float32 [M][N] or NULL (may
+ * the buffer must hold (2NK + 8, plus 2 N' ceil32(K) with the second image): size the buffer with it, never by hand.  awseg_gemm_split_bias_act: x float32 [M][K], bias float32 [N] or NULL, residual float32 [M][N] or NULL (may
  * alias out), act 0 none / 1 ReLU, out float32 [M][N].  K % 8 == 0; x and w_split 16-byte aligned.  Operand range: any
  * finite float32.  Activations are split optimistically; a block that meets |x| >= 2^15 (2^11 in the single-accumulator
  * kernels) in its A tiles recomputes that output tile with x * 2^-e (exact) and multiplies 2^e back in the epilogue — twice

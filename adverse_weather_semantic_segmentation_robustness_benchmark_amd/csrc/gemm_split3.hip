@@ -33,7 +33,8 @@ typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int G3M_MAX = 256, G3K = 32;     // the tile has 32 WV rows (WV = 8 or 4 waves); one operand's stage: rows x 128 B
-constexpr int g3_lds(int wv) { return 4 * (32 * wv * 128) + 64; }   // two stages of two operands + sMax[2]
+// two stages of two operands + sMax[2]; the four-wave blocks pack the weight stages (64-column tiles: 48 KB a block, THREE blocks per CU)
+constexpr int g3_lds(int wv, int nt) { return 2 * (32 * wv * 128) + 2 * (wv == 8 ? 32 * wv * 128 : 32 * nt * 128) + 64; }
 constexpr float kActScale0 = 16.0f;        // optimistic-pass activation scale (gemm_split.hip: split_pair_unscaled)
 constexpr int kActExp0 = -4;
 constexpr float kSplitLimit3 = 2048.0f;
@@ -116,13 +117,14 @@ __global__ __launch_bounds__(64 * WV, 2)
 void gemm_split3_kernel(g3_args a)
 {
     static_assert(NT <= WV, "a weight stage must fit an activation stage");
-    constexpr int G3M = 32 * WV, G3_STAGE = G3M * 128, G3_A0 = 0, G3_B0 = 2 * G3_STAGE;    // A stage s at s * G3_STAGE, B stage s at 2 G3_STAGE + s * G3_STAGE
+    constexpr int G3M = 32 * WV, G3_STAGE = G3M * 128, G3_A0 = 0, G3_B0 = 2 * G3_STAGE;    // A stage s at s * G3_STAGE, B stage s at 2 G3_STAGE + s * G3_BSTAGE
+    constexpr int G3_BSTAGE = WV == 8 ? G3_STAGE : 32 * NT * 128;                          // (eight waves: the round's layout; four: the tile's own width)
     constexpr int BN = 32 * NT;
     constexpr int ROWB = BF16 ? 64 : 128;                          // bytes of a weight row in a K tile
     constexpr int NBI_ALL = BN * ROWB / 1024;                      // LDS-DMA instructions per weight K tile (1 KB each)
     constexpr int NBI = NBI_ALL >= WV ? NBI_ALL / WV : 1;          // per wave (fewer than WV in all: the first NBI_ALL waves issue one each)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned* sMax = reinterpret_cast<unsigned*>(smem + 4 * G3_STAGE);
+    unsigned* sMax = reinterpret_cast<unsigned*>(smem + 2 * G3_STAGE + 2 * G3_BSTAGE);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = lane >> 5, li = lane & 31;
     const int K = a.K, nkt = (K + G3K - 1) / G3K, kb = nkt;         // K % 32 != 0 (K % 8 == 0): the last K tile is zero-filled past K
@@ -195,7 +197,7 @@ void gemm_split3_kernel(g3_args a)
         for (int j = 0; j < 4; ++j) dma16(x_rsrc, kt == nkt - 1 ? a_voff_last[j] : a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
         }
         {
-            const uint32_t lbw = lds0 + (uint32_t)(G3_B0 + stage * G3_STAGE) + wave_u * (uint32_t)(NBI * 1024);
+            const uint32_t lbw = lds0 + (uint32_t)(G3_B0 + stage * G3_BSTAGE) + wave_u * (uint32_t)(NBI * 1024);
             if (NBI_ALL >= WV || (int)wave_u < NBI_ALL) {
 #pragma unroll
                 for (int j = 0; j < NBI; ++j) dma16(w_rsrc, b_voff[j], (uint32_t)(kt * a.img_bn * ROWB), lbw + (uint32_t)(j * 1024));
@@ -270,6 +272,7 @@ void gemm_split3_kernel(g3_args a)
             G3_T(s2);
             if (t == 0 && tid == 0) sMax[par ^ 1] = 0u;
             const unsigned char* sa = smem + st * G3_STAGE;
+            const unsigned char* sbw = smem + st * G3_BSTAGE;         // weight fragments (fb carries G3_B0)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 // The arbiter favours the older wave of a SIMD: the stamps show waves 0-3 done with a K tile after 2 400 cycles and waiting
@@ -291,9 +294,9 @@ void gemm_split3_kernel(g3_args a)
 #pragma unroll
                 for (int j = 0; j < NT; ++j) {
                     if (ABL == 5) { Bh[j] = h8{(_Float16)t, (_Float16)j, 1, 2, 3, 4, 5, 6}; Bl[j] = h8{(_Float16)ks, (_Float16)j, 1, 2, 3, 4, 5, 6}; continue; }
-                    if (BF16) { Bh[j] = *reinterpret_cast<const h8*>(sa + fb[ks][0] + j * 2048); Bl[j] = Bh[j]; continue; }
-                    Bh[j] = *reinterpret_cast<const h8*>(sa + fb[ks][0] + j * 4096);
-                    Bl[j] = *reinterpret_cast<const h8*>(sa + fb[ks][1] + j * 4096);
+                    if (BF16) { Bh[j] = *reinterpret_cast<const h8*>(sbw + fb[ks][0] + j * 2048); Bl[j] = Bh[j]; continue; }
+                    Bh[j] = *reinterpret_cast<const h8*>(sbw + fb[ks][0] + j * 4096);
+                    Bl[j] = *reinterpret_cast<const h8*>(sbw + fb[ks][1] + j * 4096);
                 }
                 u32x4 H, L; unsigned h, l;
                 if (BF16) {
@@ -611,13 +614,15 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     if (ntm8 * a.ntn > 0x7fffffff) return AWSEG_ERANGE;
     a.ntm = (int)ntm; a.ntm8 = (int)ntm8;
     const int64_t slots = ntm8 * a.ntn;
-    int64_t blocks = (int64_t)cus * (half ? 2 : 1) / 8 * 8;
+    static int three = -1;                                          // AWSEG_G3_THREE=0: two four-wave blocks per CU for the 64-column tiles too
+    if (three < 0) { const char* e = getenv("AWSEG_G3_THREE"); three = e ? atoi(e) : 1; }
+    int64_t blocks = (int64_t)cus * (half ? ((bn == 64 && three) ? 3 : 2) : 1) / 8 * 8;
     if (blocks < 8) blocks = 8;
     if (blocks > slots) blocks = slots;
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("AWSEG_G3_ABL"); abl = e ? atoi(e) : 0; }
     if (abl && !conv && !bf16 && bn == 256) {
-#define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds(8)); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(512), g3_lds(8), stream, a); break; }
+#define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds(8, 8)); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(512), g3_lds(8, 8), stream, a); break; }
         switch (abl) { G3_ABL(1) G3_ABL(2) G3_ABL(3) G3_ABL(4) G3_ABL(5) default: break; }
 #undef G3_ABL
         AWSEG_LAUNCH_CHECK();
@@ -628,11 +633,11 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
         auto kf = gemm_split3_kernel<CONV_, 0, BF_, NT_, WV_>;                                                                        \
         static bool attr = false;                                                                                                     \
         if (!attr) {                                                                                                                  \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds(WV_)); \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds(WV_, NT_)); \
             if (e != hipSuccess) return (int)e;                                                                                       \
             attr = true;                                                                                                              \
         }                                                                                                                             \
-        hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(64 * WV_), g3_lds(WV_), stream, a);                                       \
+        hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(64 * WV_), g3_lds(WV_, NT_), stream, a);                                       \
     } while (0)
 #define G3_BY_NT(CONV_, BF_) do { if (bn == 256) G3_GO(CONV_, BF_, 8, 8); else if (bn == 128) G3_GO(CONV_, BF_, 4, 8); else G3_GO(CONV_, BF_, 2, 8); } while (0)
 #define G3_HALF(CONV_) do { if (bn == 128) G3_GO(CONV_, false, 4, 4); else G3_GO(CONV_, false, 2, 4); } while (0)

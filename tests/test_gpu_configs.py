@@ -135,7 +135,7 @@ def test_c3_two_gpus_over_rccl_reproduce_the_single_gpu_miou(native):
     assert one["miou"] == two["miou"], "pooled mIoU dict differs between 1 and 2 GPUs"
 
 
-@pytest.mark.parametrize("env", [{"AWSEG_WINO8": "0"}, {"AWSEG_WINO8": "1"}, {"AWSEG_WINO8": "2"}, {"AWSEG_WINO8_TPB": "3"}, {"AWSEG_WINO8_TPB": "64"}, {"AWSEG_GEMM_SPLIT_V3": "0"}, {"AWSEG_G3_STAGGER": "0"}, {"AWSEG_G3_HALF": "0"}, {"AWSEG_G3_HALF": "2"},
+@pytest.mark.parametrize("env", [{"AWSEG_WINO8": "0"}, {"AWSEG_WINO8": "1"}, {"AWSEG_WINO8": "2"}, {"AWSEG_WINO8_TPB": "3"}, {"AWSEG_WINO8_TPB": "64"}, {"AWSEG_GEMM_SPLIT_V3": "0"}, {"AWSEG_G3_STAGGER": "0"}, {"AWSEG_G3_HALF": "0"}, {"AWSEG_G3_HALF": "2"}, {"AWSEG_G3_HALF": "2", "AWSEG_G3_THREE": "0"},
                                  {"AWSEG_ASPP_LDS": "0"}, {"AWSEG_ASPP_LDS": "0", "AWSEG_ASPP_ROWS": "0"}, {"AWSEG_STATS_WIDE": "0"}])
 def test_round2_kernels_stay_selectable_and_correct(env):
     """The earlier kernels (four-wave, alternating-role and non-persistent symmetric Winograd; register-staged split GEMM; gemm_split3 without the staggered

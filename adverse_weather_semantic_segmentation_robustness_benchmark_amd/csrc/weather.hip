@@ -76,11 +76,18 @@ __device__ __forceinline__ int reflect_101(int i, int n)
 // 4 pixels per lane: 12 B in (3 dwords), three float4 out (one per channel plane).
 __global__ __launch_bounds__(kThreads)
 void normalize_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const int32_t* __restrict__ sel,
-                      norm_consts nc, float* __restrict__ out)
+                      norm_consts nc, float* __restrict__ out, bool vec)
 {
     const int64_t img = sel ? sel[blockIdx.y] : blockIdx.y;
     const uint8_t* src = imgs + img * hw * 3;
     float* dst = out + img * hw * 3;
+    if (!vec) {
+        // any H x W the reference's transform accepts (preprocessing.py:61-92): with hw % 4 != 0 (or unaligned bases) the
+        // per-image bases are not dword / float4 aligned, so every pixel goes the scalar way — same operations, same bytes
+        for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < hw; p += (int64_t)gridDim.x * kThreads)
+            for (int c = 0; c < 3; ++c) dst[(int64_t)c * hw + p] = norm1(src[p * 3 + c], nc.mean[c], nc.std[c]);
+        return;
+    }
     const int64_t nquad = hw / 4;
     for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
         const uint32_t* p = reinterpret_cast<const uint32_t*>(src + q * 12);
@@ -94,11 +101,6 @@ void normalize_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const int32_
                                    norm1(b[6 + c], nc.mean[c], nc.std[c]), norm1(b[9 + c], nc.mean[c], nc.std[c]));
             *reinterpret_cast<float4*>(dst + (int64_t)c * hw + q * 4) = v;
         }
-    }
-    // tail pixels (hw % 4)
-    if (blockIdx.x == 0) {
-        for (int64_t p = nquad * 4 + threadIdx.x; p < hw; p += kThreads)
-            for (int c = 0; c < 3; ++c) dst[(int64_t)c * hw + p] = norm1(src[p * 3 + c], nc.mean[c], nc.std[c]);
     }
 }
 
@@ -223,7 +225,7 @@ void fog_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_f
         if (ddst) for (int k = 0; k < nvalid; ++k) ddst[p + k] = depth[k];
         if (MODE == 0) continue;
         uint8_t px[12], res[12];
-        if (nvalid == 4 && ((p * 3) & 3) == 0) {
+        if (nvalid == 4 && (((uintptr_t)(src + p * 3)) & 3) == 0) {
             const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
             uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
 #pragma unroll
@@ -244,7 +246,7 @@ void fog_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_f
             }
         }
         if (dst) {
-            if (nvalid == 4 && ((p * 3) & 3) == 0) {
+            if (nvalid == 4 && (((uintptr_t)(dst + p * 3)) & 3) == 0) {
                 uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
 #pragma unroll
                 for (int w = 0; w < 3; ++w)
@@ -294,7 +296,7 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<aw
             const int ty = q / (FTW / 4), tq = q - ty * (FTW / 4);
             const int gy = y0 + ty, gx = x0 + tq * 4;
             const int64_t p = (int64_t)gy * W + gx;
-            if (gy < H && gx + 4 <= W && (((p * 3) & 3) == 0)) {
+            if (gy < H && gx + 4 <= W && ((((uintptr_t)(src + p * 3)) & 3) == 0)) {
                 const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
                 pre[it][0] = s4[0]; pre[it][1] = s4[1]; pre[it][2] = s4[2];
             }
@@ -385,7 +387,7 @@ void fog_fast_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<aw
         const int64_t p = (int64_t)gy * W + gx;
         if (ddst) for (int k = 0; k < nvalid; ++k) ddst[p + k] = (double)depth[k];
         uint8_t px[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, res[12];
-        const bool vec = (nvalid == 4) && (((p * 3) & 3) == 0);
+        const bool vec = (nvalid == 4) && ((((uintptr_t)(src + p * 3)) & 3) == 0) && (!dst || (((uintptr_t)(dst + p * 3)) & 3) == 0);
         if (vec) {
             const uint32_t w0 = pre[it][0], w1 = pre[it][1], w2 = pre[it][2];
 #pragma unroll
@@ -603,7 +605,7 @@ template <bool PHILOX>
 __global__ __launch_bounds__(kThreads)
 void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_night_job> jobs, int job0,
                   const double* __restrict__ noise_all, float g0, float g1, float g2,
-                  uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc)
+                  uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc, bool vec)
 {
     __shared__ weather_lut L;
     lut_fill(L, nc, norm_out != nullptr);
@@ -621,8 +623,9 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_n
     for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
         const int64_t p = q * 4;
         const int nvalid = (hw - p) < 4 ? (int)(hw - p) : 4;
+        const bool v4 = nvalid == 4 && vec;                       // vec: per-image bases are dword (float4, double2) aligned
         uint8_t px[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, res[12];
-        if (nvalid == 4) {
+        if (v4) {
             const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + p * 3);
             uint32_t w0 = s4[0], w1 = s4[1], w2 = s4[2];
 #pragma unroll
@@ -646,7 +649,7 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_n
 #pragma unroll
             for (int k = 0; k < 12; ++k)
                 res[k] = (uint8_t)(int)__builtin_amdgcn_fmed3f(fmaf(nf[k], amp, (float)px[k] * kg[k % 3]), 0.f, 255.f);
-        } else if (nvalid == 4) {
+        } else if (v4) {
             const double2* n2 = reinterpret_cast<const double2*>(noise + p * 3);
 #pragma unroll
             for (int k = 0; k < 6; ++k) { double2 t = n2[k]; nz[2 * k] = t.x; nz[2 * k + 1] = t.y; }
@@ -665,7 +668,7 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_n
             }
         }
         if (dst) {
-            if (nvalid == 4) {
+            if (v4) {
                 uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
 #pragma unroll
                 for (int w = 0; w < 3; ++w)
@@ -675,7 +678,7 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_n
             }
         }
         if (ndst) {
-            if (nvalid == 4 && (hw & 3) == 0) {
+            if (v4 && (hw & 3) == 0) {
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
                     *reinterpret_cast<float4*>(ndst + (int64_t)c * hw + p) =
@@ -1223,7 +1226,7 @@ void streak_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awse
         const int nvalid = (W - gx) < 4 ? (W - gx) : 4;
         const int64_t p = (int64_t)gy * W + gx;
         if (dst) {
-            if (nvalid == 4 && ((p * 3) & 3) == 0) {
+            if (nvalid == 4 && (((uintptr_t)(dst + p * 3)) & 3) == 0) {
                 uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
 #pragma unroll
                 for (int w = 0; w < 3; ++w)
@@ -1376,7 +1379,7 @@ void streak_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pac
         for (int e = 0; e < 12; ++e) res[e] = (uint8_t)(int)(__builtin_amdgcn_fmed3f(acc[e], 0.f, 1.f) * 255.0f);   // quant_f32 with one v_med3
         const int64_t p = (int64_t)gy * W + gx;
         if (dst) {
-            if (FAST || (nvalid == 4 && ((p * 3) & 3) == 0)) {
+            if (FAST || (nvalid == 4 && (((uintptr_t)(dst + p * 3)) & 3) == 0)) {
                 uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + p * 3);
 #pragma unroll
                 for (int q = 0; q < 3; ++q)
@@ -1501,12 +1504,10 @@ AWSEG_API int awseg_normalize(const uint8_t* imgs, int64_t batch, int height, in
     const int64_t n = sel ? n_sel : batch;
     if (n < 1) return 0;
     if (n > 65535) return AWSEG_ERANGE;
-    if (((uintptr_t)imgs & 3) || ((uintptr_t)out & 15) || ((hw * 3) & 3)) {
-        if ((hw & 3) != 0) return AWSEG_EALIGN;      // the 4-pixel path needs hw % 4 == 0 for per-image bases
-    }
-    if ((hw & 3) != 0) return AWSEG_EALIGN;
-    dim3 grid(grid_for(hw / 4, n), (unsigned)n);
-    hipLaunchKernelGGL(normalize_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, sel, make_nc(mean_host, std_host), out);
+    // the 4-pixel path needs dword / float4 aligned per-image bases: hw % 4 == 0 and aligned buffers; anything else is scalar
+    const bool vec = (hw & 3) == 0 && ((uintptr_t)imgs & 3) == 0 && ((uintptr_t)out & 15) == 0;
+    dim3 grid(grid_for(vec ? hw / 4 : hw, n), (unsigned)n);
+    hipLaunchKernelGGL(normalize_kernel, grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, sel, make_nc(mean_host, std_host), out, vec);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -1624,8 +1625,10 @@ AWSEG_API int awseg_night_apply(const uint8_t* imgs, int height, int width, cons
     if (n_jobs == 0) return 0;
     if (n_jobs > 65535) return AWSEG_ERANGE;
     const int64_t hw = (int64_t)height * width;
-    if ((hw * 3) & 3) return AWSEG_EALIGN;           // per-image bases must stay 4-byte aligned
-    if (((uintptr_t)imgs & 3) || (out && ((uintptr_t)out & 3)) || (noise && ((uintptr_t)noise & 15))) return AWSEG_EALIGN;
+    // 4 pixels per lane as dwords / float4 / double2 need aligned per-image bases (hw % 4 == 0 covers all three); any other
+    // size the reference accepts (preprocessing.py:204-225 takes every H x W) takes the scalar accesses of the same kernel
+    const bool vec = (hw & 3) == 0 && ((uintptr_t)imgs & 3) == 0 && (!out || ((uintptr_t)out & 3) == 0) &&
+                     (!noise || ((uintptr_t)noise & 15) == 0) && (!norm_out || ((uintptr_t)norm_out & 15) == 0);
     norm_consts nc = make_nc(mean_host, std_host);
     for (int j0 = 0; j0 < n_jobs; j0 += kMaxJobs) {
         const int cnt = n_jobs - j0 < kMaxJobs ? n_jobs - j0 : kMaxJobs;
@@ -1633,10 +1636,10 @@ AWSEG_API int awseg_night_apply(const uint8_t* imgs, int height, int width, cons
         dim3 grid(grid_for((hw + 3) / 4, cnt), cnt);
         if (noise)
             hipLaunchKernelGGL((night_kernel<false>), grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, pk, j0, noise,
-                               gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc);
+                               gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc, vec);
         else
             hipLaunchKernelGGL((night_kernel<true>), grid, dim3(kThreads), 0, awseg_s(stream), imgs, hw, pk, j0, noise,
-                               gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc);
+                               gains_host[0], gains_host[1], gains_host[2], out, norm_out, nc, vec);
         AWSEG_LAUNCH_CHECK();
     }
     return 0;

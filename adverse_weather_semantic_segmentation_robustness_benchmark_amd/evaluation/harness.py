@@ -33,6 +33,10 @@ logger = logging.getLogger(__name__)
 
 AUROC_BINS = 1 << 13                      # per-block LDS histogram (2 x 8192 x 4 B = 64 KB)
 AUROC_LO, AUROC_HI = -1e-3, 0.70          # mutual information of two members lies in [0, ln 2]
+# The device AUROC is the rank statistic of a 2^13-bin histogram of the disagreement score (ties inside a bin count half), not
+# sklearn's exact ranks (metrics.py:434): asserted within AUROC_TOLERANCE of sklearn end to end (tests/test_gpu_models.py) —
+# 30x looser than every other gate of the path, so the results dict says how the number was made.
+AUROC_TOLERANCE = 3e-3
 
 
 def _cfg(config, key, default):
@@ -160,6 +164,8 @@ def finalize(st: EvalState, metrics: RobustnessMetrics) -> Dict[str, Any]:
             results[f"ece_{name}"] = ConfidenceCalibration.ece_from_bins(bins[1 + k])
     if st.auroc is not None:
         results["ensemble_disagreement_auroc"] = st.auroc_value()
+        results["ensemble_disagreement_auroc_bins"] = float(AUROC_BINS)             # rank histogram, not exact ranks:
+        results["ensemble_disagreement_auroc_tolerance"] = AUROC_TOLERANCE           # |device - sklearn| bound the tests assert
     if "clean" in weather_mious:
         for w in ("fog", "rain", "snow", "night"):
             if w in weather_mious:

@@ -284,7 +284,9 @@ def _stem_rows(x: torch.Tensor, conv: nn.Conv2d, w: torch.Tensor, bias: torch.Te
     skey = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
     xp = _stem_scope.get(skey) if _stem_scope is not None else None
     if xp is None:
-        key = (str(x.device), B, H, wp_any)
+        # W and C are part of the key: wp_any is the same for W = 2k-1 and 2k, and a buffer filled for the wider (or deeper) input
+        # would keep that input's last column (4th channel) where this one's zero padding belongs
+        key = (str(x.device), B, H, W, C, wp_any)
         xp = _stem_pad.get(key)
         if xp is None:
             _stem_pad.clear()                                  # one shape at a time: 270 MB at 8 x 1024 x 2048

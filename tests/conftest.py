@@ -35,7 +35,10 @@ def maxconf_flips_are_rounding_ties(got, ref, s1, s2, ulps=4.0):
     differ = (np.asarray(got) != np.asarray(ref)).any(axis=1)
     gap = np.abs(c1 - c2) / (np.maximum(c1, c2) * 2.0 ** -24)
     assert (gap[differ] <= ulps).all(), f"selection differs where the confidences are {gap[differ].max():.1f} ulp apart"
-    return int(differ.sum())
+    n = int(differ.sum())
+    # the flip count is part of the stated tolerance: printed with every use, visible under `pytest -s` / `-rP`
+    print(f"max_confidence: {n} of {differ.size} pixels select the other member (all within {ulps:g} float32 ulp of a confidence tie)")
+    return n
 
 
 @pytest.fixture(scope="session")

@@ -172,6 +172,34 @@ def test_normalize(ops, oracle):
     assert np.array_equal(out2[2].cpu().numpy(), out[2]) and out2[1].abs().sum().item() == 0
 
 
+@pytest.mark.parametrize("hw_", [(17, 23), (5, 7), (1, 1), (3, 1), (33, 2)])
+def test_normalize_and_night_ragged_sizes(ops, oracle, hw_):
+    """H*W % 4 != 0 (preprocessing.py:61-92 takes any H x W): per-image bases of a batch are then not dword aligned; the
+    kernels take their scalar accesses and still give the oracle's bytes, for every frame of a batch and with `sel`."""
+    h, w = hw_
+    rs = np.random.RandomState(h * 100 + w)
+    B = 3
+    imgs = rs.randint(0, 255, (B, h, w, 3), dtype=np.uint8)
+    out = ops.normalize(dev(imgs)).cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(out[b], oracle.normalize(imgs[b]))
+    sel = torch.tensor([2, 1], dtype=torch.int32, device="cuda")
+    out2 = torch.zeros(B, 3, h, w, device="cuda")
+    ops.normalize(dev(imgs), out=out2, sel=sel)
+    assert np.array_equal(out2[1:].cpu().numpy(), out[1:]) and out2[0].abs().sum().item() == 0
+    # night on frames 2 and 1 with host-drawn noise (parity mode), byte output + fused normalised output
+    noise = rs.normal(0, 5.0 / 255.0, (2, h, w, 3))
+    nj = ops.night_jobs([2, 1], [0.7, 0.9], [0.5, 0.8])
+    nout = dev(imgs).clone()
+    nnorm = torch.zeros(B, 3, h, w, device="cuda")
+    ops.night(dev(imgs), nj, noise=dev(noise), out=nout, norm_out=nnorm)
+    for j, b in enumerate((2, 1)):
+        ref = oracle.night(imgs[b], noise[j], (0.7, 0.9)[j], (0.5, 0.8)[j])
+        assert np.array_equal(nout[b].cpu().numpy(), ref)
+        assert np.array_equal(nnorm[b].cpu().numpy(), oracle.normalize(ref))
+    assert np.array_equal(nout[0].cpu().numpy(), imgs[0])
+
+
 def test_fog_night_depth_golden(ops, golden_weather):
     """Bit-exact uint8 (and float64 depth) against what the reference itself produced."""
     g = golden_weather
@@ -192,11 +220,11 @@ def test_fog_night_depth_golden(ops, golden_weather):
         out2 = torch.empty_like(imgs)
         ops.fog(imgs, jobs, depth=depth, out=out2)
         assert torch.equal(out, out2)
-        if (h * w * 3) % 4 == 0:
-            nj = ops.night_jobs([0], [float(g[f"night_brightness{k}"])], [float(g[f"night_intensity{k}"])])
-            nout = torch.empty_like(imgs)
-            ops.night(imgs, nj, noise=dev(g[f"night_noise{k}"][None]), out=nout)
-            assert np.array_equal(nout[0].cpu().numpy(), g[f"night{k}"])
+        # every size the reference accepts, the ragged 17 x 23 fixture included (scalar accesses when H*W % 4 != 0)
+        nj = ops.night_jobs([0], [float(g[f"night_brightness{k}"])], [float(g[f"night_intensity{k}"])])
+        nout = torch.empty_like(imgs)
+        ops.night(imgs, nj, noise=dev(g[f"night_noise{k}"][None]), out=nout)
+        assert np.array_equal(nout[0].cpu().numpy(), g[f"night{k}"])
 
 
 def test_weather_batched_and_fused_normalise(ops, oracle):
@@ -1099,6 +1127,25 @@ def test_stem_rows_gemm_matches_conv7x7(ops, cfg):
     # a shape with too few tiles is declined (None), not computed some other way
     small = torch.zeros(1, 16, 35, 4, device="cuda")
     assert ops.conv_rows_gemm_split(small, ws, bias, 1, 7, 2, 3, 14) is None
+
+
+def test_stem_pad_cache_is_keyed_on_width_and_channels(ops):
+    """fused._stem_rows keeps one zero-padded [B,H,W+pads,4] image per shape.  W = 2k and W = 2k - 1 need the same padded
+    width, so a cache keyed on the padded width alone would hand the narrower input the wider one's last column where its
+    zero padding belongs (round-3 advisor finding): run W = 2k, then W = 2k - 1 at the same B and H, against F.conv2d."""
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models import fused
+    g = torch.Generator(device="cuda").manual_seed(77)
+    conv = torch.nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(64, 3, 7, 7, device="cuda", generator=g) * 0.1)
+    fused._stem_pad.clear()
+    for W in (328, 327, 328, 326):
+        x = torch.randn(3, 3, 200, W, device="cuda", generator=g) * 2.0 + 5.0      # far from zero: a stale column would show
+        got = fused._stem_rows(x.contiguous(memory_format=torch.channels_last), conv, conv.weight)
+        assert got is not None
+        ref = torch.nn.functional.conv2d(x.double(), conv.weight.double(), None, 2, 3).permute(0, 2, 3, 1)
+        err = (got.double() - ref).abs().max().item()
+        assert err < 1e-5 * max(1.0, ref.abs().max().item()), (W, err)
 
 
 @pytest.mark.parametrize("cfg", [(2, 37, 53, 64, 128, 3, 3, 2, 1), (1, 64, 96, 32, 160, 2, 2, 2, 0), (3, 40, 40, 128, 256, 1, 1, 2, 0),

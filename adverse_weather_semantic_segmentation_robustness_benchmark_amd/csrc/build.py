@@ -36,8 +36,17 @@ def _flags():
             "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]   # inline asm: wino.hip clobbers m0 on purpose
 
 
+STAMP = PKG / "libawseg_hip.flags"       # the flags the installed .so was built with (mtimes alone miss an environment-selected -D)
+
+
+def _flag_stamp() -> str:
+    return repr((_flags(), sorted(EXTRA_FLAGS.items()), SOURCES))
+
+
 def needs_build() -> bool:
     if not LIB.exists():
+        return True
+    if not STAMP.exists() or STAMP.read_text() != _flag_stamp():
         return True
     t = LIB.stat().st_mtime
     deps = [CSRC / s for s in SOURCES] + [CSRC / "awseg_common.h", PKG.parent / "include" / "awseg.h"]
@@ -66,6 +75,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     subprocess.check_call([cc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs),
                            f"-L{rocm_lib}", "-lhipblaslt", f"-Wl,-rpath,{rocm_lib}"])     # gemm.hip: plain library GEMMs
     os.replace(tmp, LIB)
+    STAMP.write_text(_flag_stamp())
     return LIB
 
 

@@ -260,7 +260,9 @@ void gemm_split3_kernel(g3_args a)
             // vector-memory operations and the 8 LDS-DMA of this K tile are older than all of them: "at most 63 (32)
             // outstanding" means the DMA have landed, without waiting out the stores' write latency)
             G3_T(s0);
-            if (t == 0 && stores_pending) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G3_TRANSPOSED ? 32 : 63) : "memory");
+            // (per template: the epilogue issues 16 NT stores — 128 / 64 / 32 — so "all but the min(63, 16 NT) youngest" covers the DMA
+            // explicitly; with vmcnt(63) the 32-store tiles would lean on the compiler's wait for the bias loads issued behind the DMA)
+            if (t == 0 && stores_pending) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(G3_TRANSPOSED ? 32 : (16 * NT < 63 ? 16 * NT : 63)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             // (the next output tile's first K tile is issued behind the guard check.)  Issuing its eight LDS-DMA instructions keeps a

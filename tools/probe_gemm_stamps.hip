@@ -3,6 +3,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DAWSEG_GEMM_STAMP -Iinclude \
 //         -Iadverse_weather_semantic_segmentation_robustness_benchmark_amd/csrc tools/probe_gemm_stamps.hip -o /tmp/probe_gemm_stamps && /tmp/probe_gemm_stamps
 #include "gemm_split.hip"
+#include "gemm_split3.hip"      // awseg_gemm_split3_* (the dispatcher in gemm_split.hip references them)
 #include <cstdio>
 #include <vector>
 
@@ -10,7 +11,7 @@ int main()
 {
     const int64_t M = 65536; const int N = 512, K = 2048;
     float *x, *w, *o; uint16_t* ws;
-    hipMalloc(&x, M * K * 4); hipMalloc(&w, (size_t)N * K * 4); hipMalloc(&o, M * N * 4); hipMalloc(&ws, (size_t)2 * N * K * 2 + 16);   // [2][N][K] halves + the 16-byte trailer {max|w| bits, exponent}
+    hipMalloc(&x, M * K * 4); hipMalloc(&w, (size_t)N * K * 4); hipMalloc(&o, M * N * 4); hipMalloc(&ws, (size_t)awseg_gemm_split_weight_halfs(N, K) * 2);   // [2][N][K] halves + trailer + the k-blocked image: the library's own size
     std::vector<float> hx(M * K), hw((size_t)N * K);
     for (size_t i = 0; i < hx.size(); ++i) hx[i] = (float)((i * 2654435761u) % 2001) / 1000.f - 1.f;
     for (size_t i = 0; i < hw.size(); ++i) hw[i] = ((float)((i * 40503u) % 2001) / 1000.f - 1.f) * 0.05f;

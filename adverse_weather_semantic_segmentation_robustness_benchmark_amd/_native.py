@@ -57,6 +57,9 @@ SIGNATURES = {
     "awseg_dwconv3x3_upcat_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_winograd_split_weight_halfs": (c_i64, [c_i, c_i]),
     "awseg_conv3x3_winograd_split_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
+    "awseg_upconv_forms_floats": (c_i64, [c_i, c_i, c_i]),
+    "awseg_upconv_forms": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_p]),
+    "awseg_depth_head_fused": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p]),
     "awseg_im2col_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "awseg_attention_d32": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
     "awseg_attention_d32_split": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),

@@ -59,6 +59,9 @@ struct ws_args {
     int nblocks, tpb;                      // wino8p_kernel: linear block indices in all, tiles per (persistent) block
     int span;                              // wino8_kernel: spatial tiles of one XCD that run the same cout group back to back (block order)
     int64_t u_halfs;                       // halfs of U in front of the trailer {2^eu as float}
+    // MODE 2 (wino8p_kernel only): the input map is not read but GENERATED per block from the bilinear forms of
+    // awseg_upconv_forms (depthfuse.hip): forms [batch][F4 | F2] float32, fh x fw = the low-resolution grid (H = 32 fh, W = 32 fw)
+    const float* forms; int fh, fw;
 };
 
 __device__ __forceinline__ float act_apply(float v, int act) { return (act == AWSEG_ACT_RELU) ? (v > 0.f ? v : 0.f) : v; }
@@ -1502,13 +1505,31 @@ void wino8s_kernel(ws_args a)
 // the exchange buffer, and a block requests the next tile's first patch in front of its own epilogue's stores: the round trip is
 // covered by the epilogue and the next tile's index arithmetic.  Everything else is wino8s_kernel (same arithmetic, same order).
 constexpr int LDS8P_BYTES = X_BYTES + P_BYTES + 64;
+// MODE 2 — the SegFormer depth head in ONE launch (PKG/models/model.py:42-52 on the upsampled features, :219-221): the block's
+// input patch is not fetched but GENERATED.  The first 3x3 runs on a x32 bilinear upsampling, so inside one cell of that
+// upsampling its pre-activation is an exact bilinear form A + B t + C s + D t s of the local pixel coordinates (t, s); the few
+// pixels whose 3x3 window crosses a cell boundary or the image border are single columns / rows (E + F s, E' + F' t) and single
+// pixels (constants).  awseg_upconv_forms (depthfuse.hip) builds those forms once per frame at the encoder's resolution; here a
+// 16 x 16 tile lies inside ONE cell, and per chunk of 16 channels
+//   * waves 0-3 fetch the tile's coefficient set by ONE LDS-DMA instruction each (3.75 KB: the cell's form, the forms of the <= 4
+//     special rows, the <= 4 special columns and their crossings; unused / out-of-image pieces are out-of-range offsets: zeros),
+//     three chunks ahead, ring of three 4 KB slots behind the exchange buffer;
+//   * 432 threads = (patch row, 6 position groups, channel quad) evaluate relu(R + S t) for three pixels each — two FMAs for the
+//     row's R, S, one FMA + one max per value — and write the chunk's patch (same LDS image the DMA used to fill) in slot A of
+//     the chunk before;
+// so the 128-channel full-resolution map (8.6 GB written, 10.6 GB read per batch of 8 at 1024 x 2048) never exists.
+constexpr int CF_BYTES = 4096;                                         // one coefficient set: 240 pieces of 16 bytes
+constexpr int CF_F2 = 1280;                                            // byte offset of the special-column pieces inside a set
+constexpr int LDS8G_BYTES = X_BYTES + 3 * CF_BYTES + 64;
+constexpr int GEN_THREADS = 18 * 24;                                   // (patch row, position group 0-5, channel quad)
 template <int MODE, bool BF16>
 __global__ __launch_bounds__(W8T, 2)
 void wino8p_kernel(ws_args a)
 {
+    constexpr bool GEN = MODE == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* sV = smem;
-    unsigned* sMax = reinterpret_cast<unsigned*>(smem + X_BYTES + P_BYTES);      // behind the fourth patch slot (the exchange buffer covers everything below X_BYTES)
+    unsigned* sMax = reinterpret_cast<unsigned*>(smem + X_BYTES + (GEN ? 3 * CF_BYTES : P_BYTES));   // behind the fourth patch slot / the coefficient ring (the exchange buffer covers everything below X_BYTES)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hk = lane >> 5, li = lane & 31;
     const int grp = wave >> 2;                                       // 0: multiply, then transform; 1: transform, then multiply
@@ -1569,8 +1590,9 @@ void wino8p_kernel(ws_args a)
     const bool three = wave_u < P_INSTR - 16;                        // this wave issues three (else two) instructions per patch
     // patch slots 0-2 behind V as in wino8s_kernel; slot 3 — chunk 0 of every tile — behind the exchange buffer, so that the NEXT
     // tile's first patch can travel while this tile's epilogue uses everything below X_BYTES
+    // (MODE 2: the patches are generated, never prefetched across tiles: three slots, chunk c in slot c % 3)
     auto slot_off = [](int slot) { return slot < 3 ? V_BYTES + slot * P_BYTES : X_BYTES; };
-    auto pslot = [](int chunk) { return chunk == 0 ? 3 : chunk % 3; };
+    auto pslot = [](int chunk) { return GEN ? chunk % 3 : (chunk == 0 ? 3 : chunk % 3); };
     const uint32_t p_lds = __builtin_amdgcn_readfirstlane(lds_addr(smem)) + (uint32_t)wave_u * 1024u;
     auto glds_patch_of = [&](const __amdgpu_buffer_rsrc_t& rsrc, const uint32_t (&pv)[3], int chunk, int slot) {
         const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane((chunk < nchunks ? chunk : nchunks - 1) * KC * 4);
@@ -1583,10 +1605,112 @@ void wino8p_kernel(ws_args a)
     // s_waitcnt vmcnt(n + 2 | n + 3): everything but this wave's youngest n register loads and ONE patch's DMA instructions
     auto vm_wait_keep_patch_and = [&](auto NC) {
         constexpr int N = decltype(NC)::value;
-        if (three) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 2) : "memory");
+        if (GEN) {                                                   // ONE coefficient DMA per chunk, waves 0-3 only
+            if (wave_u < 4) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 1) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+        }
+        else if (three) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 3) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N + 2) : "memory");
     };
 
     auto vm_wait_keep = [&](auto NC) { constexpr int N = decltype(NC)::value; asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); };
+
+    // ---- MODE 2: coefficient sets and the patch generator (see the header of this kernel)
+    // special-pixel id along an axis of n low-resolution samples (32 n pixels): the image border pixels and the two pixels at
+    // every cell boundary (coordinates 15, 16 mod 32); -1: an interior pixel of its cell — or outside the image
+    auto sid = [](int y, int n) -> int {
+        const int nn = 32 * n, m = y & 31;
+        if (y < 0 || y >= nn) return -1;
+        if (y == 0) return 0;
+        if (y == nn - 1) return 2 * n + 1;
+        return m == 15 ? 1 + 2 * (y >> 5) : (m == 16 ? 2 + 2 * (y >> 5) : -1);
+    };
+    const int64_t f4_floats = GEN ? (int64_t)(3 * a.fh + 3) * (a.fw + 1) * 4 * a.Cin : 0;
+    const int64_t f2_floats = GEN ? (int64_t)(3 * a.fh + 3) * (2 * a.fw + 2) * 2 * a.Cin : 0;
+    uint32_t cvoff = 0x80000000u;                                   // this lane's piece of a coefficient set (waves 0-3), chunk 0
+    // piece P = 64 wave + lane of a set: P < 80: F4 [row slot 0-4][coefficient A B C D][channel quad]; 80 <= P < 240: F2 [row slot]
+    // [column slot 0-3][coefficient E F][channel quad].  Row slot 0 = the tile's cell row; 1-4 = patch rows 0, 1, 16, 17 where they are
+    // special; column slots = patch columns 0, 1, 16, 17 where they are special.  Anything else: an offset no descriptor covers (zeros).
+    auto coef_addr = [&](int tb, int tbx, int tby, __amdgpu_buffer_rsrc_t& rsrc, uint32_t& cv) {
+        rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.forms + (int64_t)tb * (f4_floats + f2_floats)), 0, (int)((f4_floats + f2_floats) * 4), 0x00020000);
+        const int P = wave * 64 + lane;
+        const int y0 = tby * 16, x0 = tbx * 16;
+        const int ky = y0 < 16 ? -1 : (y0 - 16) >> 5, kx = x0 < 16 ? -1 : (x0 - 16) >> 5;
+        const bool is4 = P < 80;
+        const int Pq = is4 ? P : P - 80;
+        const int rs = is4 ? Pq >> 4 : Pq >> 5;
+        const int rr = rs == 1 ? 0 : (rs == 2 ? 1 : (rs == 3 ? 16 : 17));
+        const int rid = sid(y0 - 1 + rr, a.fh);
+        const int rsel = rs == 0 ? ky + 1 : (rid < 0 ? -1 : a.fh + 1 + rid);
+        const int cs = (Pq >> 3) & 3;
+        const int cc = cs == 0 ? 0 : (cs == 1 ? 1 : (cs == 2 ? 16 : 17));
+        const int cid = sid(x0 - 1 + cc, a.fw);
+        const int qd = P & 3;
+        const int o4 = ((rsel * (a.fw + 1) + kx + 1) * 4 + ((Pq >> 2) & 3)) * a.Cin + qd * 4;
+        const int o2 = (int)f4_floats + ((rsel * (2 * a.fw + 2) + cid) * 2 + ((Pq >> 2) & 1)) * a.Cin + qd * 4;
+        const bool ok = wave < 4 && P < 240 && rs < 5 && rsel >= 0 && (is4 || cid >= 0);
+        cv = ok ? (uint32_t)((is4 ? o4 : o2) * 4) : 0x80000000u;
+    };
+    auto glds_coef_of = [&](const __amdgpu_buffer_rsrc_t& rsrc, uint32_t cv, int chunk) {      // set `chunk` -> ring slot chunk % 3
+        if (wave_u < 4) {
+            const uint32_t soff = (uint32_t)__builtin_amdgcn_readfirstlane(chunk * KC * 4);
+            const uint32_t base = (uint32_t)__builtin_amdgcn_readfirstlane((int)(p_lds + (uint32_t)(X_BYTES + (chunk % 3) * CF_BYTES)));
+            bufdma16(rsrc, cv, soff, base);
+        }
+    };
+    // generator thread = (patch row r, position group pg, channel quad q): positions {0, 1, 8, 9, 16, 17}[pg] (the only ones that can
+    // be special columns: patch columns 0, 2, 16, 1, 15, 17), 2 + pg and 10 + pg of the row's 18 (even columns first, as the DMA laid
+    // them out); 8 consecutive lanes write 128 contiguous bytes
+    int g_c = 0, g_e = 0, g_w0 = 0, g_w1 = 0;
+    float g_s = 0.f, g_t0 = 0.f, g_t1 = 0.f, g_t2 = 0.f;
+    bool g_sp = false;
+    auto gen_setup = [&](int tbx, int tby) {
+        const int gt = tid < GEN_THREADS ? tid : 0;
+        const int r = gt / 24, rem = gt - r * 24, pg = rem >> 2, q = rem & 3;
+        const int y0 = tby * 16, x0 = tbx * 16;
+        const int ky = y0 < 16 ? -1 : (y0 - 16) >> 5, kx = x0 < 16 ? -1 : (x0 - 16) >> 5;
+        const int y = y0 - 1 + r;
+        const bool rsp = y < 0 || y >= a.H || sid(y, a.fh) >= 0;      // outside the image: its row slot holds zeros
+        const int rslot = rsp ? (r == 0 ? 1 : (r == 1 ? 2 : (r == 16 ? 3 : 4))) : 0;
+        g_s = rsp ? 0.f : (float)(y - (16 + 32 * ky));
+        g_c = rslot * 256 + q * 16;
+        const int pos0 = pg < 2 ? pg : (pg < 4 ? 6 + pg : 12 + pg);
+        const int pc0 = pos0 < 9 ? 2 * pos0 : 2 * (pos0 - 9) + 1;
+        const int xa = x0 - 1 + pc0, xc = 16 + 32 * kx;
+        const bool edge = pc0 == 0 || pc0 == 1 || pc0 == 16 || pc0 == 17;
+        g_sp = edge && (xa < 0 || xa >= a.W || sid(xa, a.fw) >= 0);
+        const int cslot = pc0 == 0 ? 0 : (pc0 == 1 ? 1 : (pc0 == 16 ? 2 : 3));
+        g_e = CF_F2 + ((rslot * 4 + cslot) * 2) * 64 + q * 16;
+        const int pos1 = 2 + pg;                                     // columns 4 .. 14; position 10 + pg: columns 3 .. 13
+        g_t0 = (float)(xa - xc);
+        g_t1 = (float)(x0 - 1 + 2 * pos1 - xc);
+        g_t2 = (float)(x0 - 1 + 2 * (pos1 - 1) + 1 - xc);
+        g_w0 = (r * PW + pos0) * 64 + q * 16;
+        g_w1 = (r * PW + pos1) * 64 + q * 16;
+    };
+    auto gen_patch = [&](int chunk) {
+        if (tid < GEN_THREADS) {
+            const unsigned char* cs = smem + X_BYTES + (chunk % 3) * CF_BYTES;
+            const float4 fa = *reinterpret_cast<const float4*>(cs + g_c), fb = *reinterpret_cast<const float4*>(cs + g_c + 64);
+            const float4 fc = *reinterpret_cast<const float4*>(cs + g_c + 128), fd = *reinterpret_cast<const float4*>(cs + g_c + 192);
+            const float4 fe = *reinterpret_cast<const float4*>(cs + g_e), ff = *reinterpret_cast<const float4*>(cs + g_e + 64);
+            const float A[4] = {fa.x, fa.y, fa.z, fa.w}, B[4] = {fb.x, fb.y, fb.z, fb.w}, C[4] = {fc.x, fc.y, fc.z, fc.w};
+            const float D[4] = {fd.x, fd.y, fd.z, fd.w}, E[4] = {fe.x, fe.y, fe.z, fe.w}, F[4] = {ff.x, ff.y, ff.z, ff.w};
+            float R[4], S[4], v0[4], v1[4], v2[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {
+                R[ch] = __builtin_fmaf(C[ch], g_s, A[ch]);
+                S[ch] = __builtin_fmaf(D[ch], g_s, B[ch]);
+                const float vs = __builtin_fmaf(F[ch], g_s, E[ch]);
+                const float vi = __builtin_fmaf(S[ch], g_t0, R[ch]);
+                v0[ch] = __builtin_fmaxf(g_sp ? vs : vi, 0.f);
+                v1[ch] = __builtin_fmaxf(__builtin_fmaf(S[ch], g_t1, R[ch]), 0.f);
+                v2[ch] = __builtin_fmaxf(__builtin_fmaf(S[ch], g_t2, R[ch]), 0.f);
+            }
+            unsigned char* pw = smem + V_BYTES + (chunk % 3) * P_BYTES;
+            *reinterpret_cast<float4*>(pw + g_w0) = make_float4(v0[0], v0[1], v0[2], v0[3]);
+            *reinterpret_cast<float4*>(pw + g_w1) = make_float4(v1[0], v1[1], v1[2], v1[3]);
+            *reinterpret_cast<float4*>(pw + g_w1 + 8 * 64) = make_float4(v2[0], v2[1], v2[2], v2[3]);
+        }
+    };
 
     // ---- transform item: (tile, channel quad) x ONE V row per slot (the thread's half of the block picks the row)
     const int it = tid & 255;
@@ -1709,12 +1833,12 @@ void wino8p_kernel(ws_args a)
                         const int i = r0 + 2 * e;
                         f32x16 z = acc[i][m];
                         if (BF16) {
-                            if (MODE == 1) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, uh[i]), __builtin_bit_cast(bf8, vh[e][m]), z, 0, 0, 0);
+                            if (MODE != 0) z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, uh[i]), __builtin_bit_cast(bf8, vh[e][m]), z, 0, 0, 0);
                             else z = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, vh[e][m]), __builtin_bit_cast(bf8, uh[i]), z, 0, 0, 0);
                         } else {
                             const h8 va = term == 2 ? vl[e][m] : vh[e][m];
                             const h8 ua = term == 1 ? ul[i] : uh[i];
-                            if (MODE == 1) z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua, va, z, 0, 0, 0);
+                            if (MODE != 0) z = __builtin_amdgcn_mfma_f32_32x32x16_f16(ua, va, z, 0, 0, 0);
                             else z = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, ua, z, 0, 0, 0);
                         }
                         acc[i][m] = z;
@@ -1722,9 +1846,14 @@ void wino8p_kernel(ws_args a)
         };
 
         // ---- prologue: patches 0 and 1 in flight, U of chunk 0, patch 0 landed; every thread builds its row (0 | 2) of chunk 0
+        if (GEN) {
+            // coefficient sets 0-2 (a persistent block requests them before the previous tile's epilogue)
+            if (!patch0_requested) { for (int c3 = 0; c3 < 3 && c3 < nchunks; ++c3) glds_coef_of(x_rsrc, cvoff, c3); }
+        } else {
         if (!patch0_requested) glds_patch(0, 3);                     // (a persistent block requests it before the previous tile's epilogue)
-        patch0_requested = false;
         if (nchunks > 1) glds_patch(1, 1);
+        }
+        patch0_requested = false;
         u_fetch2(0, 0);
         u_fetch2(0, 1);
         asm volatile("" ::: "memory");                               // (the 128 accumulator moves go BEHIND the requests: the round trip hides them)
@@ -1734,9 +1863,10 @@ void wino8p_kernel(ws_args a)
             for (int m = 0; m < 2; ++m)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][m][r] = 0.f;
-        if (nchunks > 1) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});   // patch 0: everything but patch 1 and the U fragments behind it
-        else vm_wait_keep(awseg_int<BF16 ? 4 : 8>{});
+        if (nchunks > 1 && !GEN) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{});   // patch 0: everything but patch 1 and the U fragments behind it
+        else vm_wait_keep(awseg_int<BF16 ? 4 : 8>{});                // (MODE 2: all three coefficient sets)
         __syncthreads();                                             // (also orders sMax[0] = 0 and the previous pass's V reads)
+        if (GEN) { gen_patch(0); __syncthreads(); }
         transform(pslot(0), awseg_true{});
         __syncthreads();
 #define W8_T(v)
@@ -1750,21 +1880,25 @@ void wino8p_kernel(ws_args a)
             // wave issued, in program order, the U loads counted below and one patch's DMA instructions.
             // (no DMA past the last chunk: the two clamped re-fetches per block were 43 KB of wasted reads and a memory round trip
             // in front of the epilogue; the wait then counts the U loads only)
-            const bool dma = c + 2 < nchunks;
+            // MODE 2: coefficient set c + 3 requested (its ring slot held set c, read by the generator a chunk ago); the patch of chunk
+            // c + 1 is generated behind this slot's transform from set c + 1, which landed a chunk ago (the wait below, last chunk)
+            const bool dma = GEN ? c + 3 < nchunks : c + 2 < nchunks;
             if (grp == 0) {
                 mma2(0);
                 if (more) u_fetch2(c + 1, 0);
                 W8_T(qa);
-                if (dma) glds_patch(c + 2, (c + 2) % 3);
+                if (dma) { if (GEN) glds_coef_of(x_rsrc, cvoff, c + 3); else glds_patch(c + 2, (c + 2) % 3); }
                 W8_T(qb);
                 transform(pslot(c), awseg_false{});
+                if (GEN && more) gen_patch(c + 1);
                 W8_FINE(q0, qa, qb)
                 if (more) { if (dma) vm_wait_keep_patch_and(awseg_int<BF16 ? 4 : 8>{}); else vm_wait_keep(awseg_int<BF16 ? 4 : 8>{}); }   // U rows {1, 3} of chunk c (slot B), rows {0, 2} of chunk c + 1
             } else {
                 W8_T(qa);
-                if (dma) glds_patch(c + 2, (c + 2) % 3);
+                if (dma) { if (GEN) glds_coef_of(x_rsrc, cvoff, c + 3); else glds_patch(c + 2, (c + 2) % 3); }
                 W8_T(qb);
                 transform(pslot(c), awseg_false{});
+                if (GEN && more) gen_patch(c + 1);
                 W8_T(qc);
                 W8_FINE(qa, qb, qc)
                 mma2(0);
@@ -1799,7 +1933,7 @@ void wino8p_kernel(ws_args a)
     // ---- the tiles of this block: linear block indices blockIdx.x, + gridDim.x, ... (gridDim.x is a multiple of 8: same XCD)
     int bidx = blockIdx.x;
     bool have = decode(bidx, ng, b, bx, by, rx, ry);
-    if (have) patch_addr(b, bx, by, rx, ry, x_rsrc, pvoff);
+    if (have) { if (GEN) coef_addr(b, bx, by, x_rsrc, cvoff); else patch_addr(b, bx, by, rx, ry, x_rsrc, pvoff); }
     for (int iter = 0; iter < a.tpb; ++iter) {
         // the next tile, decoded now so that its first patch can be requested in front of this tile's epilogue
         int n_ng = 0, n_b = 0, n_bx = 0, n_by = 0, n_rx = 0, n_ry = 0;
@@ -1807,8 +1941,10 @@ void wino8p_kernel(ws_args a)
         const bool nhave = iter + 1 < a.tpb && decode(nbidx, n_ng, n_b, n_bx, n_by, n_rx, n_ry);
         __amdgpu_buffer_rsrc_t n_rsrc = x_rsrc;
         uint32_t n_pv[3] = {0x80000000u, 0x80000000u, 0x80000000u};
-        if (nhave) patch_addr(n_b, n_bx, n_by, n_rx, n_ry, n_rsrc, n_pv);
+        uint32_t n_cv = 0x80000000u;
+        if (nhave) { if (GEN) coef_addr(n_b, n_bx, n_by, n_rsrc, n_cv); else patch_addr(n_b, n_bx, n_by, n_rx, n_ry, n_rsrc, n_pv); }
         if (have) {
+        if (GEN) gen_setup(bx, by);
         n0 = ng * NB;
         u_w = (uint32_t)(__builtin_amdgcn_readfirstlane(vcol) * (int)u_p + __builtin_amdgcn_readfirstlane((n0 >> 5) + nt) * 2048);
         amax = 0.f; xs = 1.0f; sx = 0;
@@ -1950,7 +2086,11 @@ void wino8p_kernel(ws_args a)
 #pragma unroll
                 for (int o = 0; o < 2; ++o) z[o] += fmaxf(y[o][r] + shv[r], 0.f) * wv[r];
             }
-        if (nhave) { glds_patch_of(n_rsrc, n_pv, 0, 3); patch0_requested = true; }   // (shift and w2 have arrived: nothing below waits on vmcnt)
+        if (nhave) {                                                 // (shift and w2 have arrived: nothing below waits on vmcnt)
+            if (GEN) { for (int c3 = 0; c3 < 3 && c3 < nchunks; ++c3) glds_coef_of(n_rsrc, n_cv, c3); }   // the ring lies behind the exchange buffer
+            else glds_patch_of(n_rsrc, n_pv, 0, 3);
+            patch0_requested = true;
+        }
 #pragma unroll
             for (int o = 0; o < 2; ++o) z[o] += __shfl_xor(z[o], 32, 64);
             __syncthreads();                                             // every wave has read its exchange data
@@ -1975,7 +2115,7 @@ void wino8p_kernel(ws_args a)
         __syncthreads();                                             // every wave is done with the exchange buffer / the reduction scratch
         bidx = nbidx; have = nhave;
         ng = n_ng; b = n_b; bx = n_bx; by = n_by; rx = n_rx; ry = n_ry;
-        x_rsrc = n_rsrc; pvoff[0] = n_pv[0]; pvoff[1] = n_pv[1]; pvoff[2] = n_pv[2];
+        x_rsrc = n_rsrc; pvoff[0] = n_pv[0]; pvoff[1] = n_pv[1]; pvoff[2] = n_pv[2]; cvoff = n_cv;
     }
 }
 
@@ -2065,10 +2205,51 @@ int ws_entry(bool bf16, const float* x, int batch, int height, int width, int ci
     a.nbx = (ws + 2 * TB - 1) / (2 * TB); a.nby = (hs + 2 * TB - 1) / (2 * TB); a.ngroups = cout / NB; a.batch = batch;
     a.u_halfs = (int64_t)16 * cin * cout * 2;
     a.span = 1; a.nblocks = 0; a.tpb = 1;
+    a.forms = nullptr; a.fh = 0; a.fw = 0;
     if (bf16) return w2 ? launch_ws<1, true>(a, awseg_s(stream)) : launch_ws<0, true>(a, awseg_s(stream));
     return w2 ? launch_ws<1, false>(a, awseg_s(stream)) : launch_ws<0, false>(a, awseg_s(stream));
 }
+
+// MODE 2 of wino8p_kernel: always the persistent kernel (the generator lives there only)
+template <bool BF16>
+int launch_gen(ws_args a, hipStream_t s)
+{
+    const int64_t tiles = (int64_t)a.nbx * a.nby * a.batch;
+    const int64_t nblocks = ((tiles + 7) / 8) * 8;
+    if (nblocks >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
+    static int tpb_env = -1;
+    if (tpb_env < 0) { const char* e = getenv("AWSEG_WINO8_TPB"); tpb_env = e ? atoi(e) : 0; }
+    int tpb = tpb_env > 0 ? tpb_env : (int)((nblocks + 511) / 512);
+    tpb = tpb < 1 ? 1 : (tpb > 64 ? 64 : tpb);
+    a.nblocks = (int)nblocks; a.tpb = tpb;
+    const int64_t grid = ((nblocks + tpb - 1) / tpb + 7) / 8 * 8;
+    auto kp = wino8p_kernel<2, BF16>;
+    hipError_t ep = hipFuncSetAttribute(reinterpret_cast<const void*>(kp), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8G_BYTES);
+    if (ep != hipSuccess) return (int)ep;
+    hipLaunchKernelGGL(kp, dim3((unsigned)grid), dim3(W8T), LDS8G_BYTES, s, a);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
 }  // namespace
+
+AWSEG_API int awseg_depth_head_fused(const float* forms, int batch, int h, int w, int cmid, const uint16_t* u_split, int u_is_bf16,
+                                     const float* shift2, const float* w2, const float* b2, float* out, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!forms || !u_split || !shift2 || !w2 || !b2 || !out || batch < 0 || h < 1 || w < 1) return AWSEG_EINVAL;
+    if (cmid < KC || (cmid % KC)) return AWSEG_ERANGE;
+    if (((uintptr_t)forms & 15) || ((uintptr_t)u_split & 15) || ((uintptr_t)w2 & 15) || ((uintptr_t)shift2 & 15)) return AWSEG_EALIGN;
+    const int64_t per_img = awseg_upconv_forms_floats(h, w, cmid);
+    if (per_img * 4 >= (int64_t)1 << 31 || (int64_t)32 * cmid * NB * 2 >= (int64_t)1 << 31 || (int64_t)1024 * h * w >= (int64_t)1 << 31) return AWSEG_ERANGE;   // 32-bit byte offsets
+    ws_args a;
+    a.x = nullptr; a.U = u_split; a.shift = shift2; a.residual = nullptr; a.w2 = w2; a.b2 = b2; a.out = out;
+    a.H = 32 * h; a.W = 32 * w; a.Cin = cmid; a.Cout = NB; a.dil = 1; a.act = AWSEG_ACT_RELU;
+    a.nbx = a.W / (2 * TB); a.nby = a.H / (2 * TB); a.ngroups = 1; a.batch = batch;
+    a.u_halfs = (int64_t)16 * cmid * NB * 2;
+    a.span = 1; a.nblocks = 0; a.tpb = 1;
+    a.forms = forms; a.fh = h; a.fw = w;
+    return u_is_bf16 ? launch_gen<true>(a, awseg_s(stream)) : launch_gen<false>(a, awseg_s(stream));
+}
 
 AWSEG_API int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
                                                 const uint16_t* u_split, const float* shift, const float* residual, int act,

@@ -109,8 +109,27 @@ class DepthEstimationHead(nn.Module):
         the first 3x3: that conv goes through the same linearity trick as the seg head (HIP), the
         rest (3x3 on the hidden map, 1x1, sigmoid) stays on MIOpen."""
         h = self.depth_head
+        Bq, hq, wq, _ = feats.shape
+        head64 = fused._is_winograd(h[4]) and h[4].out_channels == 64 and h[7].kernel_size == (1, 1) and h[7].out_channels == 1
+        if (ops.DEPTH_FUSED and head64 and height == 32 * hq and width == 32 * wq and h[0].kernel_size == (3, 3) and h[0].padding == (1, 1)
+                and (ops.PRECISION == "bf16" or ops.WINO_SPLIT) and feats.is_cuda):
+            # ONE full-resolution launch: the first 3x3 on the x32 upsampling is a bilinear form per upsampling cell (built at the
+            # encoder's resolution), evaluated tile by tile inside the second 3x3's Winograd kernel — no hidden map in HBM
+            g9, shift = _head_g9(feats, h[0], h[1])
+            forms = ops.upconv_forms(g9, shift)
+            bf = ops.PRECISION == "bf16"
+            conv, bn = h[4], h[5]
+            if bf:
+                def build():
+                    sc, sh = _fold_conv_bn(conv, bn)
+                    return ops.winograd_bf16_weights(conv.weight, sc), sh
+                us, sh2 = fused.cached(conv, "wino_bf16", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+            else:
+                us, sh2 = fused.winograd_split_conv_bn(conv, bn)
+            d = ops.depth_head_fused(forms, hq, wq, h[0].out_channels, us, sh2, h[7].weight.view(-1), h[7].bias, bf16=bf)
+            return d.unsqueeze(1)
         mid = upconv3x3_bn_relu(feats, h[0], h[1], height, width)            # [B,hidden,H,W], channels_last memory
-        if fused._is_winograd(h[4]) and h[4].out_channels == 64 and h[7].kernel_size == (1, 1):
+        if head64:
             # Conv3x3 -> BN -> ReLU -> Conv1x1 -> Sigmoid in one Winograd/MFMA launch (no 64-channel map in HBM)
             d = fused.conv3x3_winograd_bn(fused.nhwc_view(mid), h[4], h[5], w2=h[7].weight.view(-1), b2=h[7].bias)
             return d.unsqueeze(1)

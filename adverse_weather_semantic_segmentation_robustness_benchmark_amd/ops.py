@@ -579,6 +579,36 @@ def conv3x3_winograd_split(x: torch.Tensor, u_split: torch.Tensor, cout: int, sh
     return out
 
 
+DEPTH_FUSED = os.environ.get("AWSEG_DEPTH_FUSED", "1") != "0"    # the SegFormer depth head as one full-resolution launch (depthfuse.hip)
+
+
+def upconv_forms(g9: torch.Tensor, shift: torch.Tensor) -> torch.Tensor:
+    """The bilinear forms of relu(shift + conv3x3(interpolate_x32(f))) per frame (csrc/depthfuse.hip): float32 [B, F4 | F2] from
+    g9 float32 [B,h,w,9,Cmid] (the per-tap products at the encoder's resolution, BatchNorm scale folded) and the folded shift."""
+    g9 = g9.contiguous()
+    b, h, w, nine, cmid = g9.shape
+    assert nine == 9
+    per = N.lib().awseg_upconv_forms_floats(h, w, cmid)
+    forms = torch.empty(b, per, dtype=torch.float32, device=g9.device)
+    N.call("awseg_upconv_forms", N.ptr(g9), b, cmid, h, w, N.ptr(shift.contiguous()), N.ptr(forms), N.stream())
+    return forms
+
+
+def depth_head_fused(forms: torch.Tensor, h: int, w: int, cmid: int, u_image: torch.Tensor, shift2: torch.Tensor, w2: torch.Tensor,
+                     b2: torch.Tensor, bf16: bool = False) -> torch.Tensor:
+    """sigmoid(conv1x1(relu(bn(conv3x3(relu(bn(conv3x3(interpolate(f)))))))) at [B, 32h, 32w] in ONE launch from the forms of
+    upconv_forms: the hidden map between the two 3x3 convolutions is generated tile by tile inside the Winograd kernel.
+    u_image = winograd_split_weights / winograd_bf16_weights of the SECOND 3x3 (Cmid -> 64)."""
+    b = forms.shape[0]
+    need = N.lib().awseg_winograd_split_weight_halfs(cmid, 64)
+    if need < 0 or u_image.numel() != need + 8 or forms.shape[1] != N.lib().awseg_upconv_forms_floats(h, w, cmid):
+        raise N.AwsegError(f"depth_head_fused: operands do not match h {h}, w {w}, Cmid {cmid}")
+    out = torch.empty(b, 32 * h, 32 * w, dtype=torch.float32, device=forms.device)
+    N.call("awseg_depth_head_fused", N.ptr(forms), b, h, w, cmid, N.ptr(u_image), int(bf16), N.ptr(shift2.contiguous()),
+           N.ptr(w2.contiguous()), N.ptr(b2.contiguous()), N.ptr(out), N.stream())
+    return out
+
+
 GEMM_WORKSPACE_BYTES = 32 << 20
 GEMM_TUNE = os.environ.get("AWSEG_GEMM_TUNE", "0") != "0"      # opt-in: time hipBLASLt's candidates once per new problem shape
 # (measured on the bench step: 102.0 vs 101.8 images/s — the library's first-ranked algorithm is already the fastest here)

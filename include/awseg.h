@@ -495,6 +495,23 @@ int awseg_dwconv3x3_upcat_nhwc(const float* a, int a_height, int a_width, int a_
  * in front of the trailer.  Cin % 16 == 0, Cout % 64 == 0.  Operand range: any finite float32 activations — a block whose
  * patch maximum is >= 2^13 or < 2^-4 redoes its tile with power-of-two scaled activations. */
 int64_t awseg_winograd_split_weight_halfs(int cin, int cout);
+
+/* awseg_upconv_forms / awseg_depth_head_fused: DepthEstimationHead on the SegFormer branch (PKG/models/model.py:42-52 applied to
+ * F.interpolate(features, (H, W), bilinear, align_corners=False), :211, :219-221) for H = 32 h, W = 32 w in ONE full-resolution
+ * launch — the hidden map between its two 3x3 convolutions (Cmid channels at H x W: 8.6 GB per batch of 8 at 1024 x 2048) is never
+ * written.  Inside one cell of the x32 upsampling the first convolution's pre-activation is an exact bilinear form of the pixel
+ * coordinates; awseg_upconv_forms builds those forms per frame at the encoder's resolution from g9 float32 [B,h,w,9,Cmid] (the
+ * per-tap products (W_tap * bn_scale) . f, the operand of awseg_upconv3x3_bn_relu) and the folded BatchNorm shift [Cmid]:
+ *   forms float32 [B][ F4 [3h+3][w+1][4][Cmid] | F2 [3h+3][2w+2][2][Cmid] ]   (awseg_upconv_forms_floats(h, w, cmid) per frame;
+ * row selector = cell row ky + 1, then h + 1 + special row id; special ids: 0 -> pixel 0, 1 + 2k -> 15 + 32k, 2 + 2k -> 16 + 32k,
+ * 2n + 1 -> 32n - 1: csrc/depthfuse.hip).  awseg_depth_head_fused evaluates them per 16 x 16 tile inside the Winograd kernel of
+ * awseg_conv3x3_winograd_split_nhwc / _bf16_nhwc (u_split / u_is_bf16: that operator's weight image of the SECOND 3x3, Cmid ->
+ * 64, BatchNorm scale folded; shift2 its folded shift [64]) and finishes with ReLU -> Conv1x1 (w2 [64], b2 [1]) -> sigmoid:
+ * out float32 [B,H,W].  Cmid % 16 == 0; forms, u_split, shift2, w2 16-byte aligned.  AWSEG_ERANGE: sizes beyond 32-bit offsets. */
+int64_t awseg_upconv_forms_floats(int h, int w, int cmid);
+int awseg_upconv_forms(const float* g9, int batch, int cmid, int h, int w, const float* shift, float* forms, awseg_stream_t stream);
+int awseg_depth_head_fused(const float* forms, int batch, int h, int w, int cmid, const uint16_t* u_split, int u_is_bf16,
+                           const float* shift2, const float* w2, const float* b2, float* out, awseg_stream_t stream);
 int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int width, int cin, int cout, int dilation,
                                       const uint16_t* u_split, const float* shift, const float* residual, int act,
                                       const float* w2, const float* b2, float* out, awseg_stream_t stream);

@@ -1344,3 +1344,80 @@ def test_upconv3x3_train_forward_and_adjoint_vs_torch_autograd(ops, case):
     e = {"z": rel(z, ref), "d features": rel(tok.grad.permute(0, 3, 1, 2), f64.grad), "d filters": rel(w1.grad, w64.grad), "d bias": rel(b1.grad, b64.grad)}
     print(f"upconv3x3 train {case}: " + ", ".join(f"{k} {v:.2e}" for k, v in e.items()))
     assert z.shape == (B, cmid, H, W) and all(v < 2e-5 for v in e.values()), e
+
+
+# ------------------------------------------------------------------ the SegFormer depth head as ONE launch (depthfuse.hip)
+@pytest.mark.parametrize("hwc", [(1, 1, 16), (1, 2, 32), (2, 3, 128), (3, 2, 48)])
+def test_upconv_forms_table_matches_float64_restatement(ops, hwc):
+    """awseg_upconv_forms against tests/forms_ref.py (the float64 derivation of the bilinear forms, itself checked against
+    interpolate -> conv2d to 1e-14 on the CPU): every entry of F4 / F2, borders and half cells included."""
+    from tests import forms_ref
+    h, w, C = hwc
+    rs = np.random.RandomState(h * 100 + w * 10 + C)
+    G = rs.randn(2, h, w, 9, C)
+    shift = rs.randn(C)
+    forms = ops.upconv_forms(dev(G, torch.float32), dev(shift, torch.float32)).cpu().numpy().astype(np.float64)
+    for b in range(2):
+        F4, F2 = forms_ref.build_tables(G[b].astype(np.float32).astype(np.float64), shift.astype(np.float32).astype(np.float64))
+        ref = np.concatenate([F4.reshape(-1), F2.reshape(-1)])
+        assert forms[b].shape == ref.shape
+        err = np.abs(forms[b] - ref).max()
+        assert err < 2e-6 * max(1.0, np.abs(ref).max()), err          # float64 sums rounded once to float32
+
+
+@pytest.mark.parametrize("cfg", [(1, 1, 1, 128), (2, 1, 2, 128), (2, 2, 3, 128), (1, 3, 2, 64), (2, 4, 5, 128)])
+def test_depth_head_fused_matches_as_written_module(ops, cfg):
+    """DepthEstimationHead.forward_from_lowres — ONE full-resolution launch, hidden map generated inside the Winograd kernel —
+    against the as-written module on F.interpolate(features) in float64 (PKG/models/model.py:16-78, :211, :219-221): every
+    cell / border class (h or w = 1: half cells only), non-trivial BatchNorm statistics; and against the two-launch path
+    (awseg_upconv3x3_bn_relu + Winograd).  1e-4 abs is north_star's gate; measured ~1e-6."""
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import DepthEstimationHead
+    B, h, w, hidden = cfg
+    torch.manual_seed(B * 1000 + h * 100 + w * 10)
+    head = DepthEstimationHead(in_channels=256, hidden_channels=hidden).eval()
+    with torch.no_grad():
+        for m in head.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.7, 1.3); m.bias.normal_(0, 0.3)
+            if isinstance(m, torch.nn.Conv2d) and m.bias is not None:
+                m.bias.normal_(0, 0.2)
+    feats = torch.randn(B, h, w, 256)
+    ref_mod = DepthEstimationHead(in_channels=256, hidden_channels=hidden).eval().double()
+    ref_mod.load_state_dict(head.state_dict())
+    with torch.no_grad():
+        up = torch.nn.functional.interpolate(feats.permute(0, 3, 1, 2).double(), size=(32 * h, 32 * w), mode="bilinear", align_corners=False)
+        ref = ref_mod(up).numpy()
+    head = head.cuda()
+    saved = ops.DEPTH_FUSED
+    try:
+        with torch.no_grad():
+            ops.DEPTH_FUSED = True
+            got = head.forward_from_lowres(feats.cuda(), 32 * h, 32 * w).cpu().numpy()
+            ops.DEPTH_FUSED = False
+            two = head.forward_from_lowres(feats.cuda(), 32 * h, 32 * w).cpu().numpy()
+    finally:
+        ops.DEPTH_FUSED = saved
+    e_f, e_2 = np.abs(got - ref).max(), np.abs(two - ref).max()
+    print(f"depth head fused {cfg}: |err| one launch {e_f:.2e}, two launches {e_2:.2e}, between them {np.abs(got - two).max():.2e}")
+    assert got.shape == ref.shape
+    assert e_f <= 1e-5 and e_2 <= 1e-5
+
+
+def test_depth_head_fused_range_guard(ops):
+    """The generated patch goes through the same operand-range guard as a fetched one: hidden activations of 3e4 (the block reruns
+    its tile scaled) and of 1e-3 — against float64."""
+    from adverse_weather_semantic_segmentation_robustness_benchmark_amd.models.model import DepthEstimationHead
+    torch.manual_seed(5)
+    for gain in (3e4, 1e-3):
+        head = DepthEstimationHead(in_channels=256, hidden_channels=128).eval()
+        with torch.no_grad():
+            head.depth_head[0].weight.mul_(gain)
+            head.depth_head[4].weight.mul_(1.0 / gain)
+        feats = torch.randn(1, 2, 2, 256)
+        ref_mod = DepthEstimationHead(in_channels=256, hidden_channels=128).eval().double()
+        ref_mod.load_state_dict(head.state_dict())
+        with torch.no_grad():
+            up = torch.nn.functional.interpolate(feats.permute(0, 3, 1, 2).double(), size=(64, 64), mode="bilinear", align_corners=False)
+            ref = ref_mod(up).numpy()
+            got = head.cuda().forward_from_lowres(feats.cuda(), 64, 64).cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-5, (gain, np.abs(got - ref).max())

@@ -111,6 +111,14 @@ def main():
     g9d = torch.randn(B, h, w, 9, 128, device=dev)
     cases["upconv3x3_bn_relu 128ch NHWC (512 B/px written)"] = (lambda: ops.upconv3x3_bn_relu(g9d, None, sf[:128].contiguous(), H, W, True),
                                                                 "hbm", 128 * 4 * px * B)
+    # the depth head as ONE launch: forms at the encoder's resolution, then the Winograd kernel with the patch generator (no hidden map)
+    if H == 32 * h and W == 32 * w:
+        fm = ops.upconv_forms(g9d, sf[:128].contiguous())
+        usd = ops.winograd_split_weights(torch.randn(64, 128, 3, 3, device=dev) * 0.05)
+        sh64, w64, b1 = torch.randn(64, device=dev), torch.randn(64, device=dev), torch.zeros(1, device=dev)
+        cases["upconv_forms 128ch (tables at 1/32)"] = (lambda: ops.upconv_forms(g9d, sf[:128].contiguous()), "hbm", 4.0 * (g9d.numel() + fm.numel()))
+        cases["depth_head_fused 128->64 +1x1+sigmoid @full, patch generated [split f16x3, issued flops]"] = (
+            lambda: ops.depth_head_fused(fm, h, w, 128, usd, sh64, w64, b1), "mfma_f16", 3 * 2.0 * 16 * 128 * 64 * B * (H // 2) * (W // 2))
     xa = torch.randn(B, H // 16, W // 16, 2048, device=dev); wdw = torch.randn(3, 9, 2048, device=dev)
     cases["aspp_depthwise3"] = (lambda: ops.aspp_depthwise3(xa, wdw, (12, 24, 36)), "hbm", 4 * 2048 * 4 * (H // 16) * (W // 16) * B)
     xd = torch.randn(B, H // 4, W // 4, 128, device=dev); w9 = torch.randn(9, 128, device=dev); bb = torch.randn(128, device=dev)

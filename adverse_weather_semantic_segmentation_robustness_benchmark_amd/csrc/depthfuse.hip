@@ -19,7 +19,7 @@
 //     F2 [row selector]          [special column id 0 .. 2w+1][E F][C]
 // special ids along an axis of n samples: 0 -> pixel 0, 1 + 2k -> 15 + 32 k, 2 + 2k -> 16 + 32 k, 2n + 1 -> 32 n - 1.  Special rows
 // store (E', F', 0, 0) / (const, 0), so one evaluation R = A + C s, S = B + D s, value = R + S t (or E + F s) serves every pixel.
-// The folded BatchNorm shift is part of A / E / the constants.  Sums in float64, rounded once.
+// The folded BatchNorm shift is part of A / E / the constants.  Sums in float64 (the row-tap partial sums pass through float32 once).
 #include "awseg_common.h"
 
 namespace {
@@ -51,47 +51,61 @@ __device__ __forceinline__ int special_coord(int id, int n)
     return (id & 1) ? 15 + 32 * ((id - 1) >> 1) : 16 + 32 * ((id - 2) >> 1);
 }
 
+// One block = (frame, row selector, slice of CB channels).  The sum over the taps is separable: first the three row taps are
+// contracted for every (column tap dx, low-resolution column jx) — H[dx][jx] = const + slope * s, six loads of g9 each — into LDS,
+// then every column descriptor combines six H entries.  (A thread per table entry reading its 36 operands itself moved 2.9 GB
+// through L2 per batch of 8 and took 0.47 ms; this form reads 0.5 GB.)
+constexpr int FCB = 32;
 __global__ __launch_bounds__(256)
 void upconv_forms_kernel(const float* __restrict__ g9, int h, int w, int C, const float* __restrict__ shift, float* __restrict__ forms,
                          int64_t img_floats, int64_t f4_floats)
 {
-    const int b = blockIdx.z, rs = blockIdx.y;
-    const int cd = blockIdx.x * blockDim.y + threadIdx.y;           // column descriptor: cells 0 .. w, then special columns
-    if (cd >= 3 * w + 3) return;
-    tap1d ry[3], rx[3];
+    extern __shared__ float sH[];                                    // [3 dx][w][const | slope][FCB]
+    const int b = blockIdx.z, rs = blockIdx.y, c0 = blockIdx.x * FCB;
+    const int tid = threadIdx.x;
+    tap1d ry[3];
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-        ry[d] = rs <= h ? tap_free(rs - 1, d - 1, h) : tap_fixed(special_coord(rs - (h + 1), h), d - 1, h);
-        rx[d] = cd <= w ? tap_free(cd - 1, d - 1, w) : tap_fixed(special_coord(cd - (w + 1), w), d - 1, w);
-    }
+    for (int d = 0; d < 3; ++d) ry[d] = rs <= h ? tap_free(rs - 1, d - 1, h) : tap_fixed(special_coord(rs - (h + 1), h), d - 1, h);
     const float* G = g9 + (int64_t)b * h * w * 9 * C;
     float* F = forms + (int64_t)b * img_floats;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        double k0 = (double)shift[c], kt = 0.0, ks = 0.0, kts = 0.0;
+    for (int item = tid; item < 3 * w * FCB; item += 256) {
+        const int c = item % FCB, jx = (item / FCB) % w, dx = item / (FCB * w);
+        double hc = 0.0, hs = 0.0;
+        if (c0 + c < C) {
 #pragma unroll
-        for (int iy = 0; iy < 3; ++iy) {
-            if (!ry[iy].ok) continue;
-#pragma unroll
-            for (int ix = 0; ix < 3; ++ix) {
-                if (!rx[ix].ok) continue;
-                const int tap = iy * 3 + ix;
-                const double g00 = G[(((int64_t)ry[iy].i0 * w + rx[ix].i0) * 9 + tap) * C + c];
-                const double g01 = G[(((int64_t)ry[iy].i0 * w + rx[ix].i1) * 9 + tap) * C + c];
-                const double g10 = G[(((int64_t)ry[iy].i1 * w + rx[ix].i0) * 9 + tap) * C + c];
-                const double g11 = G[(((int64_t)ry[iy].i1 * w + rx[ix].i1) * 9 + tap) * C + c];
-                const double gx = g01 - g00, gy = g10 - g00, gxy = g00 - g01 - g10 + g11;
-                const double px = rx[ix].p, qx = rx[ix].q, py = ry[iy].p, qy = ry[iy].q;
-                k0 += g00 + gx * px + gy * py + gxy * px * py;
-                kt += gx * qx + gxy * qx * py;
-                ks += gy * qy + gxy * px * qy;
-                kts += gxy * qx * qy;
+            for (int iy = 0; iy < 3; ++iy) {
+                if (!ry[iy].ok) continue;
+                const int tap = iy * 3 + dx;
+                const double g0 = G[(((int64_t)ry[iy].i0 * w + jx) * 9 + tap) * C + c0 + c];
+                const double g1 = G[(((int64_t)ry[iy].i1 * w + jx) * 9 + tap) * C + c0 + c];
+                hc += g0 * (1.0 - ry[iy].p) + g1 * ry[iy].p;
+                hs += (g1 - g0) * ry[iy].q;
             }
         }
+        sH[((dx * w + jx) * 2 + 0) * FCB + c] = (float)hc;
+        sH[((dx * w + jx) * 2 + 1) * FCB + c] = (float)hs;
+    }
+    __syncthreads();
+    for (int item = tid; item < (3 * w + 3) * FCB; item += 256) {
+        const int c = item % FCB, cd = item / FCB;                   // column descriptor: cells 0 .. w, then special columns
+        if (c0 + c >= C) continue;
+        double k0 = (double)shift[c0 + c], kt = 0.0, ks = 0.0, kts = 0.0;
+#pragma unroll
+        for (int ix = 0; ix < 3; ++ix) {
+            const tap1d rx = cd <= w ? tap_free(cd - 1, ix - 1, w) : tap_fixed(special_coord(cd - (w + 1), w), ix - 1, w);
+            if (!rx.ok) continue;
+            const double h0c = sH[((ix * w + rx.i0) * 2 + 0) * FCB + c], h0s = sH[((ix * w + rx.i0) * 2 + 1) * FCB + c];
+            const double h1c = sH[((ix * w + rx.i1) * 2 + 0) * FCB + c], h1s = sH[((ix * w + rx.i1) * 2 + 1) * FCB + c];
+            k0 += h0c * (1.0 - rx.p) + h1c * rx.p;
+            kt += (h1c - h0c) * rx.q;
+            ks += h0s * (1.0 - rx.p) + h1s * rx.p;
+            kts += (h1s - h0s) * rx.q;
+        }
         if (cd <= w) {
-            float* o = F + (((int64_t)rs * (w + 1) + cd) * 4) * C + c;
+            float* o = F + (((int64_t)rs * (w + 1) + cd) * 4) * C + c0 + c;
             o[0] = (float)k0; o[C] = (float)kt; o[2 * (int64_t)C] = (float)ks; o[3 * (int64_t)C] = (float)kts;
         } else {
-            float* o = F + f4_floats + (((int64_t)rs * (2 * w + 2) + (cd - (w + 1))) * 2) * C + c;
+            float* o = F + f4_floats + (((int64_t)rs * (2 * w + 2) + (cd - (w + 1))) * 2) * C + c0 + c;
             o[0] = (float)k0; o[C] = (float)ks;                      // (a fixed column has no t terms)
         }
     }
@@ -111,9 +125,10 @@ AWSEG_API int awseg_upconv_forms(const float* g9, int batch, int cmid, int h, in
     if (!g9 || !shift || !forms || batch < 0 || h < 1 || w < 1 || cmid < 1) return AWSEG_EINVAL;
     if (batch > 65535 || 3 * h + 3 > 65535) return AWSEG_ERANGE;
     const int64_t f4 = (int64_t)(3 * h + 3) * (w + 1) * 4 * cmid;
-    const int tx = cmid >= 128 ? 128 : (cmid >= 64 ? 64 : 32), ty = 256 / tx;
-    dim3 grid((3 * w + 3 + ty - 1) / ty, 3 * h + 3, batch);
-    hipLaunchKernelGGL(upconv_forms_kernel, grid, dim3(tx, ty), 0, awseg_s(stream), g9, h, w, cmid, shift, forms,
+    const size_t lds = (size_t)3 * w * 2 * FCB * sizeof(float);
+    if (lds > 64 * 1024) return AWSEG_ERANGE;                       // w <= 85 (a 2720-pixel-wide frame); wider: the two-launch path
+    dim3 grid((cmid + FCB - 1) / FCB, 3 * h + 3, batch);
+    hipLaunchKernelGGL(upconv_forms_kernel, grid, dim3(256), lds, awseg_s(stream), g9, h, w, cmid, shift, forms,
                        awseg_upconv_forms_floats(h, w, cmid), f4);
     AWSEG_LAUNCH_CHECK();
     return 0;

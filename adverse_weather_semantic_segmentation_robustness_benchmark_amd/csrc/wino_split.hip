@@ -1660,7 +1660,7 @@ void wino8p_kernel(ws_args a)
     // be special columns: patch columns 0, 2, 16, 1, 15, 17), 2 + pg and 10 + pg of the row's 18 (even columns first, as the DMA laid
     // them out); 8 consecutive lanes write 128 contiguous bytes
     int g_c = 0, g_e = 0, g_w0 = 0, g_w1 = 0;
-    float g_s = 0.f, g_t0 = 0.f, g_t1 = 0.f, g_t2 = 0.f;
+    float g_s = 0.f, g_t0 = 0.f, g_t1 = 0.f;                        // (the third pixel is the second one's left neighbour: t1 - 1)
     bool g_sp = false;
     auto gen_setup = [&](int tbx, int tby) {
         const int gt = tid < GEN_THREADS ? tid : 0;
@@ -1682,7 +1682,6 @@ void wino8p_kernel(ws_args a)
         const int pos1 = 2 + pg;                                     // columns 4 .. 14; position 10 + pg: columns 3 .. 13
         g_t0 = (float)(xa - xc);
         g_t1 = (float)(x0 - 1 + 2 * pos1 - xc);
-        g_t2 = (float)(x0 - 1 + 2 * (pos1 - 1) + 1 - xc);
         g_w0 = (r * PW + pos0) * 64 + q * 16;
         g_w1 = (r * PW + pos1) * 64 + q * 16;
     };
@@ -1702,8 +1701,9 @@ void wino8p_kernel(ws_args a)
                 const float vs = __builtin_fmaf(F[ch], g_s, E[ch]);
                 const float vi = __builtin_fmaf(S[ch], g_t0, R[ch]);
                 v0[ch] = __builtin_fmaxf(g_sp ? vs : vi, 0.f);
-                v1[ch] = __builtin_fmaxf(__builtin_fmaf(S[ch], g_t1, R[ch]), 0.f);
-                v2[ch] = __builtin_fmaxf(__builtin_fmaf(S[ch], g_t2, R[ch]), 0.f);
+                const float p1 = __builtin_fmaf(S[ch], g_t1, R[ch]);
+                v1[ch] = __builtin_fmaxf(p1, 0.f);
+                v2[ch] = __builtin_fmaxf(__builtin_fmaf(S[ch], g_t1 - 1.0f, R[ch]), 0.f);
             }
             unsigned char* pw = smem + V_BYTES + (chunk % 3) * P_BYTES;
             *reinterpret_cast<float4*>(pw + g_w0) = make_float4(v0[0], v0[1], v0[2], v0[3]);

@@ -306,16 +306,19 @@ def resnet_features(enc, x: torch.Tensor, stem_feature: bool = False) -> List[to
     The DeepLabV3+ decoder never reads the stride-2 stem feature, so by default it is not produced (None in the
     list) and the stem's `+shift -> ReLU` runs AFTER the max-pool, on a quarter of the pixels: both are monotone
     per channel, so maxpool(relu(x + b)) == relu(maxpool(x) + b) bit for bit."""
-    x = x.contiguous(memory_format=CL)
     feats = [x]
     if stem_feature:
+        x = x.contiguous(memory_format=CL)
+        feats = [x]
         y = conv_bn_act(x, enc.conv1, enc.bn1, N.ACT_RELU)
         feats.append(y)
         y = enc.maxpool(y)
     else:
         w, shift = folded_conv_bn(enc.conv1, enc.bn1)
+        # the stem reads the input as it comes (NCHW from the weather kernels): ONE strided copy into the zero-padded image both
+        # members share — no channels_last copy of the frames per member (two of them plus a second padded fill were 0.23 ms a step)
         y = _stem_rows(x, enc.conv1, w)
-        y = y.permute(0, 3, 1, 2) if y is not None else F.conv2d(x, w, None, enc.conv1.stride, enc.conv1.padding)
+        y = y.permute(0, 3, 1, 2) if y is not None else F.conv2d(x.contiguous(memory_format=CL), w, None, enc.conv1.stride, enc.conv1.padding)
         mp = enc.maxpool
         if (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous(memory_format=CL) and y.shape[1] % 4 == 0
                 and _pair(mp.kernel_size) == (3, 3) and _pair(mp.stride) == (2, 2) and _pair(mp.padding) == (1, 1)
@@ -391,7 +394,7 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
     if not hasattr(seg, "stages"):
         # other transformers versions name their sub-modules differently: use their own forward
         return seg(x).last_hidden_state.permute(0, 2, 3, 1).contiguous()
-    t = x.contiguous(memory_format=CL)
+    t = x                                                            # (the first stage's stem takes any layout; later stages: channels_last views)
     tok = None
     for st in seg.stages:
         pe = st.patch_embeddings
@@ -402,7 +405,7 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
             y = _stem_rows(t, pe.proj, pe.proj.weight, pe.proj.bias) if pe.proj.bias is not None else None
             if y is None:
                 w = cached(pe.proj, "wcl", [pe.proj.weight], lambda: pe.proj.weight.contiguous(memory_format=CL))
-                y = nhwc_view(F.conv2d(t, w, pe.proj.bias, pe.proj.stride, pe.proj.padding))
+                y = nhwc_view(F.conv2d(t.contiguous(memory_format=CL), w, pe.proj.bias, pe.proj.stride, pe.proj.padding))
         tok = _ln(y, pe.layer_norm)                                          # [B,H,W,C]
         B, H, W, C = tok.shape
         for blk in st.blocks:

@@ -112,7 +112,7 @@ class DepthEstimationHead(nn.Module):
         Bq, hq, wq, _ = feats.shape
         head64 = fused._is_winograd(h[4]) and h[4].out_channels == 64 and h[7].kernel_size == (1, 1) and h[7].out_channels == 1
         if (ops.DEPTH_FUSED and head64 and height == 32 * hq and width == 32 * wq and h[0].kernel_size == (3, 3) and h[0].padding == (1, 1)
-                and (ops.PRECISION == "bf16" or ops.WINO_SPLIT) and feats.is_cuda):
+                and (ops.PRECISION == "bf16" or ops.WINO_SPLIT) and feats.is_cuda and wq <= 85):       # (wider: the forms kernel's LDS rows)
             # ONE full-resolution launch: the first 3x3 on the x32 upsampling is a bilinear form per upsampling cell (built at the
             # encoder's resolution), evaluated tile by tile inside the second 3x3's Winograd kernel — no hidden map in HBM
             g9, shift = _head_g9(feats, h[0], h[1])
@@ -160,10 +160,17 @@ def _head_g9(tok: torch.Tensor, conv: nn.Conv2d, bn: nn.BatchNorm2d):
     def build():
         scale, shift = _fold_conv_bn(conv, bn)
         w1r = (conv.weight * scale.view(-1, 1, 1, 1)).permute(1, 2, 3, 0).reshape(Cin, 9 * cmid).contiguous()
-        return w1r, shift
+        # the same matrix as GEMM weights [N = (tap, cout)][K = Cin] with a zero bias: this repo's float32-grade split-operand GEMM takes
+        # the product where it accepts the shape (the library's float32 kernel ran it at 67 TFLOP/s: 0.45 ms a step for the two heads)
+        return w1r, shift, w1r.t().contiguous(), torch.zeros(9 * cmid, dtype=w1r.dtype, device=w1r.device)
 
-    w1r, shift = fused.cached(conv, "w1r", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
-    return (tok.reshape(B * h * w, Cin) @ w1r).view(B, h, w, 9, cmid), shift
+    w1r, shift, wnk, zero_bias = fused.cached(conv, "w1r", [conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var], build)
+    tok2 = tok.reshape(B * h * w, Cin)
+    if tok2.is_cuda and tok2.dtype == torch.float32 and ops.PRECISION != "bf16" and ops.gemm_wants_split(B * h * w, 9 * cmid, Cin):
+        ws = fused.cached(conv, "wsplit", (wnk,), lambda: ops.gemm_split_weights(wnk))
+        g9 = ops.gemm_bias_act(tok2, wnk, zero_bias, N.ACT_NONE, w_split=ws, split=True)
+        return g9.view(B, h, w, 9, cmid), shift
+    return (tok2 @ w1r).view(B, h, w, 9, cmid), shift
 
 
 def _fold_conv_bn(conv: nn.Conv2d, bn: nn.BatchNorm2d):

@@ -92,6 +92,15 @@ def launch_work(name, args):
         # the same 16 multiplies per 2x2 output tile, each issued as THREE f16 MFMA products: priced as issued, against the f16 peak
         _, b, h, w, cin, cout = args[:6]
         return "mfma_f16", 3 * 2.0 * 16 * cin * cout * b * ((h + 1) // 2) * ((w + 1) // 2)
+    if name == "awseg_depth_head_fused":
+        # (forms, batch, h, w, cmid, u, u_is_bf16, ...): the Winograd products of the second 3x3 (cmid -> 64) at 32h x 32w, as issued
+        # (three f16 products per multiply; one in bf16 mode); the generated hidden map costs vector instructions, no matrix flops
+        _, b, h, w, cmid = args[:5]
+        return "mfma_f16", (1 if args[6] else 3) * 2.0 * 16 * cmid * 64 * b * (16 * h) * (16 * w)
+    if name == "awseg_upconv_forms":
+        # (g9, batch, cmid, h, w, shift, forms): g9 in, the two tables out
+        _, b, cmid, h, w = args[:5]
+        return "hbm", 4.0 * b * (h * w * 9 * cmid + (3 * h + 3) * (w + 1) * 4 * cmid + (3 * h + 3) * (2 * w + 2) * 2 * cmid)
     if name == "awseg_conv3x3_winograd_bf16_nhwc":
         _, b, h, w, cin, cout = args[:6]
         return "mfma_f16", 2.0 * 16 * cin * cout * b * ((h + 1) // 2) * ((w + 1) // 2)      # one bf16 product per multiply
@@ -207,12 +216,13 @@ DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
                  "awseg_conv3x3_winograd_bf16_nhwc": ("wino8p_kernel<0, true>", "wino8p_kernel<1, true>", "wino8s_kernel<0, true>", "wino8s_kernel<1, true>", "wino8_kernel<0, true>", "wino8_kernel<1, true>", "wino_split_kernel<0, true>", "wino_split_kernel<1, true>"),
                  "awseg_gemm_split_bias_act": ("gemm_split3_kernel<false, 0, false", "gemm_split3_kernel<true, 0, false", "gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false", "gemm_split_kernel<2, 2, 4, 2, false, false, true", "gemm_split_kernel<2, 2, 4, 2, true, false, true"),
                  "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
-                 "awseg_attention_d32_split": "attention_d32_split_kernel",
+                 "awseg_attention_d32_split": "attention_d32_split_kernel", "awseg_depth_head_fused": ("wino8p_kernel<2, false>", "wino8p_kernel<2, true>"),
+                 "awseg_upconv_forms": "upconv_forms_kernel",
                  "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0", "awseg_combine_confusion_stats": "ensemble_stats_kernel<",
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": ("aspp_dw3_lds_kernel", "aspp_dw3_rows_kernel", "aspp_dw3_walk_kernel")}
 
 
-TRAFFIC_TABLES = ["r03_bench_step_stats_and_traffic.csv", "r02_bench_step_stats_and_traffic.csv", "r02_kernel_bench_stats_and_traffic.csv",
+TRAFFIC_TABLES = ["r04_bench_step_stats_and_traffic.csv", "r03_bench_step_stats_and_traffic.csv", "r02_bench_step_stats_and_traffic.csv", "r02_kernel_bench_stats_and_traffic.csv",
                   "r01_kernel_bench_v4_stats_and_traffic.csv"]   # first match wins
 
 

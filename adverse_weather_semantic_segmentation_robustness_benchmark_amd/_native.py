@@ -93,7 +93,9 @@ SIGNATURES = {
                                        c_f, c_f, c_p, c_p]),
     "awseg_conv_gemm_split_bias_act": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "awseg_conv_rows_gemm_split_bias_act": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "awseg_mixffn_fused": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_maxpool3x3s2_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
+    "awseg_maxpool3x3s2_bias_relu_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),
     "awseg_upsample_bilinear": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "awseg_combine_confusion_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i,
                                            c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_p]),

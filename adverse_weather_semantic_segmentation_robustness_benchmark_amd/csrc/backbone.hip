@@ -399,8 +399,12 @@ void dwconv3x3_upcat_lds_kernel(const float* __restrict__ a, int h, int w, int C
 // max that PROPAGATES NaN like nn.MaxPool2d (fmaxf drops it): a NaN from the stem must reach the logits on this path as on torch's
 __device__ __forceinline__ float nanmax(float m, float v) { return (v > m || v != v) ? v : m; }
 
+// EPI: relu(max + shift[c]) — the ResNet stem's folded BatchNorm shift and ReLU, moved behind the pooling (both monotone per channel:
+// bit-identical to shift -> ReLU -> pool), in the pooling kernel's store instead of a pass of their own over the pooled map
+template <bool EPI>
 __global__ __launch_bounds__(kThreads)
-void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, int64_t batch, int H, int W, int C, int Ho, int Wo, float* __restrict__ out)
+void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, int64_t batch, int H, int W, int C, int Ho, int Wo, const float* __restrict__ shift,
+                              float* __restrict__ out)
 {
     const int c4n = C / 4, wp = (Wo + 1) / 2;
     const int64_t total = batch * Ho * wp * c4n;
@@ -432,7 +436,12 @@ void maxpool3x3s2_nhwc_kernel(const float* __restrict__ x, int64_t batch, int H,
             const int ox = xp * 2 + o;
             if (ox >= Wo) break;
             const float4 a = col[2 * o], bq = col[2 * o + 1], c = col[2 * o + 2];
-            const float4 r = make_float4(nanmax(nanmax(a.x, bq.x), c.x), nanmax(nanmax(a.y, bq.y), c.y), nanmax(nanmax(a.z, bq.z), c.z), nanmax(nanmax(a.w, bq.w), c.w));
+            float4 r = make_float4(nanmax(nanmax(a.x, bq.x), c.x), nanmax(nanmax(a.y, bq.y), c.y), nanmax(nanmax(a.z, bq.z), c.z), nanmax(nanmax(a.w, bq.w), c.w));
+            if (EPI) {
+                const float4 sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
+                r.x = r.x + sh.x; r.y = r.y + sh.y; r.z = r.z + sh.z; r.w = r.w + sh.w;          // bias_act_nhwc's operations, in its order
+                r.x = r.x > 0.f ? r.x : 0.f; r.y = r.y > 0.f ? r.y : 0.f; r.z = r.z > 0.f ? r.z : 0.f; r.w = r.w > 0.f ? r.w : 0.f;
+            }
             *reinterpret_cast<float4*>(out + ((b * Ho + oy) * (int64_t)Wo + ox) * C + c4 * 4) = r;
         }
     }
@@ -832,8 +841,23 @@ AWSEG_API int awseg_maxpool3x3s2_nhwc(const float* x, int64_t batch, int height,
     if (((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return AWSEG_EALIGN;
     const int ho = (height - 1) / 2 + 1, wo = (width - 1) / 2 + 1;     // floor((n + 2 - 3) / 2) + 1
     const int64_t total = batch * ho * ((wo + 1) / 2) * (channels / 4);
-    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, batch,
-                       height, width, channels, ho, wo, out);
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel<false>, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, batch,
+                       height, width, channels, ho, wo, nullptr, out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_maxpool3x3s2_bias_relu_nhwc(const float* x, int64_t batch, int height, int width, int channels, const float* shift,
+                                                float* out, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!x || !out || !shift || batch < 0 || height < 1 || width < 1 || channels < 4) return AWSEG_EINVAL;
+    if (channels % 4) return AWSEG_ERANGE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)out & 15) || ((uintptr_t)shift & 15)) return AWSEG_EALIGN;
+    const int ho = (height - 1) / 2 + 1, wo = (width - 1) / 2 + 1;
+    const int64_t total = batch * ho * ((wo + 1) / 2) * (channels / 4);
+    hipLaunchKernelGGL(maxpool3x3s2_nhwc_kernel<true>, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), x, batch,
+                       height, width, channels, ho, wo, shift, out);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -68,6 +68,8 @@ void upconv_forms_kernel(const float* __restrict__ g9, int h, int w, int C, cons
     for (int d = 0; d < 3; ++d) ry[d] = rs <= h ? tap_free(rs - 1, d - 1, h) : tap_fixed(special_coord(rs - (h + 1), h), d - 1, h);
     const float* G = g9 + (int64_t)b * h * w * 9 * C;
     float* F = forms + (int64_t)b * img_floats;
+    // (four items per thread in flight: one item's six dependent-free loads alone leave the block waiting on memory latency)
+#pragma unroll 4
     for (int item = tid; item < 3 * w * FCB; item += 256) {
         const int c = item % FCB, jx = (item / FCB) % w, dx = item / (FCB * w);
         double hc = 0.0, hs = 0.0;

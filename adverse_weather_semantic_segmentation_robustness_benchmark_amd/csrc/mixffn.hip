@@ -1,0 +1,284 @@
+// mixffn.hip — the MiT Mix-FFN of one transformer block as ONE tile kernel:
+//     out = tok + fc2( gelu( dwconv3x3( fc1( layernorm(tok) ) ) ) )
+// (transformers' SegformerMixFFN behind SegformerLayer, as PKG/models/model.py:120-130 configures it: mlp_ratio 4, GELU; the
+// encoder call is PKG/models/model.py:193-197).  The 4x-wide hidden map — written by fc1, read and written by the depthwise
+// convolution, read by fc2: four passes of 0.54 GB per block at stage 1 of a 8 x 1024 x 2048 batch — never leaves the CU.
+//
+// Block = 8 x 32 tokens of one frame (an inner 6 x 30 tile + a one-token halo for the 3x3), 256 threads; wave w owns token rows
+// 2w, 2w + 1 of the tile as two 32-token column groups.  The two GEMMs run on v_mfma_f32_32x32x16_f16 with SPLIT float32 operands
+// (x = f16(x) + f16(x - f16(x)), three f16 products per float32-grade product, float32 accumulation: gemm_split.hip / DESIGN.md 5b)
+// — the float32-input MFMA (first version) spent 64 cycles per 32 x 32 x 2 product tile and bound the kernel: 1.6 ms for the four
+// launches of a step against 0.7 ms of vector work.  Weights arrive split ([hi | lo] f16 images from the host); LayerNorm outputs
+// are bounded by |gamma| sqrt(C) + |beta| (the host checks it against the f16 range); the GELU outputs of a chunk are checked on the
+// device, and a chunk that meets |g| >= 2^15 runs its fc2 products on v_mfma_f32_32x32x2_f32 instead (float32 in: no range limit).
+// Lane = (token column, K half):
+//   * LayerNorm in registers: a lane loads the 16 (32) channels of its token its K half multiplies, the two halves meet through
+//     one cross-lane exchange for mean and variance (two-pass, as awseg_layernorm_rows);
+//   * fc1, 32 hidden channels at a time: weights as the row operand, tokens as columns, so a lane ends up with 16 hidden values of
+//     ITS token in 4-channel runs -> + bias -> zero outside the frame (the convolution's padding) -> LDS [token][32];
+//   * depthwise 3x3 + bias + GELU (erf form, the fast erf of backbone.hip) on the inner tokens -> LDS;
+//   * fc2 partial sums over those 32 hidden channels, accumulators [C outputs x 32 tokens] per column group;
+//   * epilogue: + bias + residual, inner tokens only.
+// K order of a 16-deep step: K half kh of a lane = channels 16 step + 8 kh .. + 7 (two aligned float4 / one 16-byte f16 run).  The
+// float32 fall-back of fc2 walks the same eight channels two at a time (k = 0 <-> channel e, k = 1 <-> channel 8 + e of the step).
+#include "awseg_common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// (a, b) -> packed f16 high parts and packed f16 low parts (wino_split.hip's split_pair)
+__device__ __forceinline__ void mf_split_pair(float x, float y, unsigned& hi, unsigned& lo)
+{
+    asm("v_cvt_pkrtz_f16_f32 %0, %2, %3\n\t"
+        "v_fma_mixlo_f16 %1, %2, 1.0, -%0 op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %3, 1.0, -%0 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 1"
+        : "=&v"(hi), "=&v"(lo) : "v"(x), "v"(y));
+}
+__device__ __forceinline__ void mf_split8(const float4& p, const float4& q, h8& hi, h8& lo)
+{
+    unsigned h0, h1, h2, h3, l0, l1, l2, l3;
+    mf_split_pair(p.x, p.y, h0, l0); mf_split_pair(p.z, p.w, h1, l1);
+    mf_split_pair(q.x, q.y, h2, l2); mf_split_pair(q.z, q.w, h3, l3);
+    const u32x4 H = {h0, h1, h2, h3}, L = {l0, l1, l2, l3};
+    hi = __builtin_bit_cast(h8, H); lo = __builtin_bit_cast(h8, L);
+}
+
+constexpr int MF_TW = 32, MF_TH = 8, MF_IW = 30, MF_IH = 6;
+constexpr int MF_HS = 36;                    // LDS floats per token row: 32 + 4 (16-byte aligned, conflict-free float4 columns)
+
+__device__ __forceinline__ float mf_erf(float x)
+{
+    // Abramowitz-Stegun 7.1.26 (|error| < 1.5e-7), as backbone.hip's erf_as
+    const float ax = __builtin_fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, ax, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    p = p * t;
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * ax * ax);
+    const float r = fmaf(-p, e, 1.0f);
+    return __builtin_copysignf(r, x);
+}
+__device__ __forceinline__ float mf_gelu(float v) { return 0.5f * v * (1.0f + mf_erf(v * 0.70710678118654752440f)); }
+
+struct mf_args {
+    const float* tok; const float* gamma; const float* beta; float eps;
+    const _Float16* w1s; const float* b1; const float* w9; const float* bdw; const _Float16* w2s; const float* w2; const float* b2;
+    float* out; int H, W, nbx, nby;
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 2)
+void mixffn_kernel(mf_args a)
+{
+    constexpr int HD = 4 * C, NCH = HD / 32, NS = C / 16, NJ = 2 * NS, NN = C / 32;   // NS 16-deep steps over the token width
+    __shared__ __attribute__((aligned(16))) float s_h1[MF_TH * MF_TW * MF_HS];
+    __shared__ __attribute__((aligned(16))) float s_g[MF_TH * MF_TW * MF_HS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, kh = lane >> 5;
+    int bid = blockIdx.x;
+    const int bx = bid % a.nbx; bid /= a.nbx;
+    const int by = bid % a.nby;
+    const int b = bid / a.nby;
+    const int x0 = bx * MF_IW - 1, y0 = by * MF_IH - 1;          // frame coordinates of the tile's first (halo) token
+    const float* tokb = a.tok + (int64_t)b * a.H * a.W * C;
+
+    // ---- LayerNorm of this lane's two tokens (rows 2 wave, 2 wave + 1; column col): channels 16 st + 8 kh .. + 7 of every step st
+    // (y[m][2 st], y[m][2 st + 1] = the step's two float4)
+    float4 y[2][NJ];
+    bool inimg[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int gy = y0 + 2 * wave + m, gx = x0 + col;
+        inimg[m] = gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        const float* xr = tokb + ((int64_t)(inimg[m] ? gy : 0) * a.W + (inimg[m] ? gx : 0)) * C + 8 * kh;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            y[m][j] = *reinterpret_cast<const float4*>(xr + 16 * (j >> 1) + 4 * (j & 1));
+            sum += (y[m][j].x + y[m][j].y) + (y[m][j].z + y[m][j].w);
+        }
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / (float)C);
+        float sq = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float d0 = y[m][j].x - mean, d1 = y[m][j].y - mean, d2 = y[m][j].z - mean, d3 = y[m][j].w - mean;
+            sq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        sq += __shfl_xor(sq, 32, 64);
+        const float rstd = rsqrtf(sq * (1.0f / (float)C) + a.eps);
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float4 g = *reinterpret_cast<const float4*>(a.gamma + 16 * (j >> 1) + 8 * kh + 4 * (j & 1));
+            const float4 bb = *reinterpret_cast<const float4*>(a.beta + 16 * (j >> 1) + 8 * kh + 4 * (j & 1));
+            y[m][j].x = (y[m][j].x - mean) * rstd * g.x + bb.x; y[m][j].y = (y[m][j].y - mean) * rstd * g.y + bb.y;
+            y[m][j].z = (y[m][j].z - mean) * rstd * g.z + bb.z; y[m][j].w = (y[m][j].w - mean) * rstd * g.w + bb.w;
+        }
+    }
+
+    // split once: the B operands of fc1 for every hidden chunk
+    h8 yh[2][NS], yl[2][NS];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int st = 0; st < NS; ++st) mf_split8(y[m][2 * st], y[m][2 * st + 1], yh[m][st], yl[m][st]);
+
+    f32x16 acc2[2][NN];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
+
+    for (int hc = 0; hc < NCH; ++hc) {
+        // ---- fc1: hidden channels hc * 32 .. + 31 of this wave's 64 tokens -> LDS
+        {
+            h8 wh[NS], wl[NS];                                         // weight rows hc * 32 + col, this lane's K half: [hi image | lo image]
+#pragma unroll
+            for (int st = 0; st < NS; ++st) {
+                wh[st] = *reinterpret_cast<const h8*>(a.w1s + (int64_t)(hc * 32 + col) * C + 16 * st + 8 * kh);
+                wl[st] = *reinterpret_cast<const h8*>(a.w1s + (int64_t)HD * C + (int64_t)(hc * 32 + col) * C + 16 * st + 8 * kh);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                f32x16 acc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                for (int st = 0; st < NS; ++st) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[st], yh[m][st], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[st], yh[m][st], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[st], yl[m][st], acc, 0, 0, 0);
+                }
+                // accumulator register r = hidden channel (r & 3) + 8 (r >> 2) + 4 kh of this chunk, column = token col
+                float* dst = s_h1 + ((2 * wave + m) * MF_TW + col) * MF_HS + 4 * kh;
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hc * 32 + 8 * g4 + 4 * kh);
+                    float4 v = make_float4(acc[4 * g4] + bb.x, acc[4 * g4 + 1] + bb.y, acc[4 * g4 + 2] + bb.z, acc[4 * g4 + 3] + bb.w);
+                    if (!inimg[m]) v = make_float4(0.f, 0.f, 0.f, 0.f);          // the depthwise convolution's zero padding
+                    *reinterpret_cast<float4*>(dst + 8 * g4) = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- depthwise 3x3 + bias + GELU on the inner 6 x 30 tokens: item = (token, channel quad)
+        float gmax = 0.f;
+        for (int it = tid; it < MF_IH * MF_IW * 8; it += 256) {
+            const int q = it & 7, tk = it >> 3;
+            const int iy = tk / MF_IW, ix = tk - iy * MF_IW;
+            const int ch = hc * 32 + 4 * q;
+            float4 acc = *reinterpret_cast<const float4*>(a.bdw + ch);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const float4 v = *reinterpret_cast<const float4*>(s_h1 + ((iy + dy) * MF_TW + ix + dx) * MF_HS + 4 * q);
+                    const float4 w = *reinterpret_cast<const float4*>(a.w9 + (int64_t)(dy * 3 + dx) * HD + ch);
+                    acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y); acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+                }
+            const float4 gv = make_float4(mf_gelu(acc.x), mf_gelu(acc.y), mf_gelu(acc.z), mf_gelu(acc.w));
+            gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, __builtin_fmaxf(__builtin_fabsf(gv.x), __builtin_fabsf(gv.y))),
+                                   __builtin_fmaxf(__builtin_fabsf(gv.z), __builtin_fabsf(gv.w)));
+            *reinterpret_cast<float4*>(s_g + ((iy + 1) * MF_TW + ix + 1) * MF_HS + 4 * q) = gv;
+        }
+        // (a NaN fails the comparison and takes the f16 path, where it stays a NaN; an infinity takes the float32 path)
+        const bool big = __syncthreads_or(gmax >= 32768.0f) != 0;
+        // ---- fc2: partial sums over these 32 hidden channels (halo tokens multiply whatever their LDS rows hold: their columns are dropped)
+        if (!big) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                h8 wh[NN], wl[NN];
+#pragma unroll
+                for (int n = 0; n < NN; ++n) {
+                    wh[n] = *reinterpret_cast<const h8*>(a.w2s + (int64_t)(n * 32 + col) * HD + hc * 32 + 16 * st + 8 * kh);
+                    wl[n] = *reinterpret_cast<const h8*>(a.w2s + (int64_t)C * HD + (int64_t)(n * 32 + col) * HD + hc * 32 + 16 * st + 8 * kh);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {
+                    const float* gp = s_g + ((2 * wave + m) * MF_TW + col) * MF_HS + 16 * st + 8 * kh;
+                    h8 gh, gl;
+                    mf_split8(*reinterpret_cast<const float4*>(gp), *reinterpret_cast<const float4*>(gp + 4), gh, gl);
+#pragma unroll
+                    for (int n = 0; n < NN; ++n) {
+                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], gh, acc2[m][n], 0, 0, 0);
+                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[n], gh, acc2[m][n], 0, 0, 0);
+                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], gl, acc2[m][n], 0, 0, 0);
+                    }
+                }
+            }
+        } else {
+            // float32-input MFMA on the same operands (block-uniform branch): k = 0 <-> hidden channel 16 st + e, k = 1 <-> 16 st + 8 + e
+#pragma unroll 1
+            for (int st = 0; st < 2; ++st)
+#pragma unroll 1
+                for (int e = 0; e < 8; ++e) {
+                    const int hd = hc * 32 + 16 * st + 8 * kh + e;
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        const float gv = s_g[((2 * wave + m) * MF_TW + col) * MF_HS + 16 * st + 8 * kh + e];
+#pragma unroll
+                        for (int n = 0; n < NN; ++n)
+                            acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w2[(int64_t)(n * 32 + col) * HD + hd], gv, acc2[m][n], 0, 0, 0);
+                    }
+                }
+        }
+        __syncthreads();                                             // the next chunk overwrites both LDS images
+    }
+
+    // ---- epilogue: + bias + residual, inner tokens of the frame only
+    float* outb = a.out + (int64_t)b * a.H * a.W * C;
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int row = 2 * wave + m;
+        const int gy = y0 + row, gx = x0 + col;
+        if (!(row >= 1 && row <= MF_IH && col >= 1 && col <= MF_IW && gy < a.H && gx < a.W)) continue;
+        const int64_t base = ((int64_t)gy * a.W + gx) * C;
+#pragma unroll
+        for (int n = 0; n < NN; ++n)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int ch = n * 32 + 8 * g4 + 4 * kh;
+                const float4 bb = *reinterpret_cast<const float4*>(a.b2 + ch);
+                const float4 rs = *reinterpret_cast<const float4*>(tokb + base + ch);
+                float4 v;
+                v.x = (acc2[m][n][4 * g4] + bb.x) + rs.x; v.y = (acc2[m][n][4 * g4 + 1] + bb.y) + rs.y;
+                v.z = (acc2[m][n][4 * g4 + 2] + bb.z) + rs.z; v.w = (acc2[m][n][4 * g4 + 3] + bb.w) + rs.w;
+                *reinterpret_cast<float4*>(outb + base + ch) = v;
+            }
+    }
+}
+
+}  // namespace
+
+AWSEG_API int awseg_mixffn_fused(const float* tok, int batch, int height, int width, int channels, const float* ln_gamma, const float* ln_beta,
+                                 float ln_eps, const uint16_t* w1_split, const float* b1, const float* dw_taps, const float* dw_bias,
+                                 const uint16_t* w2_split, const float* w2, const float* b2, float* out, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    const void* w1 = w1_split;
+    if (!tok || !ln_gamma || !ln_beta || !w1_split || !b1 || !dw_taps || !dw_bias || !w2_split || !w2 || !b2 || !out || batch < 0 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (channels != 32 && channels != 64) return AWSEG_ERANGE;       // the two token widths whose hidden maps are worth the trouble (MiT-B0 stages 1, 2)
+    if (out == tok) return AWSEG_EINVAL;                             // blocks read their neighbours' tokens: not in place
+    const uintptr_t al = (uintptr_t)tok | (uintptr_t)ln_gamma | (uintptr_t)ln_beta | (uintptr_t)w1 | (uintptr_t)b1 | (uintptr_t)dw_taps |
+                         (uintptr_t)dw_bias | (uintptr_t)w2 | (uintptr_t)w2_split | (uintptr_t)b2 | (uintptr_t)out;
+    if (al & 15) return AWSEG_EALIGN;
+    mf_args a;
+    a.tok = tok; a.gamma = ln_gamma; a.beta = ln_beta; a.eps = ln_eps; a.w1s = reinterpret_cast<const _Float16*>(w1_split); a.b1 = b1;
+    a.w9 = dw_taps; a.bdw = dw_bias; a.w2s = reinterpret_cast<const _Float16*>(w2_split); a.w2 = w2; a.b2 = b2;
+    a.out = out; a.H = height; a.W = width;
+    a.nbx = (width + MF_IW - 1) / MF_IW; a.nby = (height + MF_IH - 1) / MF_IH;
+    const int64_t blocks = (int64_t)batch * a.nbx * a.nby;
+    if (blocks >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
+    if (channels == 32) hipLaunchKernelGGL(mixffn_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, awseg_s(stream), a);
+    else hipLaunchKernelGGL(mixffn_kernel<64>, dim3((unsigned)blocks), dim3(256), 0, awseg_s(stream), a);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

@@ -323,12 +323,13 @@ def resnet_features(enc, x: torch.Tensor, stem_feature: bool = False) -> List[to
         if (y.is_cuda and y.dtype == torch.float32 and y.is_contiguous(memory_format=CL) and y.shape[1] % 4 == 0
                 and _pair(mp.kernel_size) == (3, 3) and _pair(mp.stride) == (2, 2) and _pair(mp.padding) == (1, 1)
                 and _pair(mp.dilation) == (1, 1) and not mp.ceil_mode):
-            y = ops.maxpool3x3s2_nhwc(nhwc_view(y)).permute(0, 3, 1, 2)          # HIP: no int64 index tensor (torch writes 537 MB of them)
+            # HIP: no int64 index tensor (torch writes 537 MB of them); the stem's shift + ReLU ride in the pooling kernel's store
+            y = ops.maxpool3x3s2_nhwc(nhwc_view(y), shift=shift).permute(0, 3, 1, 2)
         else:
             y = mp(y)
-        if not y.is_contiguous(memory_format=CL):
-            y = y.contiguous(memory_format=CL)
-        ops.bias_act_nhwc_(y.permute(0, 2, 3, 1), shift, None, N.ACT_RELU)
+            if not y.is_contiguous(memory_format=CL):
+                y = y.contiguous(memory_format=CL)
+            ops.bias_act_nhwc_(y.permute(0, 2, 3, 1), shift, None, N.ACT_RELU)
         feats.append(None)
     for layer in (enc.layer1, enc.layer2, enc.layer3, enc.layer4):
         for blk in layer:
@@ -442,6 +443,20 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
             # tok + o_proj(o): the residual is the GEMM's beta*C operand, accumulated over tok's buffer
             tok = _linear_residual(o, a.o_proj, tok)
             m = blk.mlp
+            ln2 = blk.layernorm_after
+            if (ops.MIXFFN_FUSED and ops.PRECISION != "bf16" and tok.is_cuda and tok.dtype == torch.float32 and C in (32, 64)
+                    and getattr(seg.config, "hidden_act", "gelu") == "gelu" and m.fc1.bias is not None and m.fc2.bias is not None
+                    and m.dwconv.dwconv.bias is not None and ln2.weight is not None and ln2.bias is not None):
+                # the whole Mix-FFN as one tile kernel: the 4x-wide hidden map never reaches HBM (four launches and four passes otherwise)
+                prep = cached(m, "mixffn", [ln2.weight, ln2.bias, m.fc1.weight, m.fc2.weight],
+                              lambda: (ops.mixffn_split_weights(m.fc1.weight), ops.mixffn_split_weights(m.fc2.weight))
+                              if ops.mixffn_operands_ok(ln2.weight, ln2.bias, m.fc1.weight, m.fc2.weight) else None)
+                fusedtok = None if prep is None else ops.mixffn_fused(
+                    tok, ln2.weight, ln2.bias, ln2.eps, m.fc1.weight, m.fc1.bias, dw_taps(m.dwconv.dwconv), m.dwconv.dwconv.bias,
+                    m.fc2.weight, m.fc2.bias, w1_split=prep[0], w2_split=prep[1], checked=True)
+                if fusedtok is not None:
+                    tok = fusedtok
+                    continue
             hcur = _linear(_ln(tok, blk.layernorm_after), m.fc1)
             if getattr(seg.config, "hidden_act", "gelu") == "gelu":
                 hcur = ops.dwconv3x3_nhwc(hcur, dw_taps(m.dwconv.dwconv), m.dwconv.dwconv.bias, N.ACT_GELU)   # dwconv + GELU fused

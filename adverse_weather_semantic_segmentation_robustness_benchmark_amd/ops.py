@@ -579,6 +579,45 @@ def conv3x3_winograd_split(x: torch.Tensor, u_split: torch.Tensor, cout: int, sh
     return out
 
 
+MIXFFN_FUSED = os.environ.get("AWSEG_MIXFFN_FUSED", "1") != "0"  # MiT Mix-FFN (LN -> fc1 -> dw3x3 + GELU -> fc2 + residual) as one tile kernel
+
+
+def mixffn_split_weights(w: torch.Tensor) -> torch.Tensor:
+    """float32 [N,K] -> float16 [2,N,K]: f16(w) and f16(w - f16(w)) — the operand images awseg_mixffn_fused multiplies."""
+    hi = w.to(torch.float16)
+    return torch.stack([hi, (w - hi.float()).to(torch.float16)]).contiguous()
+
+
+def mixffn_fused(tok: torch.Tensor, gamma, beta, eps: float, w1, b1, dw_taps, dw_bias, w2, b2, w1_split=None, w2_split=None,
+                 checked: bool = False) -> Optional[torch.Tensor]:
+    """tok + fc2(gelu(dwconv3x3(fc1(layernorm(tok))))) on NHWC tokens [B,H,W,C] in one launch (csrc/mixffn.hip); None when the
+    kernel does not take the problem (C not 32 / 64, hidden != 4C, weights or LayerNorm parameters beyond the f16 operand range):
+    the caller keeps its separate launches.  `checked`: the caller has verified the range conditions (mixffn_operands_ok) —
+    otherwise they are checked here, which synchronises the host with the device."""
+    b, h, w, c = tok.shape
+    if c not in (32, 64) or w1.shape != (4 * c, c) or w2.shape != (c, 4 * c) or dw_taps.shape != (9, 4 * c):
+        return None
+    if not checked and not mixffn_operands_ok(gamma, beta, w1, w2):
+        return None
+    tok = tok.contiguous()
+    out = torch.empty_like(tok)
+    w1s = w1_split if w1_split is not None else mixffn_split_weights(w1)
+    w2s = w2_split if w2_split is not None else mixffn_split_weights(w2)
+    rc = N.try_call("awseg_mixffn_fused", N.ptr(tok), b, h, w, c, N.ptr(gamma.contiguous()), N.ptr(beta.contiguous()), float(eps),
+                    N.ptr(w1s), N.ptr(b1.contiguous()), N.ptr(dw_taps.contiguous()), N.ptr(dw_bias.contiguous()),
+                    N.ptr(w2s), N.ptr(w2.contiguous()), N.ptr(b2.contiguous()), N.ptr(out), N.stream())
+    return out if rc == 0 else None
+
+
+def mixffn_operands_ok(gamma, beta, w1, w2) -> bool:
+    """The f16 operand range of awseg_mixffn_fused: |w| < 2^15 and the LayerNorm outputs' bound max|gamma| sqrt(C) + max|beta| < 2^15
+    (one host synchronisation: callers cache the answer per parameter version)."""
+    c = gamma.numel()
+    lim = 32768.0
+    vals = torch.stack([gamma.abs().max() * (c ** 0.5) + beta.abs().max(), w1.abs().max(), w2.abs().max()])
+    return bool(torch.isfinite(vals).all().item()) and bool((vals < lim).all().item())
+
+
 DEPTH_FUSED = os.environ.get("AWSEG_DEPTH_FUSED", "1") != "0"    # the SegFormer depth head as one full-resolution launch (depthfuse.hip)
 
 
@@ -887,12 +926,16 @@ def restore_split(state: dict) -> None:
     HEAD_SPLIT = bool(state.get("segformer_head", HEAD_SPLIT))
 
 
-def maxpool3x3s2_nhwc(x_nhwc: torch.Tensor) -> torch.Tensor:
-    """nn.MaxPool2d(3, stride=2, padding=1) on a contiguous float32 [B,H,W,C] tensor -> [B,Ho,Wo,C] (no index tensor)."""
+def maxpool3x3s2_nhwc(x_nhwc: torch.Tensor, shift: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """nn.MaxPool2d(3, stride=2, padding=1) on a contiguous float32 [B,H,W,C] tensor -> [B,Ho,Wo,C] (no index tensor); with
+    `shift` [C]: relu(pool + shift) in the same pass (the ResNet stem's BatchNorm shift + ReLU moved behind the pooling)."""
     x = x_nhwc.contiguous()
     b, h, w, c = x.shape
     out = torch.empty(b, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c, dtype=torch.float32, device=x.device)
-    N.call("awseg_maxpool3x3s2_nhwc", N.ptr(x), b, h, w, c, N.ptr(out), N.stream())
+    if shift is not None:
+        N.call("awseg_maxpool3x3s2_bias_relu_nhwc", N.ptr(x), b, h, w, c, N.ptr(shift.contiguous()), N.ptr(out), N.stream())
+    else:
+        N.call("awseg_maxpool3x3s2_nhwc", N.ptr(x), b, h, w, c, N.ptr(out), N.stream())
     return out
 
 

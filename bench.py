@@ -97,6 +97,11 @@ def launch_work(name, args):
         # (three f16 products per multiply; one in bf16 mode); the generated hidden map costs vector instructions, no matrix flops
         _, b, h, w, cmid = args[:5]
         return "mfma_f16", (1 if args[6] else 3) * 2.0 * 16 * cmid * 64 * b * (16 * h) * (16 * w)
+    if name == "awseg_mixffn_fused":
+        # (tok, batch, H, W, C, ...): the two GEMMs (C -> 4C on the haloed 8 x 32 tile, 4C -> C) as issued, three f16 products per multiply;
+        # algorithmic bytes would be tok in + out (8 C bytes a token) — the kernel is bound by the GELU's vector work, priced here against the matrix peak
+        _, b, h, w, c = args[:5]
+        return "mfma_f16", 3 * 2.0 * b * h * w * (4 * c * c) * (256.0 / 180.0 + 1.0)
     if name == "awseg_upconv_forms":
         # (g9, batch, cmid, h, w, shift, forms): g9 in, the two tables out
         _, b, cmid, h, w = args[:5]
@@ -217,7 +222,7 @@ DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
                  "awseg_gemm_split_bias_act": ("gemm_split3_kernel<false, 0, false", "gemm_split3_kernel<true, 0, false", "gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false", "gemm_split_kernel<2, 2, 4, 2, false, false, true", "gemm_split_kernel<2, 2, 4, 2, true, false, true"),
                  "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
                  "awseg_attention_d32_split": "attention_d32_split_kernel", "awseg_depth_head_fused": ("wino8p_kernel<2, false>", "wino8p_kernel<2, true>"),
-                 "awseg_upconv_forms": "upconv_forms_kernel",
+                 "awseg_upconv_forms": "upconv_forms_kernel", "awseg_mixffn_fused": ("mixffn_kernel<32>", "mixffn_kernel<64>"),
                  "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0", "awseg_combine_confusion_stats": "ensemble_stats_kernel<",
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": ("aspp_dw3_lds_kernel", "aspp_dw3_rows_kernel", "aspp_dw3_walk_kernel")}
 

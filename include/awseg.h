@@ -615,11 +615,29 @@ int awseg_attention_d32(const float* q, const float* k, const float* v, float* o
 int awseg_attention_d32_split(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                               int n_queries, int n_keys, float scale, awseg_stream_t stream);
 
+/* awseg_mixffn_fused: one MiT Mix-FFN (transformers' SegformerLayer: hidden = hidden + MixFFN(layer_norm_2(hidden)), MixFFN = dense1
+ * -> depthwise 3x3 (padding 1, bias) -> GELU (erf) -> dense2; the encoder PKG/models/model.py:120-130 configures and :193-197 calls)
+ * as ONE tile kernel: out[b,y,x,:] = tok + w2 . gelu(dwconv(w1 . layernorm(tok) + b1) + dw_bias) + b2 on float32 NHWC tokens
+ * [batch, height, width, channels]; the 4x-wide hidden map stays in LDS.  The two GEMMs run on the f16 matrix cores with SPLIT
+ * float32 operands (three f16 products per float32-grade product, float32 accumulation): w1_split uint16 [2][4C][C], w2_split
+ * uint16 [2][C][4C] = f16 bit patterns of f16(w) and of f16(w - f16(w)) (nn.Linear layouts [out][in]); w2 float32 [C][4C] as well
+ * (a chunk whose GELU outputs reach 2^15 runs its fc2 products on the float32-input MFMA).  The caller guarantees |w| < 2^15 and
+ * max|ln_gamma| sqrt(C) + max|ln_beta| < 2^15 (the LayerNorm outputs' bound); dw_taps [9][4C] tap-major (ky * 3 + kx); all
+ * vectors 16-byte aligned.  channels 32 or 64 (AWSEG_ERANGE otherwise: the caller keeps its four launches); out must not alias tok. */
+int awseg_mixffn_fused(const float* tok, int batch, int height, int width, int channels, const float* ln_gamma, const float* ln_beta,
+                       float ln_eps, const uint16_t* w1_split, const float* b1, const float* dw_taps, const float* dw_bias,
+                       const uint16_t* w2_split, const float* w2, const float* b2, float* out, awseg_stream_t stream);
+
 /* nn.MaxPool2d(kernel 3, stride 2, padding 1) on a float32 NHWC tensor [batch, height, width, channels] (channels % 4 == 0)
  * -> [batch, (height - 1) / 2 + 1, (width - 1) / 2 + 1, channels]; padding does not take part in the maximum.  The ResNet stem
  * of the smp encoder the reference builds (PKG/models/model.py:262-268); no index tensor is produced. */
 int awseg_maxpool3x3s2_nhwc(const float* x, int64_t batch, int height, int width, int channels, float* out,
                             awseg_stream_t stream);
+/* The same pooling with the stem's epilogue in its store: out = relu(maxpool(x) + shift[c]) — BatchNorm's folded shift and the
+ * ReLU of the smp ResNet stem (conv1 -> bn1 -> relu -> maxpool) commute with the maximum per channel, so they run once per POOLED
+ * pixel here instead of as a pass of their own (same two float32 operations as awseg_bias_act_nhwc: bit-identical). */
+int awseg_maxpool3x3s2_bias_relu_nhwc(const float* x, int64_t batch, int height, int width, int channels, const float* shift,
+                                      float* out, awseg_stream_t stream);
 
 /* Bilinear upsampling of [planes, low_height, low_width] float32 maps to [planes, height, width] with torch's
  * upsample_bilinear2d arithmetic (source index, weights, order of the four products), align_corners 0 or 1.  Replaces

@@ -956,6 +956,12 @@ def test_maxpool3x3s2_nhwc_equals_torch(ops, shape):
     ref = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     got = ops.maxpool3x3s2_nhwc(x)
     assert ref.isnan().sum().item() >= 3 and torch.equal(got.isnan(), ref.isnan()) and torch.equal(got.nan_to_num(0.0), ref.nan_to_num(0.0))
+    # the stem's epilogue in the pooling kernel's store == the pooling followed by awseg_bias_act_nhwc, bit for bit
+    x2 = torch.randn(B, H, W, C, device="cuda", generator=g)
+    shift = torch.randn(C, device="cuda", generator=g)
+    two = ops.maxpool3x3s2_nhwc(x2)
+    ops.bias_act_nhwc_(two, shift, None, 1)
+    assert torch.equal(ops.maxpool3x3s2_nhwc(x2, shift=shift), two)
 
 
 @pytest.mark.parametrize("cfg", [(2, 19, 16, 32, 64, 128, True), (1, 3, 7, 5, 28, 20, True), (2, 1, 4, 8, 64, 128, False),
@@ -1421,3 +1427,43 @@ def test_depth_head_fused_range_guard(ops):
             ref = ref_mod(up).numpy()
             got = head.cuda().forward_from_lowres(feats.cuda(), 64, 64).cpu().numpy()
         assert np.abs(got - ref).max() <= 1e-5, (gain, np.abs(got - ref).max())
+
+
+# ------------------------------------------------------------------ MiT Mix-FFN as one tile kernel (mixffn.hip)
+@pytest.mark.parametrize("cfg", [(2, 13, 37, 32), (1, 6, 30, 64), (1, 20, 70, 64), (3, 1, 1, 32), (1, 64, 96, 32)])
+def test_mixffn_fused_matches_float64_ops(ops, cfg):
+    """awseg_mixffn_fused (LayerNorm -> fc1 -> depthwise 3x3 -> GELU -> fc2 -> + residual in one launch, hidden map in LDS)
+    against the same five torch operations in float64 (transformers' SegformerLayer second half): ragged tiles (H % 6, W % 30),
+    frames smaller than a tile, tile borders inside the frame, both token widths.  1e-5 of the output magnitude."""
+    B, H, W, C = cfg
+    g = torch.Generator(device="cuda").manual_seed(sum(cfg))
+    tok = torch.randn(B, H, W, C, device="cuda", generator=g) * 2.0 + 0.3
+    gamma, beta = torch.rand(C, device="cuda", generator=g) + 0.5, torch.randn(C, device="cuda", generator=g) * 0.2
+    w1, b1 = torch.randn(4 * C, C, device="cuda", generator=g) / C ** 0.5, torch.randn(4 * C, device="cuda", generator=g) * 0.1
+    wd, bd = torch.randn(4 * C, 1, 3, 3, device="cuda", generator=g) * 0.3, torch.randn(4 * C, device="cuda", generator=g) * 0.1
+    w2, b2 = torch.randn(C, 4 * C, device="cuda", generator=g) / (4 * C) ** 0.5, torch.randn(C, device="cuda", generator=g) * 0.1
+    taps = wd.view(4 * C, 9).t().contiguous()
+    got = ops.mixffn_fused(tok, gamma, beta, 1e-6, w1, b1, taps, bd, w2, b2)
+    assert got is not None and got.data_ptr() != tok.data_ptr()
+    F = torch.nn.functional
+    td = tok.double()
+    h = F.linear(F.layer_norm(td, (C,), gamma.double(), beta.double(), 1e-6), w1.double(), b1.double())       # [B,H,W,4C]
+    h = F.conv2d(h.permute(0, 3, 1, 2), wd.double(), bd.double(), 1, 1, 1, 4 * C).permute(0, 2, 3, 1)
+    ref = td + F.linear(F.gelu(h), w2.double(), b2.double())
+    err = (got.double() - ref).abs().max().item()
+    print(f"mixffn fused {cfg}: max abs err {err:.2e} at magnitude {ref.abs().max().item():.1f}")
+    assert err < 1e-5 * max(1.0, ref.abs().max().item())
+    # GELU outputs beyond the f16 operand range: the chunk's fc2 runs on the float32-input MFMA (block-uniform branch) — same gate
+    big = ops.mixffn_fused(tok, gamma, beta, 1e-6, w1, b1 + 3.0e5, taps, bd, w2 * 1e-3, b2)
+    hb = F.linear(F.layer_norm(td, (C,), gamma.double(), beta.double(), 1e-6), w1.double(), b1.double() + 3.0e5)
+    hb = F.conv2d(hb.permute(0, 3, 1, 2), wd.double(), bd.double(), 1, 1, 1, 4 * C).permute(0, 2, 3, 1)
+    refb = td + F.linear(F.gelu(hb), (w2 * 1e-3).double(), b2.double())
+    errb = (big.double() - refb).abs().max().item()
+    print(f"mixffn fused {cfg}, hidden activations ~3e5: max abs err {errb:.2e} at magnitude {refb.abs().max().item():.1f}")
+    assert errb < 1e-5 * max(1.0, refb.abs().max().item())
+    # parameters beyond the f16 operand range are declined (the caller keeps its separate launches)
+    assert ops.mixffn_fused(tok, gamma, beta, 1e-6, w1 * 1e6, b1, taps, bd, w2, b2) is None
+    # widths the kernel does not take are declined, not computed some other way
+    assert ops.mixffn_fused(torch.zeros(1, 4, 4, 160, device="cuda"), torch.ones(160, device="cuda"), torch.zeros(160, device="cuda"), 1e-6,
+                            torch.zeros(640, 160, device="cuda"), torch.zeros(640, device="cuda"), torch.zeros(9, 640, device="cuda"),
+                            torch.zeros(640, device="cuda"), torch.zeros(160, 640, device="cuda"), torch.zeros(160, device="cuda")) is None

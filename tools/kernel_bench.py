@@ -119,6 +119,17 @@ def main():
         cases["upconv_forms 128ch (tables at 1/32)"] = (lambda: ops.upconv_forms(g9d, sf[:128].contiguous()), "hbm", 4.0 * (g9d.numel() + fm.numel()))
         cases["depth_head_fused 128->64 +1x1+sigmoid @full, patch generated [split f16x3, issued flops]"] = (
             lambda: ops.depth_head_fused(fm, h, w, 128, usd, sh64, w64, b1), "mfma_f16", 3 * 2.0 * 16 * 128 * 64 * B * (H // 2) * (W // 2))
+    # MiT Mix-FFN as one tile kernel (stage 1: 32 channels at 1/4, stage 2: 64 at 1/8): algorithmic bytes = tokens in + out
+    for cm, dv in ((32, 4), (64, 8)):
+        tk = torch.randn(B, H // dv, W // dv, cm, device=dev)
+        gm, bt = torch.rand(cm, device=dev) + 0.5, torch.randn(cm, device=dev) * 0.1
+        f1, fb1 = torch.randn(4 * cm, cm, device=dev) / cm ** 0.5, torch.randn(4 * cm, device=dev) * 0.1
+        tp, tb = torch.randn(9, 4 * cm, device=dev) * 0.3, torch.randn(4 * cm, device=dev) * 0.1
+        f2, fb2 = torch.randn(cm, 4 * cm, device=dev) / (4 * cm) ** 0.5, torch.randn(cm, device=dev) * 0.1
+        s1w, s2w = ops.mixffn_split_weights(f1), ops.mixffn_split_weights(f2)
+        cases[f"mixffn_fused C={cm} @1/{dv} (LN+fc1+dw3x3+GELU+fc2+res, one launch)"] = (
+            lambda tk=tk, gm=gm, bt=bt, f1=f1, fb1=fb1, tp=tp, tb=tb, f2=f2, fb2=fb2, s1w=s1w, s2w=s2w:
+            ops.mixffn_fused(tk, gm, bt, 1e-6, f1, fb1, tp, tb, f2, fb2, w1_split=s1w, w2_split=s2w, checked=True), "hbm", 8.0 * tk.numel())
     xa = torch.randn(B, H // 16, W // 16, 2048, device=dev); wdw = torch.randn(3, 9, 2048, device=dev)
     cases["aspp_depthwise3"] = (lambda: ops.aspp_depthwise3(xa, wdw, (12, 24, 36)), "hbm", 4 * 2048 * 4 * (H // 16) * (W // 16) * B)
     xd = torch.randn(B, H // 4, W // 4, 128, device=dev); w9 = torch.randn(9, 128, device=dev); bb = torch.randn(128, device=dev)

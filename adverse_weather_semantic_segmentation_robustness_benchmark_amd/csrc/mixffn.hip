@@ -137,15 +137,25 @@ void mixffn_kernel(mf_args a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc2[m][n][r] = 0.f;
 
+    // fc1 weight rows hc * 32 + col, this lane's K half ([hi image | lo image]); fetched a chunk ahead: with two waves per SIMD a load
+    // issued where it is used waits out an L2 round trip with nothing else to run (the first version: 0.35 ms per stage-1 launch)
+    h8 wh[NS], wl[NS];
+    auto load_w1 = [&](int hc) {
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            wh[st] = *reinterpret_cast<const h8*>(a.w1s + (int64_t)(hc * 32 + col) * C + 16 * st + 8 * kh);
+            wl[st] = *reinterpret_cast<const h8*>(a.w1s + (int64_t)HD * C + (int64_t)(hc * 32 + col) * C + 16 * st + 8 * kh);
+        }
+    };
+    if (C <= 32) load_w1(0);                                         // (C = 64: no room for a chunk-ahead copy — fetched where they are used)
+    // depthwise stage: a thread owns one channel quad q and one tile column ix and walks the six inner rows with a sliding 3 x 3 window
+    // (three LDS reads per output instead of nine; the nine tap vectors and the bias stay in registers for the chunk)
+    const int dq = tid & 7, dix = tid >> 3;                          // 32 columns x 8 quads; columns 30, 31 idle
+
     for (int hc = 0; hc < NCH; ++hc) {
         // ---- fc1: hidden channels hc * 32 .. + 31 of this wave's 64 tokens -> LDS
         {
-            h8 wh[NS], wl[NS];                                         // weight rows hc * 32 + col, this lane's K half: [hi image | lo image]
-#pragma unroll
-            for (int st = 0; st < NS; ++st) {
-                wh[st] = *reinterpret_cast<const h8*>(a.w1s + (int64_t)(hc * 32 + col) * C + 16 * st + 8 * kh);
-                wl[st] = *reinterpret_cast<const h8*>(a.w1s + (int64_t)HD * C + (int64_t)(hc * 32 + col) * C + 16 * st + 8 * kh);
-            }
+            if (C > 32) load_w1(hc);
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 f32x16 acc;
@@ -168,39 +178,59 @@ void mixffn_kernel(mf_args a)
                 }
             }
         }
-        __syncthreads();
-        // ---- depthwise 3x3 + bias + GELU on the inner 6 x 30 tokens: item = (token, channel quad)
-        float gmax = 0.f;
-        for (int it = tid; it < MF_IH * MF_IW * 8; it += 256) {
-            const int q = it & 7, tk = it >> 3;
-            const int iy = tk / MF_IW, ix = tk - iy * MF_IW;
-            const int ch = hc * 32 + 4 * q;
-            float4 acc = *reinterpret_cast<const float4*>(a.bdw + ch);
+        // this chunk's fc2 weights and its depthwise taps: requested in front of the barrier, used behind it
+        // (C = 64: the 32 fragment registers do not fit beside the depthwise window — fetched behind the depthwise stage instead)
+        h8 vh[2][NN], vl[2][NN];
+        auto load_w2 = [&]() {
 #pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
+            for (int st = 0; st < 2; ++st)
 #pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const float4 v = *reinterpret_cast<const float4*>(s_h1 + ((iy + dy) * MF_TW + ix + dx) * MF_HS + 4 * q);
-                    const float4 w = *reinterpret_cast<const float4*>(a.w9 + (int64_t)(dy * 3 + dx) * HD + ch);
-                    acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y); acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+                for (int n = 0; n < NN; ++n) {
+                    vh[st][n] = *reinterpret_cast<const h8*>(a.w2s + (int64_t)(n * 32 + col) * HD + hc * 32 + 16 * st + 8 * kh);
+                    vl[st][n] = *reinterpret_cast<const h8*>(a.w2s + (int64_t)C * HD + (int64_t)(n * 32 + col) * HD + hc * 32 + 16 * st + 8 * kh);
                 }
-            const float4 gv = make_float4(mf_gelu(acc.x), mf_gelu(acc.y), mf_gelu(acc.z), mf_gelu(acc.w));
-            gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, __builtin_fmaxf(__builtin_fabsf(gv.x), __builtin_fabsf(gv.y))),
-                                   __builtin_fmaxf(__builtin_fabsf(gv.z), __builtin_fabsf(gv.w)));
-            *reinterpret_cast<float4*>(s_g + ((iy + 1) * MF_TW + ix + 1) * MF_HS + 4 * q) = gv;
+        };
+        if (C <= 32) load_w2();
+        float4 tap[9];
+#pragma unroll
+        for (int t9 = 0; t9 < 9; ++t9) tap[t9] = *reinterpret_cast<const float4*>(a.w9 + (int64_t)t9 * HD + hc * 32 + 4 * dq);
+        const float4 dbias = *reinterpret_cast<const float4*>(a.bdw + hc * 32 + 4 * dq);
+        __syncthreads();
+        // ---- depthwise 3x3 + bias + GELU on the inner 6 x 30 tokens
+        float gmax = 0.f;
+        if (dix < MF_IW) {
+            float4 win[3][3];                                        // halo rows iy .. iy + 2, halo columns dix .. dix + 2
+            const float* hp = s_h1 + dix * MF_HS + 4 * dq;
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) win[r][dx] = *reinterpret_cast<const float4*>(hp + (r * MF_TW + dx) * MF_HS);
+#pragma unroll
+            for (int iy = 0; iy < MF_IH; ++iy) {
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) win[(iy + 2) % 3][dx] = *reinterpret_cast<const float4*>(hp + ((iy + 2) * MF_TW + dx) * MF_HS);
+                float4 acc = dbias;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const float4 v = win[(iy + dy) % 3][dx], w = tap[dy * 3 + dx];
+                        acc.x = fmaf(v.x, w.x, acc.x); acc.y = fmaf(v.y, w.y, acc.y); acc.z = fmaf(v.z, w.z, acc.z); acc.w = fmaf(v.w, w.w, acc.w);
+                    }
+                const float4 gv = make_float4(mf_gelu(acc.x), mf_gelu(acc.y), mf_gelu(acc.z), mf_gelu(acc.w));
+                gmax = __builtin_fmaxf(__builtin_fmaxf(gmax, __builtin_fmaxf(__builtin_fabsf(gv.x), __builtin_fabsf(gv.y))),
+                                       __builtin_fmaxf(__builtin_fabsf(gv.z), __builtin_fabsf(gv.w)));
+                *reinterpret_cast<float4*>(s_g + ((iy + 1) * MF_TW + dix + 1) * MF_HS + 4 * dq) = gv;
+            }
         }
+        if (C > 32) load_w2();
+        if (C <= 32 && hc + 1 < NCH) load_w1(hc + 1);                 // the next chunk's fc1 rows travel during this chunk's fc2
         // (a NaN fails the comparison and takes the f16 path, where it stays a NaN; an infinity takes the float32 path)
         const bool big = __syncthreads_or(gmax >= 32768.0f) != 0;
         // ---- fc2: partial sums over these 32 hidden channels (halo tokens multiply whatever their LDS rows hold: their columns are dropped)
         if (!big) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                h8 wh[NN], wl[NN];
-#pragma unroll
-                for (int n = 0; n < NN; ++n) {
-                    wh[n] = *reinterpret_cast<const h8*>(a.w2s + (int64_t)(n * 32 + col) * HD + hc * 32 + 16 * st + 8 * kh);
-                    wl[n] = *reinterpret_cast<const h8*>(a.w2s + (int64_t)C * HD + (int64_t)(n * 32 + col) * HD + hc * 32 + 16 * st + 8 * kh);
-                }
 #pragma unroll
                 for (int m = 0; m < 2; ++m) {
                     const float* gp = s_g + ((2 * wave + m) * MF_TW + col) * MF_HS + 16 * st + 8 * kh;
@@ -208,9 +238,9 @@ void mixffn_kernel(mf_args a)
                     mf_split8(*reinterpret_cast<const float4*>(gp), *reinterpret_cast<const float4*>(gp + 4), gh, gl);
 #pragma unroll
                     for (int n = 0; n < NN; ++n) {
-                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], gh, acc2[m][n], 0, 0, 0);
-                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[n], gh, acc2[m][n], 0, 0, 0);
-                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[n], gl, acc2[m][n], 0, 0, 0);
+                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[st][n], gh, acc2[m][n], 0, 0, 0);
+                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[st][n], gh, acc2[m][n], 0, 0, 0);
+                        acc2[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[st][n], gl, acc2[m][n], 0, 0, 0);
                     }
                 }
             }

@@ -2,17 +2,25 @@
 # tools/make_profiles.py turns the rocprofv3 directories into the committed CSV summaries).
 set -x
 cd $GRAFT_REPO_ROOT
-R=r03
+R=${R:-r04}
+PART=${PART:-all}          # a: HIP-event lines + the step's trace / counters; b: kernel_bench trace / counters, B5, train (a gpurun call is capped at 20 min)
+export TMPDIR=/tmp
+B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0"
+K="$GRAFT_REPO_ROOT/tools/kernel_bench.py --iters 2 --only winograd,gemm_l4,gemm_aspp,combine,fog,night,rain,snow,normalize,segformer_head,stats,ece,aspp_dep,dwconv,depth_head_fused,upconv_forms,mixffn"
+O=$GRAFT_REPO_ROOT/gpurun_out
+if [ "$PART" != "b" ]; then
+cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python tools/kernel_bench.py --iters 10 > gpurun_out/${R}_kernel_bench_hip_events.log 2>&1; echo "kernel_bench exit $?"
 timeout -k 10 400 python bench.py > gpurun_out/${R}_bench_line_default.json 2> gpurun_out/${R}_bench_line_default.err; echo "bench exit $?"
-timeout -k 10 500 python bench.py --model b5_r101 > gpurun_out/${R}_bench_line_b5_r101_bf16.json 2> gpurun_out/${R}_bench_line_b5.err; echo "bench b5 exit $?"
-cd /tmp && export TMPDIR=/tmp
-B="$GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 2 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0"
-K="$GRAFT_REPO_ROOT/tools/kernel_bench.py --iters 2 --only winograd,gemm_l4,gemm_aspp,combine,fog,night,rain,snow,normalize,segformer_head,stats,ece,aspp_dep,dwconv"
-O=$GRAFT_REPO_ROOT/gpurun_out
+cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_step -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0 > $O/${R}_prof_step.log 2>&1; echo "prof step exit $?"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_step_fetch -o step -- python3 $B > $O/${R}_prof_step_fetch.log 2>&1; echo "step fetch exit $?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_step_write -o step -- python3 $B > $O/${R}_prof_step_write.log 2>&1; echo "step write exit $?"
+fi
+if [ "$PART" != "a" ]; then
+cd $GRAFT_REPO_ROOT
+timeout -k 10 500 python bench.py --model b5_r101 > gpurun_out/${R}_bench_line_b5_r101_bf16.json 2> gpurun_out/${R}_bench_line_b5.err; echo "bench b5 exit $?"
+cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_kb_trace -o kb -- python3 $K > $O/${R}_prof_kb_trace.log 2>&1; echo "kb trace exit $?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_kb_fetch -o kb -- python3 $K > $O/${R}_prof_kb_fetch.log 2>&1; echo "kb fetch exit $?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_kb_write -o kb -- python3 $K > $O/${R}_prof_kb_write.log 2>&1; echo "kb write exit $?"
@@ -23,6 +31,7 @@ timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_train -o train -- python3 $GRAFT_REPO_ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --kernel-steps 0 > $O/${R}_prof_train.log 2>&1; echo "prof train exit $?"
 cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python bench.py --mode train --steps 3 --warmup 2 > gpurun_out/${R}_bench_line_train_1024x2048_bs8.json 2> gpurun_out/${R}_bench_line_train.err; echo "bench train exit $?"
+fi
 du -sh $O/${R}_prof_* | tail -8
 # Afterwards, in the repo (CPU is enough):
 #   bash tools/make_round_profiles.sh        # or, step by step:

@@ -1,13 +1,13 @@
 # Turns the rocprofv3 directories of tools/gpu_profile_session.sh (merged back into gpurun_out/) into the committed summaries under
 # profiles/ for round $R (CPU is enough):  bash tools/make_round_profiles.sh
 set -e
-R=${R:-r03}
+R=${R:-r04}
 python tools/make_profiles.py step gpurun_out/${R}_prof_step ensemble_stats_kernel profiles/${R}_bench_step_kernels.csv \
   "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0 (the shipped build of the round, ingestion on)"
 python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_step gpurun_out/${R}_prof_step_fetch gpurun_out/${R}_prof_step_write profiles/${R}_bench_step_stats_and_traffic.csv \
   "bench.py under rocprofv3: --kernel-trace --stats pass + separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; mean per dispatch over the launches of the timed steps" mean
 python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_kb_trace gpurun_out/${R}_prof_kb_fetch gpurun_out/${R}_prof_kb_write profiles/${R}_kernel_bench_stats_and_traffic.csv \
-  "tools/kernel_bench.py --iters 2 --only winograd,gemm_l4,gemm_aspp,combine,fog,night,rain,snow,normalize,segformer_head,stats,ece,aspp_dep,dwconv under rocprofv3 (kernel trace + separate FETCH_SIZE / WRITE_SIZE passes), median per dispatch"
+  "tools/kernel_bench.py --iters 2 --only winograd,gemm_l4,gemm_aspp,combine,fog,night,rain,snow,normalize,segformer_head,stats,ece,aspp_dep,dwconv,depth_head_fused,upconv_forms,mixffn under rocprofv3 (kernel trace + separate FETCH_SIZE / WRITE_SIZE passes), median per dispatch"
 python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_b5 gpurun_out/${R}_prof_b5_fetch gpurun_out/${R}_prof_b5_write profiles/${R}_bench_b5_step_stats_and_traffic.csv \
   "bench.py --model b5_r101 (BASELINE config 5: SegFormer-B5 + DeepLabV3+-R101, bf16 MFMA path) under rocprofv3: --kernel-trace --stats pass + separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; mean per dispatch over the launches of the timed steps" mean
 cp gpurun_out/${R}_kernel_bench_hip_events.log gpurun_out/${R}_bench_line_default.json gpurun_out/${R}_bench_line_b5_r101_bf16.json gpurun_out/${R}_bench_line_train_1024x2048_bs8.json profiles/

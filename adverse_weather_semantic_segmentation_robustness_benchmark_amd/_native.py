@@ -93,6 +93,8 @@ SIGNATURES = {
                                        c_f, c_f, c_p, c_p]),
     "awseg_conv_gemm_split_bias_act": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "awseg_conv_rows_gemm_split_bias_act": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
+    "awseg_dwconv3x3_wgrad_workspace": (c_i64, [c_i64, c_i, c_i, c_i]),
+    "awseg_dwconv3x3_wgrad_nhwc": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "awseg_mixffn_fused": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_maxpool3x3s2_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "awseg_maxpool3x3s2_bias_relu_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),

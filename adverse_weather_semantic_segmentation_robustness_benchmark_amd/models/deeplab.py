@@ -144,6 +144,17 @@ class SeparableConv2d(nn.Sequential):
             Conv2d(in_ch, in_ch, kernel_size, padding=padding, dilation=dilation, groups=in_ch, bias=False),
             Conv2d(in_ch, out_ch, 1, bias=bias))
 
+    def forward(self, x):
+        dw, pw = self[0], self[1]
+        if torch.is_grad_enabled() and x.dim() == 4 and ops.depthwise_conv3x3_train_ok(dw, x) and Conv2d.linear_in_training and pw.kernel_size == (1, 1):
+            # training: depthwise half on this repo's NHWC kernels (forward, input gradient, weight gradient) and the pointwise half as
+            # the GEMM it is, on the same channels-last tensor — MIOpen's picks for the grouped convolution cost 37 + 5 + 6 ms per call
+            b, c, h, w = x.shape
+            y = ops.depthwise_conv3x3_nhwc_train(x.permute(0, 2, 3, 1).contiguous(), dw)
+            z = F.linear(y.view(b * h * w, c), pw.weight.view(pw.out_channels, c), pw.bias)
+            return z.view(b, h, w, pw.out_channels).permute(0, 3, 1, 2).contiguous()
+        return super().forward(x)
+
 
 class ASPPSeparableConv(nn.Sequential):
     def __init__(self, in_ch, out_ch, dilation):

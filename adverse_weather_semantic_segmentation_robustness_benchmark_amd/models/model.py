@@ -76,6 +76,26 @@ def _build_mit(model_name: str, pretrained: bool):
     return SegformerModel(cfg)
 
 
+def _mit_dwconv_forward(self, hidden_states, height, width):
+    """transformers' SegformerDepthWiseConv.forward with the TRAINING pass of the depthwise 3x3 on this repo's kernels: the tokens
+    [B, N, C] ARE the NHWC map, so no transposes either way (the library forward hands MIOpen a channels-last view, whose grouped
+    convolution kernels cost 37 ms per weight gradient at 1024x2048: a quarter of the training step).  Eval and CPU: as written."""
+    conv = self.dwconv
+    if (torch.is_grad_enabled() and hidden_states.dim() == 3 and hidden_states.is_contiguous() and ops.depthwise_conv3x3_train_ok(conv, hidden_states)):
+        b, n, c = hidden_states.shape
+        return ops.depthwise_conv3x3_nhwc_train(hidden_states.view(b, height, width, c), conv).view(b, n, c)
+    b, n, c = hidden_states.shape
+    x = hidden_states.transpose(1, 2).view(b, c, height, width)
+    return conv(x).flatten(2).transpose(1, 2)
+
+
+def _patch_mit_dwconv(seg) -> None:
+    import types
+    for mod in seg.modules():
+        if type(mod).__name__ == "SegformerDepthWiseConv" and isinstance(getattr(mod, "dwconv", None), nn.Conv2d):
+            mod.forward = types.MethodType(_mit_dwconv_forward, mod)
+
+
 class DepthEstimationHead(nn.Module):
     """PKG/models/model.py:16-78 — same Sequential layout (keys depth_head.{0,1,4,5,7})."""
 
@@ -197,6 +217,7 @@ class SegFormerModel(nn.Module):
         self.num_classes = num_classes
         self.include_depth = include_depth
         self.segformer = _build_mit(model_name, pretrained)
+        _patch_mit_dwconv(self.segformer)
         self.feature_dim = getattr(self.segformer.config, "hidden_sizes", [256])[-1]
         self.segmentation_head = nn.Sequential(
             nn.Conv2d(self.feature_dim, 256, kernel_size=3, padding=1),

@@ -491,6 +491,59 @@ def dwconv3x3_nhwc(x: torch.Tensor, w9: torch.Tensor, bias: Optional[torch.Tenso
     return out
 
 
+def dwconv3x3_wgrad_nhwc(x: torch.Tensor, dy: torch.Tensor, dilation: int = 1, want_bias: bool = True):
+    """Weight (and bias) gradient of the depthwise 3x3 on NHWC tensors: (dW9 [9,C] tap-major, db [C] or None)."""
+    x, dy = x.contiguous(), dy.contiguous()
+    b, h, w, c = x.shape
+    ws = N.workspace.get(x.device, N.lib().awseg_dwconv3x3_wgrad_workspace(b, h, w, c), tag="dwgrad")
+    dw9 = torch.empty(9, c, dtype=torch.float32, device=x.device)
+    db = torch.empty(c, dtype=torch.float32, device=x.device) if want_bias else None
+    N.call("awseg_dwconv3x3_wgrad_nhwc", N.ptr(x), N.ptr(dy), b, h, w, c, int(dilation), N.ptr(ws), N.ptr(dw9), N.ptr(db), N.stream())
+    return dw9, db
+
+
+DW_TRAIN = os.environ.get("AWSEG_DW_TRAIN", "1") != "0"          # depthwise 3x3 convolutions of the TRAINING graph on this repo's kernels
+
+
+class _DepthwiseConv3x3NHWC(torch.autograd.Function):
+    """Depthwise 3x3 (stride 1, padding = dilation, groups = channels) on an NHWC tensor under autograd: forward and input gradient on
+    awseg_dwconv3x3_nhwc (the gradient with flipped taps), weight / bias gradient on awseg_dwconv3x3_wgrad_nhwc.  MIOpen's
+    immediate-mode picks for these layers cost 37 ms (weight gradient), 5 ms (input gradient) and 6 ms (forward) per call at
+    1024x2048 — 14 + 14 + 8 calls a training step (profiles/r03_train_step_kernels.csv)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, dilation):
+        c = weight.shape[0]
+        w9 = weight.view(c, 9).t().contiguous()
+        ctx.save_for_backward(x, weight)
+        ctx.dilation, ctx.has_bias = int(dilation), bias is not None
+        return dwconv3x3_nhwc(x, w9, bias, 0, dilation=dilation)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        c = weight.shape[0]
+        g = g.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = dwconv3x3_nhwc(g, weight.view(c, 9).flip(1).t().contiguous(), None, 0, dilation=ctx.dilation)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw9, db = dwconv3x3_wgrad_nhwc(x, g, ctx.dilation, want_bias=ctx.has_bias)
+            dw = dw9.t().reshape(c, 1, 3, 3)
+        return dx, dw, db, None
+
+
+def depthwise_conv3x3_train_ok(conv, x: torch.Tensor) -> bool:
+    """An nn.Conv2d this Function computes: depthwise 3x3, stride 1, padding == dilation, float32 on the GPU, C % 4 == 0."""
+    return (DW_TRAIN and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (3, 3) and conv.stride == (1, 1)
+            and conv.groups == conv.in_channels == conv.out_channels and conv.padding == conv.dilation and conv.dilation[0] == conv.dilation[1]
+            and conv.in_channels % 4 == 0 and conv.padding_mode == "zeros")
+
+
+def depthwise_conv3x3_nhwc_train(x_nhwc: torch.Tensor, conv) -> torch.Tensor:
+    return _DepthwiseConv3x3NHWC.apply(x_nhwc, conv.weight, conv.bias, conv.dilation[0])
+
+
 def bias_act_nhwc_(x_nhwc: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
                    act: int = 0) -> torch.Tensor:
     """In place: x = act(x + bias[c] (+ residual)) on a contiguous [..., C] float32 tensor."""

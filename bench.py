@@ -582,6 +582,18 @@ def train_main(args):
             cpu = cpu_train_baseline(model, H, W, C)
         except Exception as e:  # noqa: BLE001
             cpu = {"value": None, "unit": "images/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+    # every replica must hold the same parameters after the timed steps (data-parallel averaging): the per-rank float64 sums of all
+    # parameters, gathered — rank 0 reports them and whether they are identical (tests/test_gpu_configs.py, RCCL-gated)
+    with torch.no_grad():
+        psum = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+        pabs = torch.stack([p.detach().double().abs().sum() for p in model.parameters()]).sum().reshape(1)
+    mine2 = torch.cat([psum, pabs]).to(dev)
+    if parallel.is_dist():
+        gathered = [torch.zeros_like(mine2) for _ in range(world)]
+        torch.distributed.all_gather(gathered, mine2)
+    else:
+        gathered = [mine2]
+    replica_sums = [[float(v) for v in g.cpu()] for g in gathered]
     if rank == 0:
         line = {
             "metric": f"images/sec ({H}x{W}, AdverseWeatherTrainer train step: ensemble + FogDensityAwareLoss + depth heads)",
@@ -597,6 +609,7 @@ def train_main(args):
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
             "peak_hbm_gb": round(torch.cuda.max_memory_allocated(dev) / 2 ** 30, 1),
             "losses": {k: round(float(v), 6) for k, v in res.items()},
+            "replica_parameter_sums": replica_sums, "replicas_identical": all(r == replica_sums[0] for r in replica_sums),
         }
         print(json.dumps(line), flush=True)
     if parallel.is_dist():

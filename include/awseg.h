@@ -615,6 +615,17 @@ int awseg_attention_d32(const float* q, const float* k, const float* v, float* o
 int awseg_attention_d32_split(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                               int n_queries, int n_keys, float scale, awseg_stream_t stream);
 
+/* awseg_dwconv3x3_wgrad_nhwc: weight and bias gradient of a depthwise 3x3 convolution (stride 1, zero padding = dilation) on float32
+ * NHWC tensors x, dy [batch, height, width, channels] — the backward of the MiT Mix-FFN's depthwise convolution (transformers'
+ * SegformerDepthWiseConv, PKG/models/model.py:120-130) and of the DeepLabV3+ separable convolutions (:259-265) inside
+ * AdverseWeatherTrainer.train_epoch's loss.backward() (PKG/training/trainer.py:333).  dw9 float32 [9][channels] tap-major
+ * (ky * 3 + kx), db float32 [channels] or NULL.  channels % 4 == 0; workspace of awseg_dwconv3x3_wgrad_workspace(...) bytes
+ * (per-chunk partial sums, folded in a fixed order: deterministic).  The forward and the input gradient are awseg_dwconv3x3_nhwc
+ * (the latter on dy with the taps flipped). */
+int64_t awseg_dwconv3x3_wgrad_workspace(int64_t batch, int height, int width, int channels);
+int awseg_dwconv3x3_wgrad_nhwc(const float* x, const float* dy, int64_t batch, int height, int width, int channels, int dilation,
+                               void* workspace, float* dw9, float* db, awseg_stream_t stream);
+
 /* awseg_mixffn_fused: one MiT Mix-FFN (transformers' SegformerLayer: hidden = hidden + MixFFN(layer_norm_2(hidden)), MixFFN = dense1
  * -> depthwise 3x3 (padding 1, bias) -> GELU (erf) -> dense2; the encoder PKG/models/model.py:120-130 configures and :193-197 calls)
  * as ONE tile kernel: out[b,y,x,:] = tok + w2 . gelu(dwconv(w1 . layernorm(tok) + b1) + dw_bias) + b2 on float32 NHWC tokens

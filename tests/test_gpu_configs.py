@@ -135,6 +135,31 @@ def test_c3_two_gpus_over_rccl_reproduce_the_single_gpu_miou(native):
     assert one["miou"] == two["miou"], "pooled mIoU dict differs between 1 and 2 GPUs"
 
 
+def test_c4_two_ranks_on_one_gpu_over_gloo_keep_the_replicas_identical(native):
+    """The same check on a one-GPU lease: two ranks share the device, gradients averaged over gloo (bench.py falls back to it when
+    there are more ranks than devices) — the trainer's bucketed all-reduce path end to end, minus RCCL itself."""
+    two = _bench_line("--gpus", "2", "--mode", "train", "--steps", "1", "--warmup", "1", "--batch", "2", "--height", "128", "--width", "256",
+                      "--no-cpu-baseline", "--kernel-steps", "0")
+    print("N=2 train (gloo, one GPU):", two["value"], two["losses"], two["replica_parameter_sums"])
+    assert two["n_gpus"] == 2 and two["config"]["dist_backend"] == "gloo" and two["rccl_ranks"] == 0
+    assert two["replicas_identical"] and len(two["replica_parameter_sums"]) == 2
+    assert all(v == v for v in two["losses"].values())
+
+
+def test_c4_two_gpus_over_rccl_keep_the_replicas_identical(native):
+    """BASELINE configs[3] on the smallest multi-GPU lease: two ranks, one device each, AdverseWeatherTrainer steps with the bucketed
+    gradient all-reduce over RCCL — after the steps both replicas hold bit-identical parameters (the gloo twin of this check:
+    tests/test_abi_and_host.py::test_two_rank_gloo_counter_allreduce_matches_single_process)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("one-GPU lease: RCCL needs one device per rank (the 2-rank gloo test covers the gradient buckets)")
+    two = _bench_line("--gpus", "2", "--mode", "train", "--steps", "2", "--warmup", "1", "--batch", "2", "--height", "256", "--width", "512",
+                      "--no-cpu-baseline", "--kernel-steps", "0")
+    print("N=2 train:", two["value"], two["losses"], two["replica_parameter_sums"])
+    assert two["n_gpus"] == 2 and two["rccl_ranks"] == 2 and two["config"]["dist_backend"] == "nccl"
+    assert two["replicas_identical"] and len(two["replica_parameter_sums"]) == 2
+    assert all(v == v for v in two["losses"].values())                    # finite losses
+
+
 @pytest.mark.parametrize("env", [{"AWSEG_WINO8": "0"}, {"AWSEG_WINO8": "1"}, {"AWSEG_WINO8": "2"}, {"AWSEG_WINO8_TPB": "3"}, {"AWSEG_WINO8_TPB": "64"}, {"AWSEG_GEMM_SPLIT_V3": "0"}, {"AWSEG_G3_STAGGER": "0"}, {"AWSEG_G3_HALF": "0"}, {"AWSEG_G3_HALF": "2"}, {"AWSEG_G3_HALF": "2", "AWSEG_G3_THREE": "0"},
                                  {"AWSEG_ASPP_LDS": "0"}, {"AWSEG_ASPP_LDS": "0", "AWSEG_ASPP_ROWS": "0"}, {"AWSEG_STATS_WIDE": "0"}])
 def test_round2_kernels_stay_selectable_and_correct(env):

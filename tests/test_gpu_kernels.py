@@ -1467,3 +1467,31 @@ def test_mixffn_fused_matches_float64_ops(ops, cfg):
     assert ops.mixffn_fused(torch.zeros(1, 4, 4, 160, device="cuda"), torch.ones(160, device="cuda"), torch.zeros(160, device="cuda"), 1e-6,
                             torch.zeros(640, 160, device="cuda"), torch.zeros(640, device="cuda"), torch.zeros(9, 640, device="cuda"),
                             torch.zeros(640, device="cuda"), torch.zeros(160, 640, device="cuda"), torch.zeros(160, device="cuda")) is None
+
+
+# ------------------------------------------------------------------ depthwise 3x3 under autograd (training step, dwtrain.hip)
+@pytest.mark.parametrize("cfg", [(2, 9, 13, 8, 1, True), (1, 33, 47, 128, 1, True), (2, 20, 24, 64, 12, False), (1, 64, 96, 304, 1, False), (3, 5, 5, 4, 2, True)])
+def test_depthwise_conv3x3_train_matches_torch_autograd(ops, cfg):
+    """_DepthwiseConv3x3NHWC (forward / input gradient on awseg_dwconv3x3_nhwc, weight + bias gradient on awseg_dwconv3x3_wgrad_nhwc)
+    against torch's float64 autograd of the same nn.Conv2d: dilation 1 / 2 / 12 (larger than the frame's half: every tap clipped
+    somewhere), ragged chunks, channel counts below and above one 32-quad slice."""
+    B, H, W, C, d, has_bias = cfg
+    g = torch.Generator(device="cuda").manual_seed(sum(cfg[:5]))
+    conv = torch.nn.Conv2d(C, C, 3, 1, d, d, groups=C, bias=has_bias).cuda()
+    x = torch.randn(B, H, W, C, device="cuda", generator=g, requires_grad=True)
+    gy = torch.randn(B, H, W, C, device="cuda", generator=g)
+    assert ops.depthwise_conv3x3_train_ok(conv, x)
+    y = ops.depthwise_conv3x3_nhwc_train(x, conv)
+    y.backward(gy)
+    got = (y.detach(), x.grad.clone(), conv.weight.grad.clone(), None if not has_bias else conv.bias.grad.clone())
+    ref_conv = torch.nn.Conv2d(C, C, 3, 1, d, d, groups=C, bias=has_bias).cuda().double()
+    ref_conv.load_state_dict(conv.state_dict())
+    xd = x.detach().double().permute(0, 3, 1, 2).requires_grad_(True)
+    yr = ref_conv(xd)
+    yr.backward(gy.double().permute(0, 3, 1, 2))
+    ref = (yr.detach().permute(0, 2, 3, 1), xd.grad.permute(0, 2, 3, 1), ref_conv.weight.grad, None if not has_bias else ref_conv.bias.grad)
+    for name, a, b in zip(("forward", "input gradient", "weight gradient", "bias gradient"), got, ref):
+        if a is None:
+            continue
+        err = (a.double() - b).abs().max().item()
+        assert err < 2e-5 * max(1.0, b.abs().max().item()), (cfg, name, err)

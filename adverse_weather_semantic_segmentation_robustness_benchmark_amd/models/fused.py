@@ -444,7 +444,8 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
             tok = _linear_residual(o, a.o_proj, tok)
             m = blk.mlp
             ln2 = blk.layernorm_after
-            if (ops.MIXFFN_FUSED and ops.PRECISION != "bf16" and tok.is_cuda and tok.dtype == torch.float32 and C in (32, 64)
+            # (also in bf16 mode — MiT-B5's stage 1 is 64 wide: the fused kernel computes in float32 grade, above what that mode asks for)
+            if (ops.MIXFFN_FUSED and tok.is_cuda and tok.dtype == torch.float32 and C in (32, 64)
                     and getattr(seg.config, "hidden_act", "gelu") == "gelu" and m.fc1.bias is not None and m.fc2.bias is not None
                     and m.dwconv.dwconv.bias is not None and ln2.weight is not None and ln2.bias is not None):
                 # the whole Mix-FFN as one tile kernel: the 4x-wide hidden map never reaches HBM (four launches and four passes otherwise)

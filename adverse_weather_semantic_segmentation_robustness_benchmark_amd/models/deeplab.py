@@ -14,6 +14,8 @@ Two forwards over the same parameters:
 """
 from __future__ import annotations
 
+import os
+
 from typing import List
 
 import torch
@@ -32,6 +34,10 @@ class Conv2d(nn.Conv2d):
     reference graph the tests compare against is unchanged."""
 
     linear_in_training = True
+    # (AWSEG_TRAIN_KEEP_CL=0: copy back to NCHW after every 1x1, as in round 3)  The F.linear result stays a channels-last-strided tensor — BatchNorm / ReLU / the
+    # residual add behind it run on that layout and the NEXT 1x1 reads it without a copy; only a spatial convolution copies its input
+    # back to NCHW (MIOpen's NHWC picks for those are the slow ones, DESIGN.md 8a).  Halves the layout copies of a bottleneck.
+    keep_channels_last = os.environ.get("AWSEG_TRAIN_KEEP_CL", "1") != "0"
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if (Conv2d.linear_in_training and x.is_cuda and torch.is_grad_enabled() and self.kernel_size == (1, 1) and self.groups == 1
@@ -40,7 +46,10 @@ class Conv2d(nn.Conv2d):
                 x = x[:, :, ::self.stride[0], ::self.stride[1]]
             b, c, h, w = x.shape
             y = F.linear(x.permute(0, 2, 3, 1).reshape(b * h * w, c), self.weight.view(self.out_channels, c), self.bias)
-            return y.view(b, h, w, self.out_channels).permute(0, 3, 1, 2).contiguous()
+            y = y.view(b, h, w, self.out_channels).permute(0, 3, 1, 2)
+            return y if Conv2d.keep_channels_last else y.contiguous()
+        if Conv2d.keep_channels_last and x.is_cuda and torch.is_grad_enabled() and x.dim() == 4 and not x.is_contiguous():
+            x = x.contiguous()
         return super().forward(x)
 
 

@@ -336,7 +336,10 @@ class DeepLabV3Plus(nn.Module):
             # the classifier as a GEMM on the NHWC rows (deterministic accumulation order; MIOpen's 1x1 path is not promised to be)
             dl = fused.nhwc_view(dec)
             Bq, H4, W4, Cd = dl.shape
-            y2 = ops.gemm_bias_act(dl.reshape(Bq * H4 * W4, Cd), head.weight.view(head.out_channels, Cd), head.bias, 0, split=False)
+            # (the dispatcher's choice: on 10^6 rows the 19-class head is one masked 64-column tile of this repo's split-operand GEMM,
+            # bound by reading the decoder map once; smaller problems stay on the library's float32 kernel)
+            y2 = ops.gemm_bias_act(dl.reshape(Bq * H4 * W4, Cd), head.weight.view(head.out_channels, Cd), head.bias, 0,
+                                   w_split=fused.split_weights(head, head.weight.view(head.out_channels, Cd), Bq * H4 * W4))
             low = y2.view(Bq, H4, W4, -1).permute(0, 3, 1, 2).contiguous()  # [B,C,H/4,W/4] NCHW (small)
         else:
             low = head(dec).contiguous()

@@ -274,9 +274,24 @@ class SegFormerModel(nn.Module):
         up = None
         if not seg_hip or (dh is not None and not dep_hip):
             up = F.interpolate(feats, size=(H, W), mode="bilinear", align_corners=False)     # model.py:211
-        results = {"segmentation": head[1:](ops.upconv3x3_train(tok, head[0].weight, head[0].bias, H, W)) if seg_hip else head(up)}
+        def tail(seq, z):
+            # the layers behind the first convolution: every BatchNorm2d -> ReLU [-> Dropout2d] run is ONE fused pass forward and two
+            # backward (ops._BNReLUDropout2d: same batch statistics, same Dropout2d draw); everything else is the reference's module
+            mods = list(seq)[1:]
+            i = 0
+            while i < len(mods):
+                nxt = mods[i + 1] if i + 1 < len(mods) else None
+                drop = mods[i + 2] if (i + 2 < len(mods) and isinstance(mods[i + 2], nn.Dropout2d)) else None
+                if isinstance(mods[i], nn.BatchNorm2d) and nxt is not None and ops.bn_relu_dropout2d_train_ok(z, mods[i], nxt, drop):
+                    z = ops.bn_relu_dropout2d_train(z, mods[i], drop)
+                    i += 3 if drop is not None else 2
+                else:
+                    z = mods[i](z)
+                    i += 1
+            return z
+        results = {"segmentation": tail(head, ops.upconv3x3_train(tok, head[0].weight, head[0].bias, H, W)) if seg_hip else head(up)}
         if dh is not None:
-            results["depth"] = dh[1:](ops.upconv3x3_train(tok, dh[0].weight, dh[0].bias, H, W)) if dep_hip else self.depth_head(up)
+            results["depth"] = tail(dh, ops.upconv3x3_train(tok, dh[0].weight, dh[0].bias, H, W)) if dep_hip else self.depth_head(up)
         return results
 
     @torch.no_grad()
@@ -326,8 +341,7 @@ class DeepLabV3PlusModel(nn.Module):
     def _forward_hip(self, x):
         if not x.is_cuda:
             raise N.AwsegError("eval-mode forward runs HIP kernels: it needs CUDA (HIP) tensors; no CPU fallback exists")
-        xc = x.contiguous(memory_format=torch.channels_last)
-        seg, enc = self.model.forward_fused(xc, return_features=True)
+        seg, enc = self.model.forward_fused(x, return_features=True)     # (the stem reads x in place; see fused.resnet_features)
         results = {"segmentation": seg.contiguous()}
         if self.include_depth:
             # the reference runs the encoder a second time here (model.py:358); in eval mode the
@@ -374,8 +388,9 @@ class EnsembleModel(nn.Module):
         """members -> ONE pass: combine, /temperature, argmax, confusion (slots: overall + condition).
         stats = (edges, ece_bins, auroc_hist, lo, hi): also accumulate the calibration / disagreement statistics in that pass
         when nothing per-pixel is asked for (`self._stats_fused` tells the caller whether it happened)."""
-        if x.is_cuda and x.dim() == 4 and not x.is_contiguous(memory_format=torch.channels_last):
-            x = x.contiguous(memory_format=torch.channels_last)    # both members start from NHWC memory: convert once, not once each
+        # (no channels-last copy of the frames here: both 7x7 stems read the zero-padded 4-channel image that fused._stem_rows builds
+        # from the input in whatever layout it has — once per forward, shared through stem_scope; a member whose stem does not take
+        # that path converts for itself)
         self.deeplabv3plus._defer_depth_upsample = self.include_depth
         try:
             with fused.stem_scope():                               # the two 7x7 stems share one zero-padded copy of the input

@@ -544,6 +544,67 @@ def depthwise_conv3x3_nhwc_train(x_nhwc: torch.Tensor, conv) -> torch.Tensor:
     return _DepthwiseConv3x3NHWC.apply(x_nhwc, conv.weight, conv.bias, conv.dilation[0])
 
 
+BN_TRAIN = os.environ.get("AWSEG_BN_TRAIN", "1") != "0"          # BatchNorm2d -> ReLU -> Dropout2d of the training heads as fused HIP passes
+
+
+class _BNReLUDropout2d(torch.autograd.Function):
+    """BatchNorm2d (batch statistics) -> ReLU -> Dropout2d(p) on an NCHW map under autograd (csrc/bntrain.hip): one forward pass
+    and two backward passes instead of ~15, and autograd keeps x + two per-channel vectors + the [B, C] noise instead of three
+    full-size maps.  The Dropout2d mask is drawn exactly as F.dropout2d draws it (a [B, C, 1, 1] Bernoulli(1 - p) / (1 - p) from the
+    device generator), so a seeded run consumes the same random numbers as the module graph."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, p):
+        b, c, h, w = x.shape
+        hw = h * w
+        ws = N.workspace.get(x.device, N.lib().awseg_bn_train_workspace(b, c, hw), tag="bntrain")
+        mean = torch.empty(c, dtype=torch.float32, device=x.device)
+        var = torch.empty_like(mean)
+        N.call("awseg_bn_train_stats", N.ptr(x), b, c, hw, N.ptr(ws), N.ptr(mean), N.ptr(var), N.stream())
+        invstd = torch.rsqrt(var + eps)
+        if running_mean is not None and momentum is not None:
+            n = b * hw
+            running_mean.mul_(1.0 - momentum).add_(mean, alpha=momentum)
+            running_var.mul_(1.0 - momentum).add_(var, alpha=momentum * n / max(n - 1, 1))       # running statistics keep the UNBIASED variance
+        noise = None
+        if p > 0.0:
+            noise = x.new_empty(b, c, 1, 1).bernoulli_(1.0 - p).div_(1.0 - p)                      # F.dropout2d's own draw
+        out = torch.empty_like(x)
+        N.call("awseg_bn_relu_dropout_forward", N.ptr(x), b, c, hw, N.ptr(mean), N.ptr(invstd), N.ptr(gamma.contiguous()), N.ptr(beta.contiguous()),
+               N.ptr(None if noise is None else noise.view(b, c)), N.ptr(out), N.stream())
+        ctx.save_for_backward(x, gamma, beta, mean, invstd, noise if noise is not None else mean.new_empty(0))
+        ctx.has_noise = noise is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, beta, mean, invstd, noise = ctx.saved_tensors
+        b, c, h, w = x.shape
+        hw = h * w
+        g = g.contiguous()
+        ws = N.workspace.get(x.device, N.lib().awseg_bn_train_workspace(b, c, hw), tag="bntrain")
+        dgamma, dbeta, dx = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(x)
+        N.call("awseg_bn_relu_dropout_backward", N.ptr(x), N.ptr(g), b, c, hw, N.ptr(mean), N.ptr(invstd), N.ptr(gamma.contiguous()),
+               N.ptr(beta.contiguous()), N.ptr(noise.view(b, c) if ctx.has_noise else None), N.ptr(ws), N.ptr(dgamma), N.ptr(dbeta), N.ptr(dx), N.stream())
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def bn_relu_dropout2d_train_ok(x: torch.Tensor, bn, relu, drop) -> bool:
+    """The module triple this Function computes: a training-mode affine BatchNorm2d with running statistics, nn.ReLU, and an
+    nn.Dropout2d (or None) in training mode, on a contiguous float32 NCHW map on the GPU whose planes are whole float4s."""
+    import torch.nn as nn
+    return (BN_TRAIN and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous()
+            and (x.shape[2] * x.shape[3]) % 4 == 0 and isinstance(bn, nn.BatchNorm2d) and bn.training and bn.affine
+            and bn.track_running_stats and bn.momentum is not None and isinstance(relu, nn.ReLU)
+            and (drop is None or (isinstance(drop, nn.Dropout2d) and drop.training)) and x.shape[0] <= 65535 and x.shape[1] <= 65535)
+
+
+def bn_relu_dropout2d_train(x: torch.Tensor, bn, drop=None) -> torch.Tensor:
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNReLUDropout2d.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, 0.0 if drop is None else float(drop.p))
+
+
 def bias_act_nhwc_(x_nhwc: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,
                    act: int = 0) -> torch.Tensor:
     """In place: x = act(x + bias[c] (+ residual)) on a contiguous [..., C] float32 tensor."""

@@ -149,6 +149,10 @@ def launch_work(name, args):
         _, b, h, _, _, kh, st, pdy, wo = args[:9]
         ho = (h + 2 * pdy - kh) // st + 1
         return "mfma_f16", 3 * 2.0 * b * ho * wo * args[14] * kh * 32
+    if name == "awseg_dwconv3x3_wgrad_nhwc":
+        # (x, dy, batch, H, W, C, ...): the two maps read once; the partial sums are noise beside them
+        _, _, b, h, w, c = args[:6]
+        return "hbm", 8.0 * b * h * w * c
     if name == "awseg_dwconv3x3_nhwc":
         # (x, batch, H, W, C, ...): read + write of the activation
         _, b, h, w, c = args[:5]
@@ -224,6 +228,9 @@ DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
                  "awseg_attention_d32_split": "attention_d32_split_kernel", "awseg_depth_head_fused": ("wino8p_kernel<2, false>", "wino8p_kernel<2, true>"),
                  "awseg_upconv_forms": "upconv_forms_kernel", "awseg_mixffn_fused": ("mixffn_kernel<32>", "mixffn_kernel<64>"),
                  "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0", "awseg_combine_confusion_stats": "ensemble_stats_kernel<",
+                 "awseg_upconv3x3_adjoint": "upconv3x3_adjoint_kernel", "awseg_upconv3x3_linear": "head_mfma_kernel<", "awseg_dwconv3x3_wgrad_nhwc": "dwconv3x3_wgrad_partial_kernel",
+                 "awseg_dwconv3x3_nhwc": ("dwconv3x3_nhwc_strip2_kernel", "dwconv3x3_nhwc_strip_kernel", "dwconv3x3_nhwc_kernel"),
+                 "awseg_fog_ce_forward": "fog_ce_forward", "awseg_fog_ce_backward": "fog_ce_backward",
                  "awseg_upconv3x3_bn_relu": "head_mfma_kernel<4, false", "awseg_aspp_depthwise3": ("aspp_dw3_lds_kernel", "aspp_dw3_rows_kernel", "aspp_dw3_walk_kernel")}
 
 
@@ -234,7 +241,10 @@ TRAFFIC_TABLES = ["r04_bench_step_stats_and_traffic.csv", "r03_bench_step_stats_
 B5_TRAFFIC_TABLE = "r03_bench_b5_step_stats_and_traffic.csv"     # the same passes of `bench.py --model b5_r101`
 
 
-def pmc_traffic(name, b5=False):
+TRAIN_TRAFFIC_TABLE = "r04_train_step_stats_and_traffic.csv"     # the same passes of `bench.py --mode train`
+
+
+def pmc_traffic(name, b5=False, train=False):
     """(HBM bytes per launch of `name`, source) from the committed PMC passes (profiles/: separate rocprofv3
     --pmc FETCH_SIZE and --pmc WRITE_SIZE runs; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for
     wide coalesced reads).  The first table is from THIS command (bench.py, mean over the launches of a
@@ -247,7 +257,7 @@ def pmc_traffic(name, b5=False):
         return None, None
     if isinstance(keys, str):
         keys = (keys,)
-    for fname in ([B5_TRAFFIC_TABLE] if b5 else []) + TRAFFIC_TABLES:
+    for fname in ([TRAIN_TRAFFIC_TABLE] if train else ([B5_TRAFFIC_TABLE] if b5 else []) + TRAFFIC_TABLES):
         path = ROOT / "profiles" / fname
         if not path.exists():
             continue
@@ -257,7 +267,7 @@ def pmc_traffic(name, b5=False):
         if hit:
             calls = sum(float(r["calls"]) for r in hit)
             kb = sum(float(r["calls"]) * (2.0 * float(r["FETCH_SIZE_KB"]) + float(r["WRITE_SIZE_KB"])) for r in hit) / calls
-            what = ("this command under rocprofv3, mean over a step's launches" if ("bench_step" in fname or fname == B5_TRAFFIC_TABLE)
+            what = ("this command under rocprofv3, mean over a step's launches" if ("bench_step" in fname or fname in (B5_TRAFFIC_TABLE, TRAIN_TRAFFIC_TABLE))
                     else "tools/kernel_bench.py, median per dispatch of its shapes")
             return int(kb * 1024), f"profiles/{fname} (separate --pmc FETCH_SIZE / WRITE_SIZE passes; {what})"
     return None, None
@@ -572,8 +582,9 @@ def train_main(args):
         kernels.sort(key=lambda k: -k["launches_per_step"] * k["avg_ms"])
         if kernels:
             k0 = kernels[0]
+            traffic, tsrc = pmc_traffic(k0["kernel"], train=True)
             roofline = {"kernel": k0["kernel"], "bound": ("mfma" if k0["bound"].startswith("mfma") else "hbm"), "achieved": k0["achieved"],
-                        "peak": k0["peak"], "unit": k0["unit"], "frac": k0["frac"], "traffic": None, "traffic_source": None,
+                        "peak": k0["peak"], "unit": k0["unit"], "frac": k0["frac"], "traffic": traffic, "traffic_source": tsrc,
                         "measured": "HIP events around each launch on the launching stream, one untimed step after the timed region; dominant HAND-WRITTEN "
                                     "kernel (the forward / backward convolutions are MIOpen's: profiles/r03_train_step_kernels.csv)"}
     cpu = None

@@ -1495,3 +1495,36 @@ def test_depthwise_conv3x3_train_matches_torch_autograd(ops, cfg):
             continue
         err = (a.double() - b).abs().max().item()
         assert err < 2e-5 * max(1.0, b.abs().max().item()), (cfg, name, err)
+
+
+# ------------------------------------------------------------------ BatchNorm2d -> ReLU -> Dropout2d of the training heads (bntrain.hip)
+@pytest.mark.parametrize("cfg", [(2, 8, 6, 10, 0.1), (3, 128, 32, 64, 0.1), (1, 5, 4, 4, 0.0), (2, 64, 130, 66, 0.5)])
+def test_bn_relu_dropout2d_train_matches_the_module_graph(ops, cfg):
+    """ops._BNReLUDropout2d against nn.BatchNorm2d(train) -> nn.ReLU -> nn.Dropout2d in float64 on the SAME Dropout2d draw (same
+    seed: the Function draws its mask exactly as F.dropout2d does): output, input gradient, gamma / beta gradients, running
+    statistics (unbiased variance, momentum), num_batches_tracked."""
+    B, C, H, W, p = cfg
+    g = torch.Generator(device="cuda").manual_seed(sum(int(v * 10) for v in cfg))
+    x = (torch.randn(B, C, H, W, device="cuda", generator=g) * 2.0 + 0.5).requires_grad_(True)
+    gy = torch.randn(B, C, H, W, device="cuda", generator=g)
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3); bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2.0)
+    ref_bn = torch.nn.BatchNorm2d(C).cuda().double().train()
+    ref_bn.load_state_dict(bn.state_dict())
+    relu, drop = torch.nn.ReLU(), (torch.nn.Dropout2d(p).train() if p > 0 else None)
+    assert ops.bn_relu_dropout2d_train_ok(x, bn, relu, drop)
+    torch.manual_seed(1234)
+    y = ops.bn_relu_dropout2d_train(x, bn, drop)
+    y.backward(gy)
+    xd = x.detach().double().requires_grad_(True)
+    torch.manual_seed(1234)
+    noise = torch.empty(B, C, 1, 1, device="cuda").bernoulli_(1.0 - p).div_(1.0 - p).double() if p > 0 else 1.0
+    yr = torch.relu(ref_bn(xd)) * noise
+    yr.backward(gy.double())
+    for name, a, b in (("output", y.detach(), yr.detach()), ("dx", x.grad, xd.grad), ("dgamma", bn.weight.grad, ref_bn.weight.grad),
+                       ("dbeta", bn.bias.grad, ref_bn.bias.grad), ("running_mean", bn.running_mean, ref_bn.running_mean),
+                       ("running_var", bn.running_var, ref_bn.running_var)):
+        err = (a.double() - b).abs().max().item()
+        assert err < 3e-5 * max(1.0, b.abs().max().item()), (cfg, name, err)
+    assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1

@@ -29,6 +29,9 @@ timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_b5_fetch -o step -- python3 $B5 > $O/${R}_prof_b5_fetch.log 2>&1; echo "b5 fetch exit $?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_b5_write -o step -- python3 $B5 > $O/${R}_prof_b5_write.log 2>&1; echo "b5 write exit $?"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_train -o train -- python3 $GRAFT_REPO_ROOT/bench.py --mode train --steps 2 --warmup 1 --no-cpu-baseline --kernel-steps 0 > $O/${R}_prof_train.log 2>&1; echo "prof train exit $?"
+TR="$GRAFT_REPO_ROOT/bench.py --mode train --steps 1 --warmup 1 --no-cpu-baseline --kernel-steps 0"
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_train_fetch -o train -- python3 $TR > $O/${R}_prof_train_fetch.log 2>&1; echo "train fetch exit $?"
+timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_train_write -o train -- python3 $TR > $O/${R}_prof_train_write.log 2>&1; echo "train write exit $?"
 cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python bench.py --mode train --steps 3 --warmup 2 > gpurun_out/${R}_bench_line_train_1024x2048_bs8.json 2> gpurun_out/${R}_bench_line_train.err; echo "bench train exit $?"
 fi

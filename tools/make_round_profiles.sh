@@ -10,6 +10,8 @@ python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_kb_trace gpurun_
   "tools/kernel_bench.py --iters 2 --only winograd,gemm_l4,gemm_aspp,combine,fog,night,rain,snow,normalize,segformer_head,stats,ece,aspp_dep,dwconv,depth_head_fused,upconv_forms,mixffn under rocprofv3 (kernel trace + separate FETCH_SIZE / WRITE_SIZE passes), median per dispatch"
 python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_b5 gpurun_out/${R}_prof_b5_fetch gpurun_out/${R}_prof_b5_write profiles/${R}_bench_b5_step_stats_and_traffic.csv \
   "bench.py --model b5_r101 (BASELINE config 5: SegFormer-B5 + DeepLabV3+-R101, bf16 MFMA path) under rocprofv3: --kernel-trace --stats pass + separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; mean per dispatch over the launches of the timed steps" mean
+python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_train gpurun_out/${R}_prof_train_fetch gpurun_out/${R}_prof_train_write profiles/${R}_train_step_stats_and_traffic.csv \
+  "bench.py --mode train (BASELINE config 4, 1024x2048, batch 8) under rocprofv3: --kernel-trace --stats pass (3 steps) + separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (2 steps); hand-written kernels only, mean per dispatch" mean
 cp gpurun_out/${R}_kernel_bench_hip_events.log gpurun_out/${R}_bench_line_default.json gpurun_out/${R}_bench_line_b5_r101_bf16.json gpurun_out/${R}_bench_line_train_1024x2048_bs8.json profiles/
 python tools/make_profiles.py check-log profiles/${R}_kernel_bench_hip_events.log | tail -1
 R=$R python - <<'PY'

@@ -28,7 +28,9 @@ c_i, c_i64, c_u64, c_f, c_d, c_p = C.c_int, C.c_int64, C.c_uint64, C.c_float, C.
 FOG_JOB = np.dtype([("image", "<i4"), ("_pad", "<i4"), ("beta", "<f8"), ("atmos", "<f8"), ("seed", "<u8")], align=True)
 NIGHT_JOB = np.dtype([("image", "<i4"), ("_pad", "<i4"), ("brightness", "<f8"), ("intensity", "<f8"), ("seed", "<u8")], align=True)
 PRIM_JOB = np.dtype([("image", "<i4"), ("prim_offset", "<i4"), ("prim_count", "<i4"), ("blur_ksize", "<i4"), ("intensity", "<f8")], align=True)
-assert FOG_JOB.itemsize == 32 and NIGHT_JOB.itemsize == 32 and PRIM_JOB.itemsize == 24
+WEATHER_JOB = np.dtype([("kind", "<i4"), ("image", "<i4"), ("a", "<f8"), ("b", "<f8"), ("seed", "<u8"), ("prim_offset", "<i4"), ("prim_count", "<i4")], align=True)
+WEATHER_CLEAN, WEATHER_FOG, WEATHER_RAIN, WEATHER_SNOW, WEATHER_NIGHT = 0, 1, 2, 3, 4
+assert FOG_JOB.itemsize == 32 and NIGHT_JOB.itemsize == 32 and PRIM_JOB.itemsize == 24 and WEATHER_JOB.itemsize == 40
 
 # name -> (restype, argtypes); every symbol include/awseg.h declares
 SIGNATURES = {
@@ -73,6 +75,7 @@ SIGNATURES = {
     "awseg_night_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_rain_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_snow_apply": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_weather_batch": (c_i, [c_p, c_i, c_i, c_p, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "awseg_streak_workspace": (c_i64, [c_i, c_i, c_i]),
     "awseg_fog_density_field": (c_i, [c_p, c_i, c_i64, c_u64, c_p, c_p, c_p]),
     "awseg_loss_partials": (c_i64, [c_i64, c_i64]),

@@ -74,22 +74,22 @@ __device__ __forceinline__ int reflect_101(int i, int n)
 
 // ------------------------------------------------------------------------------------ A7
 // 4 pixels per lane: 12 B in (3 dwords), three float4 out (one per channel plane).
-__global__ __launch_bounds__(kThreads)
-void normalize_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const int32_t* __restrict__ sel,
-                      norm_consts nc, float* __restrict__ out, bool vec)
+// (bodies take their block coordinates as arguments: the same code runs under its own launcher and, kind by kind, inside the ONE
+// launch of awseg_weather_batch at the end of this file)
+__device__ __forceinline__ void normalize_body(const uint8_t* __restrict__ imgs, int64_t hw, int64_t img, const norm_consts& nc,
+                                               float* __restrict__ out, bool vec, int bx, int nbx)
 {
-    const int64_t img = sel ? sel[blockIdx.y] : blockIdx.y;
     const uint8_t* src = imgs + img * hw * 3;
     float* dst = out + img * hw * 3;
     if (!vec) {
         // any H x W the reference's transform accepts (preprocessing.py:61-92): with hw % 4 != 0 (or unaligned bases) the
         // per-image bases are not dword / float4 aligned, so every pixel goes the scalar way — same operations, same bytes
-        for (int64_t p = (int64_t)blockIdx.x * kThreads + threadIdx.x; p < hw; p += (int64_t)gridDim.x * kThreads)
+        for (int64_t p = (int64_t)bx * kThreads + threadIdx.x; p < hw; p += (int64_t)nbx * kThreads)
             for (int c = 0; c < 3; ++c) dst[(int64_t)c * hw + p] = norm1(src[p * 3 + c], nc.mean[c], nc.std[c]);
         return;
     }
     const int64_t nquad = hw / 4;
-    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
+    for (int64_t q = (int64_t)bx * kThreads + threadIdx.x; q < nquad; q += (int64_t)nbx * kThreads) {
         const uint32_t* p = reinterpret_cast<const uint32_t*>(src + q * 12);
         uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
         uint8_t b[12];
@@ -102,6 +102,13 @@ void normalize_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const int32_
             *reinterpret_cast<float4*>(dst + (int64_t)c * hw + q * 4) = v;
         }
     }
+}
+
+__global__ __launch_bounds__(kThreads)
+void normalize_kernel(const uint8_t* __restrict__ imgs, int64_t hw, const int32_t* __restrict__ sel,
+                      norm_consts nc, float* __restrict__ out, bool vec)
+{
+    normalize_body(imgs, hw, sel ? sel[blockIdx.y] : blockIdx.y, nc, out, vec, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------------- next #4 (style LUT)
@@ -452,20 +459,17 @@ __device__ __forceinline__ float dpp_from_next(float v)     // lane i <- lane i 
 constexpr int kFogStripQuads = 60;                           // output quads per wave
 constexpr int kFogRing = 2 * FR + 1;                         // 17
 
-__global__ __launch_bounds__(256)
-void fog_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_fog_job> jobs, int job0,
-                      gauss_taps_f32 taps, uint8_t* __restrict__ out, float* __restrict__ norm_out,
-                      double* __restrict__ depth_out, norm_consts nc, int rows_per_strip)
+__device__ __forceinline__ void fog_strip_body(const uint8_t* __restrict__ imgs, int H, int W, const awseg_fog_job job, int job_slot,
+                                               const gauss_taps_f32& taps, uint8_t* __restrict__ out, float* __restrict__ norm_out,
+                                               double* __restrict__ depth_out, const norm_consts& nc, int rows_per_strip,
+                                               weather_lut& L, float4* s_ring, int bx, int by)
 {
-    __shared__ weather_lut L;
-    extern __shared__ float4 s_ring[];                       // [17][256]
     lut_fill(L, nc, norm_out != nullptr);
     __syncthreads();
-    const awseg_fog_job job = jobs.j[blockIdx.z];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int Wq = W >> 2;
-    const int q = blockIdx.x * kFogStripQuads - 2 + lane;    // this lane's pixel quad (may lie outside the row)
-    const int y0 = (blockIdx.y * 4 + wv) * rows_per_strip;
+    const int q = bx * kFogStripQuads - 2 + lane;            // this lane's pixel quad (may lie outside the row)
+    const int y0 = (by * 4 + wv) * rows_per_strip;
     if (y0 >= H) return;                                     // wave-uniform
     const int rows_out = (H - y0) < rows_per_strip ? (H - y0) : rows_per_strip;
     // scipy 'reflect' (d c b a | a b c d | d c b a) on pixels = the mirrored quad, its four samples in reverse order
@@ -478,7 +482,7 @@ void fog_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<a
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
-    double* ddst = depth_out ? depth_out + (int64_t)(job0 + blockIdx.z) * hw : nullptr;
+    double* ddst = depth_out ? depth_out + (int64_t)job_slot * hw : nullptr;
     const float beta = (float)job.beta, A255 = 255.0f * (float)job.atmos;
     const float inv_h = 100.0f / (float)H;
     const float kAmp = 10.0f * 0.009584116f;                 // sigma 10 x 1 / sqrt(2 (256^2 - 1) / 12): unit-variance byte differences
@@ -571,6 +575,16 @@ void fog_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<a
     }
 }
 
+__global__ __launch_bounds__(256)
+void fog_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_fog_job> jobs, int job0,
+                      gauss_taps_f32 taps, uint8_t* __restrict__ out, float* __restrict__ norm_out,
+                      double* __restrict__ depth_out, norm_consts nc, int rows_per_strip)
+{
+    __shared__ weather_lut L;
+    extern __shared__ float4 s_ring[];                       // [17][256]
+    fog_strip_body(imgs, H, W, jobs.j[blockIdx.z], job0 + blockIdx.z, taps, out, norm_out, depth_out, nc, rows_per_strip, L, s_ring, blockIdx.x, blockIdx.y);
+}
+
 // fog from a caller-provided depth map (the two-step form of the reference).
 __global__ __launch_bounds__(kThreads)
 void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_fog_job> jobs, int job0,
@@ -602,17 +616,15 @@ void fog_apply_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<aws
 // 4 pixels per lane (12 B in as three dwords, 12 B and/or three float4 out).  Throughput mode draws
 // its 12 normals from three Philox calls; parity mode reads the host's float64 draws.
 template <bool PHILOX>
-__global__ __launch_bounds__(kThreads)
-void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_night_job> jobs, int job0,
-                  const double* __restrict__ noise_all, float g0, float g1, float g2,
-                  uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc, bool vec)
+__device__ __forceinline__ void night_body(const uint8_t* __restrict__ imgs, int64_t hw, const awseg_night_job job, int job_slot,
+                                           const double* __restrict__ noise_all, float g0, float g1, float g2,
+                                           uint8_t* __restrict__ out, float* __restrict__ norm_out, const norm_consts& nc, bool vec,
+                                           weather_lut& L, int bx, int nbx)
 {
-    __shared__ weather_lut L;
     lut_fill(L, nc, norm_out != nullptr);
     __syncthreads();
-    const awseg_night_job job = jobs.j[blockIdx.y];
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
-    const double* noise = PHILOX ? nullptr : noise_all + (int64_t)(job0 + blockIdx.y) * hw * 3;
+    const double* noise = PHILOX ? nullptr : noise_all + (int64_t)job_slot * hw * 3;
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
     const float bf = (float)job.brightness;                       // Python float x f32 array -> f32, :213
@@ -620,7 +632,7 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_n
     const double sigma = 5.0 / 255.0;                             // :222
     const double ni = job.intensity;
     const int64_t nquad = (hw + 3) / 4;
-    for (int64_t q = (int64_t)blockIdx.x * kThreads + threadIdx.x; q < nquad; q += (int64_t)gridDim.x * kThreads) {
+    for (int64_t q = (int64_t)bx * kThreads + threadIdx.x; q < nquad; q += (int64_t)nbx * kThreads) {
         const int64_t p = q * 4;
         const int nvalid = (hw - p) < 4 ? (int)(hw - p) : 4;
         const bool v4 = nvalid == 4 && vec;                       // vec: per-image bases are dword (float4, double2) aligned
@@ -689,6 +701,16 @@ void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_n
             }
         }
     }
+}
+
+template <bool PHILOX>
+__global__ __launch_bounds__(kThreads)
+void night_kernel(const uint8_t* __restrict__ imgs, int64_t hw, job_pack<awseg_night_job> jobs, int job0,
+                  const double* __restrict__ noise_all, float g0, float g1, float g2,
+                  uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc, bool vec)
+{
+    __shared__ weather_lut L;
+    night_body<PHILOX>(imgs, hw, jobs.j[blockIdx.y], job0 + blockIdx.y, noise_all, g0, g1, g2, out, norm_out, nc, vec, L, blockIdx.x, gridDim.x);
 }
 
 // ---------------------------------------------------------------- rasteriser (A4 / A5)
@@ -1263,18 +1285,15 @@ template <int RR> struct strip_rows { static constexpr int value = RR == 1 ? 16 
 // image edge loads with its dword indices clamped into the row and then copies the BORDER_REFLECT_101 source pixels over the
 // out-of-image ones (pixel -j <- pixel j, pixel W-1+j <- pixel W-1-j: 3R selects per side) — no divergent second path.
 template <bool SNOW, int RR, bool FAST>
-__global__ __launch_bounds__(256)
-void streak_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_prim_job> jobs, blur_taps bt,
-                         uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc,
-                         const uint32_t* __restrict__ bits_all, int wd)
+__device__ __forceinline__ void streak_strip_body(const uint8_t* __restrict__ imgs, int H, int W, const awseg_prim_job job, const blur_taps& bt,
+                                                  uint8_t* __restrict__ out, float* __restrict__ norm_out, const norm_consts& nc,
+                                                  const uint32_t* __restrict__ bits, int wd, weather_lut& L, float* s_in, int bx, int by)
 {
+    // s_in [256 + 4]: pre-blur value of a byte; entries 256..258: the streak colour per channel, so a covered pixel is an index
+    // select in front of ONE table read
     constexpr int R = RR, NR = strip_rows<RR>::value, NW = 4 + 2 * R, NBYTE = NW * 3, RING = 2 * R + 1;
     constexpr int OFF = (4 - ((3 * R) & 3)) & 3;                 // (gx - R) * 3 mod 4 for gx % 4 == 0: 1 (R = 1), 3 (R = 3)
     constexpr int ND = (OFF + NBYTE + 3) / 4;                    // dwords that hold the window's bytes: 5 / 9
-    __shared__ weather_lut L;
-    __shared__ float s_in[256 + 4];                              // pre-blur value of a byte; entries 256..258: the streak colour per channel,
-                                                                 // so a covered pixel is an index select in front of ONE table read
-    const awseg_prim_job job = jobs.j[blockIdx.z];
     float pm, pa;
     if (SNOW) { pm = 1.f; pa = (float)(job.intensity * 0.2); }
     else { double haze = job.intensity * 0.3; pm = (float)(1.0 - haze); pa = (float)(haze * 0.7); }
@@ -1291,11 +1310,10 @@ void streak_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pac
     }
     __syncthreads();
     const int64_t hw = (int64_t)H * W;
-    const int gx = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
-    const int y0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * NR;
+    const int gx = (bx * 64 + (threadIdx.x & 63)) * 4;
+    const int y0 = (by * 4 + (threadIdx.x >> 6)) * NR;
     if (gx >= W || y0 >= H) return;
     const uint8_t* src = imgs + (int64_t)job.image * hw * 3;
-    const uint32_t* bits = bits_all + (int64_t)blockIdx.z * H * wd;
     uint8_t* dst = out ? out + (int64_t)job.image * hw * 3 : nullptr;
     float* ndst = norm_out ? norm_out + (int64_t)job.image * hw * 3 : nullptr;
     const int nvalid = (W - gx) < 4 ? (W - gx) : 4;
@@ -1416,6 +1434,18 @@ void streak_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pac
     }
 }
 
+template <bool SNOW, int RR, bool FAST>
+__global__ __launch_bounds__(256)
+void streak_strip_kernel(const uint8_t* __restrict__ imgs, int H, int W, job_pack<awseg_prim_job> jobs, blur_taps bt,
+                         uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc,
+                         const uint32_t* __restrict__ bits_all, int wd)
+{
+    __shared__ weather_lut L;
+    __shared__ float s_in[256 + 4];
+    streak_strip_body<SNOW, RR, FAST>(imgs, H, W, jobs.j[blockIdx.z], bt, out, norm_out, nc, bits_all + (int64_t)blockIdx.z * H * wd, wd, L, s_in,
+                                      blockIdx.x, blockIdx.y);
+}
+
 // Coverage pre-pass: one wave per primitive of a frame, the same integer rasteriser writing a frame-wide 1-bit map
 // (atomicOr; bits[job][H][wd]).  The map is zeroed by the launcher.
 template <bool SNOW>
@@ -1494,7 +1524,137 @@ int grid_for(int64_t items, int64_t jobs)
     return (int)(want < 1 ? 1 : want);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// ONE launch for a batch of frames of MIXED kinds (throughput mode: in-kernel Philox noise).  A step of the evaluation loop
+// draws a condition per frame (PKG/data/loader.py:265), so with a launch per kind each launch covers one or two frames and the five
+// of them run back to back, every one bound by its own launch latency and tail (0.19 ms for 252 MB of algorithmic traffic, round 3).
+// Here every frame is a JOB with a block range; a block looks its job up in the table that travels in the kernel arguments and runs
+// that kind's body — the bodies above, unchanged, so the bytes are those of the per-kind launchers.  Long-running kinds (the fog
+// strips) get the first block indices.  Rain / snow read the coverage maps of the raster pre-pass (two small launches in front).
+struct wb_entry {
+    int kind, b0, nbx, nby, slot, strip_rows;
+    awseg_fog_job fog; awseg_night_job night; awseg_prim_job prim;
+};
+struct wb_table { int n; int pad; wb_entry e[kMaxJobs]; };
+
+__global__ __launch_bounds__(256)
+void weather_batch_kernel(const uint8_t* __restrict__ imgs, int H, int W, wb_table tab, gauss_taps_f32 taps, blur_taps bt_rain, blur_taps bt_snow,
+                          float g0, float g1, float g2, uint8_t* __restrict__ out, float* __restrict__ norm_out, norm_consts nc,
+                          const uint32_t* __restrict__ bits_all, int wd)
+{
+    __shared__ weather_lut L;
+    __shared__ float s_in[256 + 4];
+    extern __shared__ float4 s_ring[];                              // fog: [17][256]
+    const int b = blockIdx.x;
+    int j = 0;
+    for (int k = 1; k < tab.n; ++k) j = b >= tab.e[k].b0 ? k : j;    // entries are sorted by their first block
+    const wb_entry e = tab.e[j];
+    const int local = b - e.b0, bx = local % e.nbx, by = local / e.nbx;
+    const int64_t hw = (int64_t)H * W;
+    switch (e.kind) {
+    case AWSEG_WEATHER_CLEAN: normalize_body(imgs, hw, e.fog.image, nc, norm_out, true, bx, e.nbx); break;
+    case AWSEG_WEATHER_FOG: fog_strip_body(imgs, H, W, e.fog, 0, taps, out, norm_out, nullptr, nc, e.strip_rows, L, s_ring, bx, by); break;
+    case AWSEG_WEATHER_RAIN:
+        streak_strip_body<false, 1, true>(imgs, H, W, e.prim, bt_rain, out, norm_out, nc, bits_all + (int64_t)e.slot * H * wd, wd, L, s_in, bx, by); break;
+    case AWSEG_WEATHER_SNOW:
+        streak_strip_body<true, 1, true>(imgs, H, W, e.prim, bt_snow, out, norm_out, nc, bits_all + (int64_t)e.slot * H * wd, wd, L, s_in, bx, by); break;
+    default: night_body<true>(imgs, hw, e.night, 0, nullptr, g0, g1, g2, out, norm_out, nc, true, L, bx, e.nbx); break;
+    }
+}
+
 }  // namespace
+
+AWSEG_API int awseg_weather_batch(const uint8_t* imgs, int height, int width, const awseg_weather_job* jobs, int n_jobs,
+                                  const int32_t* rain_drops, const int32_t* snow_flakes, const double* taps_host, const float* gains_host,
+                                  uint8_t* out, float* norm_out, const float* mean_host, const float* std_host, void* workspace,
+                                  awseg_stream_t stream)
+{
+    if (n_jobs == 0) return 0;
+    if (!imgs || !jobs || !norm_out || !mean_host || !std_host || !taps_host || !gains_host || height < 1 || width < 1 || n_jobs < 0) return AWSEG_EINVAL;
+    if (n_jobs > kMaxJobs) return AWSEG_ERANGE;                       // the caller splits larger batches
+    const int H = height, W = width;
+    const int64_t hw = (int64_t)H * W;
+    if ((W & 3) || W < 16) return AWSEG_ERANGE;                       // the strip bodies' aligned-dword windows; other sizes: the per-kind launchers
+    if (out == imgs) return AWSEG_EINVAL;
+    if (((uintptr_t)imgs & 3) || ((uintptr_t)norm_out & 15) || (out && ((uintptr_t)out & 3)) || (workspace && ((uintptr_t)workspace & 3))) return AWSEG_EALIGN;
+    hipStream_t s = awseg_s(stream);
+    const int wd = (W + 31) / 32;
+    int n_fog = 0, n_rain = 0, n_snow = 0;
+    for (int i = 0; i < n_jobs; ++i) {
+        const int k = jobs[i].kind;
+        if (k < AWSEG_WEATHER_CLEAN || k > AWSEG_WEATHER_NIGHT || jobs[i].image < 0) return AWSEG_EINVAL;
+        n_fog += k == AWSEG_WEATHER_FOG; n_rain += k == AWSEG_WEATHER_RAIN; n_snow += k == AWSEG_WEATHER_SNOW;
+    }
+    if ((n_rain && !rain_drops) || (n_snow && !snow_flakes) || ((n_rain || n_snow) && !workspace)) return AWSEG_EINVAL;
+    uint32_t* bits = reinterpret_cast<uint32_t*>(workspace);
+    // fog strip height: as fog_common (one round of two blocks per CU; short strips when few frames are foggy)
+    int fog_rows = 0, fog_nbx = 0, fog_nby = 0;
+    if (n_fog) {
+        fog_nbx = ((W >> 2) + kFogStripQuads - 1) / kFogStripQuads;
+        const int64_t per_round = (int64_t)AWSEG_CUS * 2 / fog_nbx / n_fog;
+        fog_rows = per_round >= 1 ? (int)((H + 4 * per_round - 1) / (4 * per_round)) : H;
+        const int min_rows = n_fog <= 2 ? 8 : 24;
+        if (fog_rows < min_rows) fog_rows = min_rows;
+        fog_nby = ((H + fog_rows - 1) / fog_rows + 3) / 4;
+    }
+    const int nr = strip_rows<1>::value;
+    const int st_nbx = (W + 255) / 256, st_nby = (H + 4 * nr - 1) / (4 * nr);
+    int pw_blocks = (int)((hw / 4 + kThreads - 1) / kThreads);         // pointwise kinds: grid-stride over pixel quads
+    const int pw_cap = AWSEG_CUS * 8 / n_jobs > 64 ? AWSEG_CUS * 8 / n_jobs : 64;
+    if (pw_blocks > pw_cap) pw_blocks = pw_cap;
+    if ((hw & 3) != 0) return AWSEG_ERANGE;
+    wb_table tab;
+    tab.n = 0; tab.pad = 0;
+    job_pack<awseg_prim_job> rain_pk, snow_pk;
+    awseg_prim_job rsel[kMaxJobs], ssel[kMaxJobs];
+    int rcnt = 0, scnt = 0, rmax = 0, smax = 0;
+    int next_block = 0;
+    const int order[5] = { AWSEG_WEATHER_FOG, AWSEG_WEATHER_RAIN, AWSEG_WEATHER_SNOW, AWSEG_WEATHER_NIGHT, AWSEG_WEATHER_CLEAN };
+    for (int o = 0; o < 5; ++o)
+        for (int i = 0; i < n_jobs; ++i) {
+            const awseg_weather_job& jb = jobs[i];
+            if (jb.kind != order[o]) continue;
+            wb_entry& e = tab.e[tab.n++];
+            e.kind = jb.kind; e.b0 = next_block; e.slot = 0; e.strip_rows = fog_rows;
+            e.fog.image = jb.image; e.fog._pad = 0; e.fog.beta = jb.a; e.fog.atmos = jb.b; e.fog.seed = jb.seed;
+            e.night.image = jb.image; e.night._pad = 0; e.night.brightness = jb.a; e.night.intensity = jb.b; e.night.seed = jb.seed;
+            e.prim.image = jb.image; e.prim.prim_offset = jb.prim_offset; e.prim.prim_count = jb.prim_count; e.prim.blur_ksize = 3; e.prim.intensity = jb.a;
+            if (jb.kind == AWSEG_WEATHER_FOG) { e.nbx = fog_nbx; e.nby = fog_nby; }
+            else if (jb.kind == AWSEG_WEATHER_RAIN || jb.kind == AWSEG_WEATHER_SNOW) {
+                if (jb.prim_count < 0 || jb.prim_offset < 0) return AWSEG_EINVAL;
+                e.nbx = st_nbx; e.nby = st_nby;
+                if (jb.kind == AWSEG_WEATHER_RAIN) { e.slot = rcnt; rsel[rcnt++] = e.prim; rmax = jb.prim_count > rmax ? jb.prim_count : rmax; }
+                else { e.slot = n_rain + scnt; ssel[scnt++] = e.prim; smax = jb.prim_count > smax ? jb.prim_count : smax; }
+            }
+            else { e.nbx = pw_blocks; e.nby = 1; }
+            next_block += e.nbx * e.nby;
+        }
+    if (n_rain + n_snow) {
+        if (hipMemsetAsync(bits, 0, (size_t)(n_rain + n_snow) * H * wd * sizeof(uint32_t), s) != hipSuccess) return AWSEG_EINVAL;
+        if (rcnt && rmax > 0) {
+            rain_pk = pack_jobs(rsel, 0, rcnt);
+            hipLaunchKernelGGL((raster_kernel<false>), dim3((rmax + 3) / 4, rcnt), dim3(256), 0, s, H, W, rain_pk, rain_drops, bits, wd);
+            AWSEG_LAUNCH_CHECK();
+        }
+        if (scnt && smax > 0) {
+            snow_pk = pack_jobs(ssel, 0, scnt);
+            hipLaunchKernelGGL((raster_kernel<true>), dim3((smax + 3) / 4, scnt), dim3(256), 0, s, H, W, snow_pk, snow_flakes, bits + (size_t)n_rain * H * wd, wd);
+            AWSEG_LAUNCH_CHECK();
+        }
+    }
+    gauss_taps_f32 tf;
+    for (int i = 0; i < 2 * FR + 1; ++i) tf.w[i] = (float)taps_host[i];
+    const size_t lds = n_fog ? (size_t)kFogRing * 256 * sizeof(float4) : 0;
+    static bool attr_set = false;
+    if (lds && !attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(weather_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)kFogRing * 256 * sizeof(float4))) != hipSuccess) return AWSEG_EINVAL;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(weather_batch_kernel, dim3((unsigned)next_block), dim3(256), lds, s, imgs, H, W, tab, tf, make_blur(3, 0.5), make_blur(3, 1.0),
+                       gains_host[0], gains_host[1], gains_host[2], out, norm_out, make_nc(mean_host, std_host), bits, wd);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
 
 AWSEG_API int awseg_normalize(const uint8_t* imgs, int64_t batch, int height, int width, const int32_t* sel, int n_sel,
                               const float* mean_host, const float* std_host, float* out, awseg_stream_t stream)

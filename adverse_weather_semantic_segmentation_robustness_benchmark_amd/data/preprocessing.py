@@ -181,6 +181,43 @@ class WeatherDegradationTransforms:
         def philox(idx):
             return [seeds[b] if seeds[b] is not None else self._next_seed() for b in idx]
         dev = imgs.device
+        if (not per_pixel and norm_out is not None and ops.weather_batch_ok(H, W) and B <= ops.WEATHER_BATCH_MAX and (H * W) % 4 == 0
+                and (out is None or out.data_ptr() != imgs.data_ptr())):
+            # throughput mode: every frame of the batch in ONE launch (awseg_weather_batch: a job per frame, the per-kind kernels' bodies,
+            # identical bytes); snow frames that drew the 7x7 blur keep their own launch.  Seeds are drawn in the per-kind order (fog, night).
+            wj = np.zeros(B, dtype=ops.N.WEATHER_JOB)
+            n = 0
+            rain_lists, snow_lists, snow7 = [], [], []
+            roff = soff = 0
+            fseeds, nseeds = philox(groups["fog"]), philox(groups["night"])
+            for b in groups["clean"]:
+                wj[n]["kind"], wj[n]["image"] = ops.N.WEATHER_CLEAN, b; n += 1
+            for b, sd in zip(groups["fog"], fseeds):
+                fj = ops.fog_jobs([b], [draws[b][1]], [sd])[0]
+                wj[n]["kind"], wj[n]["image"], wj[n]["a"], wj[n]["b"], wj[n]["seed"] = ops.N.WEATHER_FOG, b, fj["beta"], fj["atmos"], fj["seed"]; n += 1
+            for b, sd in zip(groups["night"], nseeds):
+                nj = ops.night_jobs([b], [draws[b][1]], [draws[b][0]], [sd])[0]
+                wj[n]["kind"], wj[n]["image"], wj[n]["a"], wj[n]["b"], wj[n]["seed"] = ops.N.WEATHER_NIGHT, b, nj["brightness"], nj["intensity"], nj["seed"]; n += 1
+            for b in groups["rain"]:
+                pl = np.asarray(draws[b][1], dtype=np.int32).reshape(-1, 5)
+                wj[n]["kind"], wj[n]["image"], wj[n]["a"], wj[n]["prim_offset"], wj[n]["prim_count"] = ops.N.WEATHER_RAIN, b, float(draws[b][0]), roff, len(pl); n += 1
+                rain_lists.append(pl); roff += len(pl)
+            for b in groups["snow"]:
+                if int(draws[b][2]) == 7:
+                    snow7.append(b); continue
+                pl = np.asarray(draws[b][1], dtype=np.int32).reshape(-1, 3)
+                wj[n]["kind"], wj[n]["image"], wj[n]["a"], wj[n]["prim_offset"], wj[n]["prim_count"] = ops.N.WEATHER_SNOW, b, float(draws[b][0]), soff, len(pl); n += 1
+                snow_lists.append(pl); soff += len(pl)
+            rd = np.concatenate(rain_lists + [np.zeros((1, 5), np.int32)]) if rain_lists else None
+            sf = np.concatenate(snow_lists + [np.zeros((1, 3), np.int32)]) if snow_lists else None
+            if n == 0 or ops.weather_batch(imgs, wj[:n], rd, sf, norm_out, out=out):
+                if out is not None and groups["clean"]:
+                    out[groups["clean"]] = imgs[groups["clean"]]
+                if snow7:
+                    jobs, prims = ops.prim_jobs(snow7, [draws[b][0] for b in snow7], [draws[b][1] for b in snow7], [7] * len(snow7))
+                    ops.snow(imgs, jobs, prims, out=out, norm_out=norm_out)
+                return out
+            seeds = {**seeds, **dict(zip(groups["fog"], fseeds)), **dict(zip(groups["night"], nseeds))}     # declined: per-kind calls, same seeds
         if groups["clean"]:
             idx = groups["clean"]
             if out is not None and out.data_ptr() != imgs.data_ptr():

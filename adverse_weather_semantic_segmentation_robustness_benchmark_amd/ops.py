@@ -294,6 +294,30 @@ def night(imgs: torch.Tensor, jobs: np.ndarray, noise: Optional[torch.Tensor] = 
                                       N.ptr(norm_out), N.host(m), N.host(s), N.stream())
 
 
+WEATHER_BATCH = os.environ.get("AWSEG_WEATHER_BATCH", "1") != "0"   # one launch for a batch of mixed conditions (throughput mode)
+WEATHER_BATCH_MAX = 16
+
+
+def weather_batch_ok(h: int, w: int) -> bool:
+    return WEATHER_BATCH and w % 4 == 0 and w >= 16
+
+
+def weather_batch(imgs: torch.Tensor, jobs: np.ndarray, rain_drops: Optional[np.ndarray], snow_flakes: Optional[np.ndarray],
+                  norm_out: torch.Tensor, out: Optional[torch.Tensor] = None, mean=None, std=None) -> bool:
+    """apply_weather_effect + Normalize for <= 16 frames of mixed conditions in ONE launch (awseg_weather_batch; in-kernel Philox noise).
+    jobs: np.ndarray of N.WEATHER_JOB.  Returns False when the launcher declines the geometry (the caller uses the per-kind calls)."""
+    imgs = imgs.contiguous()
+    _, h, w, _ = imgs.shape
+    n_cov = int(((jobs["kind"] == N.WEATHER_RAIN) | (jobs["kind"] == N.WEATHER_SNOW)).sum())
+    ws = N.workspace.get(imgs.device, N.lib().awseg_streak_workspace(n_cov, h, w), tag="streak") if n_cov else None
+    rd = None if rain_drops is None else torch.from_numpy(np.ascontiguousarray(rain_drops, dtype=np.int32)).to(imgs.device, non_blocking=True)
+    sf = None if snow_flakes is None else torch.from_numpy(np.ascontiguousarray(snow_flakes, dtype=np.int32)).to(imgs.device, non_blocking=True)
+    m, s = _mean_std(mean, std)
+    rc = N.try_call("awseg_weather_batch", N.ptr(imgs), h, w, N.host_jobs(jobs), len(jobs), N.ptr(rd), N.ptr(sf), N.host(_TAPS), N.host(NIGHT_GAINS),
+                    N.ptr(out), N.ptr(norm_out), N.host(m), N.host(s), N.ptr(ws), N.stream())
+    return rc == 0
+
+
 def _streak_workspace(imgs: torch.Tensor, n_jobs: int, h: int, w: int, prepass: bool):
     """Coverage-map scratch of the rain / snow launchers (awseg_streak_workspace); None = rasterise inside the blur kernel."""
     if not prepass or n_jobs < 1:

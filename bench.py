@@ -198,6 +198,8 @@ def algorithmic_work(name, B, H, W, C, info):
         return "hbm", (3 + 12) * px * n                # u8 in, fused f32 CHW normalised out; Philox noise: 0 B
     if name in ("awseg_night_apply", "awseg_rain_apply", "awseg_snow_apply", "awseg_normalize"):
         return "hbm", (3 + 12) * px * n
+    if name == "awseg_weather_batch":                  # every frame of the batch in one launch (7x7-snow frames keep awseg_snow_apply): u8 in, f32 CHW out
+        return "hbm", (3 + 12) * px * n
     if name == "awseg_combine_argmax_confusion":
         return "hbm", (2 * C * 4 + 1) * px * B         # two member logit maps + labels in; counters only out
     if name == "awseg_combine_confusion_stats":
@@ -226,7 +228,7 @@ DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
                  "awseg_gemm_split_bias_act": ("gemm_split3_kernel<false, 0, false", "gemm_split3_kernel<true, 0, false", "gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false", "gemm_split_kernel<2, 2, 4, 2, false, false, true", "gemm_split_kernel<2, 2, 4, 2, true, false, true"),
                  "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
                  "awseg_attention_d32_split": "attention_d32_split_kernel", "awseg_depth_head_fused": ("wino8p_kernel<2, false>", "wino8p_kernel<2, true>"),
-                 "awseg_upconv_forms": "upconv_forms_kernel", "awseg_mixffn_fused": ("mixffn_kernel<32>", "mixffn_kernel<64>"),
+                 "awseg_upconv_forms": "upconv_forms_kernel", "awseg_weather_batch": "weather_batch_kernel", "awseg_mixffn_fused": ("mixffn_kernel<32>", "mixffn_kernel<64>"),
                  "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0", "awseg_combine_confusion_stats": "ensemble_stats_kernel<",
                  "awseg_upconv3x3_adjoint": "upconv3x3_adjoint_kernel", "awseg_upconv3x3_linear": "head_mfma_kernel<", "awseg_dwconv3x3_wgrad_nhwc": "dwconv3x3_wgrad_partial_kernel",
                  "awseg_dwconv3x3_nhwc": ("dwconv3x3_nhwc_strip2_kernel", "dwconv3x3_nhwc_strip_kernel", "dwconv3x3_nhwc_kernel"),
@@ -706,7 +708,7 @@ def main():
         conds = [CONDITIONS[g % len(CONDITIONS)] for g in ids]
         info.update({"awseg_fog_fused": conds.count("fog"), "awseg_night_apply": conds.count("night"),
                      "awseg_rain_apply": conds.count("rain"), "awseg_snow_apply": conds.count("snow"),
-                     "awseg_normalize": conds.count("clean"), "awseg_weather_batch": len(ids)})
+                     "awseg_normalize": conds.count("clean"), "awseg_weather_batch": len(ids)})   # (upper bound for the batch launch: a frame that drew the 7x7 snow blur runs in awseg_snow_apply)
         if buffers is not None:
             r, l = buffers[0][:len(local_idx)], buffers[1][:len(local_idx)]
         elif local_idx == list(range(local_idx[0], local_idx[0] + len(local_idx))):

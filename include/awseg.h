@@ -85,6 +85,17 @@ typedef struct awseg_prim_job {
     double   intensity;
 } awseg_prim_job;
 
+/* One frame of awseg_weather_batch: kind + the parameters of that kind.  a / b: fog beta / atmospheric light; night brightness /
+ * intensity; rain, snow: intensity / unused.  seed: Philox key (fog, night).  prim_offset / prim_count: the frame's drops (rain:
+ * int32[.,5] in rain_drops) or flakes (snow: int32[.,3] in snow_flakes). */
+enum { AWSEG_WEATHER_CLEAN = 0, AWSEG_WEATHER_FOG = 1, AWSEG_WEATHER_RAIN = 2, AWSEG_WEATHER_SNOW = 3, AWSEG_WEATHER_NIGHT = 4 };
+typedef struct awseg_weather_job {
+    int32_t  kind; int32_t image;
+    double   a; double b;
+    uint64_t seed;
+    int32_t  prim_offset; int32_t prim_count;
+} awseg_weather_job;
+
 /* ------------------------------------------------------------------------- *
  *  A13  IoUMetrics.compute_iou — confusion accumulation
  *       replaces PKG/evaluation/metrics.py:54-71
@@ -267,6 +278,19 @@ int awseg_night_apply(const uint8_t* imgs, int height, int width,
                       uint8_t* out, float* norm_out,
                       const float* mean_host, const float* std_host,
                       awseg_stream_t stream);
+
+/* A1 + A3-A7 for a batch of frames of MIXED conditions in ONE launch (throughput mode: in-kernel Philox noise for fog and night):
+ * apply_weather_effect's dispatch (PKG/data/preprocessing.py:61-92) over the frames of a batch as PKG/data/loader.py:265-278 draws them,
+ * each frame one job (<= 16 per call), fused Normalize/ToTensor output norm_out float32 [B,3,H,W] (required) and optional uint8
+ * out [B,H,W,3] (not written for clean frames; must not alias imgs).  Same kernels' bodies as awseg_normalize / awseg_fog_fused /
+ * awseg_rain_apply / awseg_snow_apply (3x3 blur only) / awseg_night_apply: identical bytes.  width % 4 == 0, width >= 16, else
+ * AWSEG_ERANGE (the caller uses the per-kind entry points, which take every size).  workspace: awseg_streak_workspace(rain + snow
+ * frames, H, W) bytes for the coverage maps (NULL when the batch has neither).  taps_host: the 17 Gaussian taps of the synthetic
+ * depth; gains_host: night's three channel gains. */
+int awseg_weather_batch(const uint8_t* imgs, int height, int width, const awseg_weather_job* jobs, int n_jobs,
+                        const int32_t* rain_drops, const int32_t* snow_flakes, const double* taps_host, const float* gains_host,
+                        uint8_t* out, float* norm_out, const float* mean_host, const float* std_host, void* workspace,
+                        awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  A4  _apply_rain           replaces PKG/data/preprocessing.py:131-168

@@ -16,6 +16,8 @@ cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_step -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0 > $O/${R}_prof_step.log 2>&1; echo "prof step exit $?"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_step_fetch -o step -- python3 $B > $O/${R}_prof_step_fetch.log 2>&1; echo "step fetch exit $?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_step_write -o step -- python3 $B > $O/${R}_prof_step_write.log 2>&1; echo "step write exit $?"
+timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/${R}_prof_step_busy -o step -- python3 $B > $O/${R}_prof_step_busy.log 2>&1; echo "step busy exit $?"
+rm -f $O/${R}_prof_step_busy/*/*kernel_trace* 2>/dev/null
 fi
 if [ "$PART" != "a" ]; then
 cd $GRAFT_REPO_ROOT

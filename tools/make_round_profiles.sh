@@ -6,6 +6,7 @@ python tools/make_profiles.py step gpurun_out/${R}_prof_step ensemble_stats_kern
   "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 6 --warmup 3 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0 (the shipped build of the round, ingestion on)"
 python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_step gpurun_out/${R}_prof_step_fetch gpurun_out/${R}_prof_step_write profiles/${R}_bench_step_stats_and_traffic.csv \
   "bench.py under rocprofv3: --kernel-trace --stats pass + separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes; mean per dispatch over the launches of the timed steps" mean
+[ -d gpurun_out/${R}_prof_step_busy ] && python tools/scratch/pmc_busy_table.py gpurun_out/${R}_prof_step_busy profiles/${R}_pmc_step_busy.csv ${R}
 python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_kb_trace gpurun_out/${R}_prof_kb_fetch gpurun_out/${R}_prof_kb_write profiles/${R}_kernel_bench_stats_and_traffic.csv \
   "tools/kernel_bench.py --iters 2 --only winograd,gemm_l4,gemm_aspp,combine,fog,night,rain,snow,normalize,segformer_head,stats,ece,aspp_dep,dwconv,depth_head_fused,upconv_forms,mixffn under rocprofv3 (kernel trace + separate FETCH_SIZE / WRITE_SIZE passes), median per dispatch"
 python tools/make_profiles.py kernel-table gpurun_out/${R}_prof_b5 gpurun_out/${R}_prof_b5_fetch gpurun_out/${R}_prof_b5_write profiles/${R}_bench_b5_step_stats_and_traffic.csv \

@@ -267,19 +267,14 @@ def stem_scope():
         _stem_scope = prev
 
 
-def _stem_rows(x: torch.Tensor, conv: nn.Conv2d, w: torch.Tensor, bias: torch.Tensor = None):
-    """A 7x7 stem on <= 4 input channels (ResNet conv1: stride 2; MiT's first patch embedding: stride 4, 32 channels) as one
-    split-operand GEMM whose A operand is gathered row by row from a zero-padded [B, H, W + pads, 4] copy of the image
-    (ops.conv_rows_gemm_split) instead of MIOpen's float32 implicit GEMM (+ its separate bias kernel).  Returns the NHWC result
-    [B, Ho, Wo, N], or None when the shape is not a stem's / the kernel does not take it."""
-    st = conv.stride[0]
-    if not (STEM_ROWS and ops.GEMM_SPLIT and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (7, 7) and conv.stride in ((2, 2), (4, 4))
-            and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels <= 4
-            and (conv.out_channels % 64 == 0 or 8 <= conv.out_channels < 64) and ops.PRECISION != "bf16"):
-        return None
+def stem_image_ok(x: torch.Tensor) -> bool:
+    return STEM_ROWS and ops.GEMM_SPLIT and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] <= 4 and ops.PRECISION != "bf16"
+
+
+def stem_image(x: torch.Tensor) -> torch.Tensor:
+    """The zero-padded 4-channel NHWC copy [B, H, W + pads, 4] of the frames that both 7x7 stems read (3 zero columns on the left, enough on
+    the right for the last run of 8 pixels at either stride); built once per forward inside a stem_scope, the buffer kept across forwards."""
     B, C, H, W = x.shape
-    wo = (W + 6 - 7) // st + 1
-    wp = max(W + 3, (wo - 1) * st + 8)                     # 3 zero columns on the left; the last run of 8 pixels ends inside the row
     wp_any = max(W + 3, ((W + 6 - 7) // 2) * 2 + 8, ((W + 6 - 7) // 4) * 4 + 8)   # one image for both strides
     skey = (x.data_ptr(), tuple(x.shape), tuple(x.stride()))
     xp = _stem_scope.get(skey) if _stem_scope is not None else None
@@ -294,7 +289,24 @@ def _stem_rows(x: torch.Tensor, conv: nn.Conv2d, w: torch.Tensor, bias: torch.Te
         xp[:, :, 3:3 + W, :C] = x.permute(0, 2, 3, 1)      # the padding columns / channel stay zero
         if _stem_scope is not None:
             _stem_scope[skey] = xp
-    assert wp <= wp_any
+    return xp
+
+
+def _stem_rows(x: torch.Tensor, conv: nn.Conv2d, w: torch.Tensor, bias: torch.Tensor = None):
+    """A 7x7 stem on <= 4 input channels (ResNet conv1: stride 2; MiT's first patch embedding: stride 4, 32 channels) as one
+    split-operand GEMM whose A operand is gathered row by row from a zero-padded [B, H, W + pads, 4] copy of the image
+    (ops.conv_rows_gemm_split) instead of MIOpen's float32 implicit GEMM (+ its separate bias kernel).  Returns the NHWC result
+    [B, Ho, Wo, N], or None when the shape is not a stem's / the kernel does not take it."""
+    st = conv.stride[0]
+    if not (STEM_ROWS and ops.GEMM_SPLIT and x.is_cuda and x.dtype == torch.float32 and conv.kernel_size == (7, 7) and conv.stride in ((2, 2), (4, 4))
+            and conv.padding == (3, 3) and conv.dilation == (1, 1) and conv.groups == 1 and conv.in_channels <= 4
+            and (conv.out_channels % 64 == 0 or 8 <= conv.out_channels < 64) and ops.PRECISION != "bf16"):
+        return None
+    B, C, H, W = x.shape
+    wo = (W + 6 - 7) // st + 1
+    wp = max(W + 3, (wo - 1) * st + 8)                     # 3 zero columns on the left; the last run of 8 pixels ends inside the row
+    xp = stem_image(x)
+    assert wp <= xp.shape[2]
     ws = cached(conv, "stemrows", [w], lambda: ops.gemm_split_weights(ops.stem_rows_weights(w)))
     return ops.conv_rows_gemm_split(xp, ws, bias, N.ACT_NONE, 7, st, 3, wo)
 

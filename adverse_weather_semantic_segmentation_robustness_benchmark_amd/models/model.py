@@ -96,6 +96,9 @@ def _patch_mit_dwconv(seg) -> None:
             mod.forward = types.MethodType(_mit_dwconv_forward, mod)
 
 
+_SIDE_STREAMS: Dict[str, "torch.cuda.Stream"] = {}
+
+
 class DepthEstimationHead(nn.Module):
     """PKG/models/model.py:16-78 — same Sequential layout (keys depth_head.{0,1,4,5,7})."""
 
@@ -394,8 +397,24 @@ class EnsembleModel(nn.Module):
         self.deeplabv3plus._defer_depth_upsample = self.include_depth
         try:
             with fused.stem_scope():                               # the two 7x7 stems share one zero-padded copy of the input
-                o1 = self.segformer(x)
-                o2 = self.deeplabv3plus(x)
+                if ops.TWO_STREAMS and x.is_cuda:
+                    # the two members are independent until the combine: DeepLabV3+ runs on a side stream beside SegFormer (whose many
+                    # small launches — stages 3 / 4 at 1/16 and 1/32 resolution, LayerNorms, the reduced-token projections — leave
+                    # most CUs idle on their own).  One fork, one join; the shared padded image is built in front of the fork.
+                    cur = torch.cuda.current_stream(x.device)
+                    side = self._side_stream(x.device)
+                    if fused.stem_image_ok(x):
+                        fused.stem_image(x)
+                    side.wait_stream(cur)
+                    with torch.cuda.stream(side):
+                        o2 = self.deeplabv3plus(x)
+                    o1 = self.segformer(x)
+                    cur.wait_stream(side)
+                    for t in o2.values():
+                        t.record_stream(cur)
+                else:
+                    o1 = self.segformer(x)
+                    o2 = self.deeplabv3plus(x)
         finally:
             self.deeplabv3plus._defer_depth_upsample = False
         mode = _STRATEGY.get(self.ensemble_strategy, N.COMBINE_MEAN)
@@ -426,6 +445,12 @@ class EnsembleModel(nn.Module):
             else:
                 res.update(self._combine_depth(o1["depth"], o2["depth"]))
         return res
+
+    def _side_stream(self, device):
+        key = str(device)                                           # (module-level: a Stream on the module would break copy.deepcopy(model))
+        if key not in _SIDE_STREAMS:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+        return _SIDE_STREAMS[key]
 
     def _combine_depth(self, d1, d2):
         if self.ensemble_strategy == "weighted_average":                              # model.py:472-475

@@ -756,6 +756,7 @@ def mixffn_operands_ok(gamma, beta, w1, w2) -> bool:
     return bool(torch.isfinite(vals).all().item()) and bool((vals < lim).all().item())
 
 
+TWO_STREAMS = os.environ.get("AWSEG_TWO_STREAMS", "1") != "0"    # ensemble eval: DeepLabV3+ on a side stream beside SegFormer (0: one stream)
 DEPTH_FUSED = os.environ.get("AWSEG_DEPTH_FUSED", "1") != "0"    # the SegFormer depth head as one full-resolution launch (depthfuse.hip)
 
 
@@ -808,7 +809,7 @@ def gemm_bias_act(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, act: int
         return gemm_bf16_bias_act(x, wb, bias, act, residual=residual, out=out)
     if gemm_wants_split(m, n, k) if split is None else split:
         return gemm_split_bias_act(x, w_split if w_split is not None else gemm_split_weights(w), bias, act, residual=residual, out=out)
-    ws = N.workspace.get(x.device, GEMM_WORKSPACE_BYTES, tag="gemm")
+    ws = N.workspace.get(x.device, GEMM_WORKSPACE_BYTES, tag="gemm%d" % torch.cuda.current_stream(x.device).cuda_stream)   # one per stream (TWO_STREAMS)
     key = (str(x.device), m, n, k, residual is not None, act)
     if GEMM_TUNE and m > 0 and key not in _gemm_tuned:
         _gemm_tuned.add(key)

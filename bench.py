@@ -806,11 +806,15 @@ def main():
         if args.kernel_steps > 0:
             st = new_state()
             torch.cuda.synchronize()
+            # (one stream for this pass: with the two ensemble members on two streams a launch's event pair also times whatever the
+            # other stream runs beside it — the per-kernel figures are those of each kernel with the chip to itself)
+            two_streams, ops.TWO_STREAMS = ops.TWO_STREAMS, False
             CLOCK.enabled = True
             for i in range(args.kernel_steps):
                 step(st, args.warmup + args.steps + i)
             torch.cuda.synchronize()
             CLOCK.enabled = False
+            ops.TWO_STREAMS = two_streams
 
         # ---- float32-input MFMA comparison (N = 1) -----------------------------------------------------------------
         fp32 = None
@@ -863,7 +867,8 @@ def main():
         traffic, tsrc = pmc_traffic(k0["kernel"], b5=bf16)
         roofline = {"kernel": k0["kernel"], "bound": ("mfma" if k0["bound"].startswith("mfma") else "hbm"), "achieved": k0["achieved"],
                     "peak": k0["peak"], "unit": k0["unit"], "frac": k0["frac"], "traffic": traffic, "traffic_source": tsrc,
-                    "measured": f"HIP events around each launch on the launching stream, {args.kernel_steps} untimed steps after the timed region"}
+                    "measured": f"HIP events around each launch on the launching stream, {args.kernel_steps} untimed steps after the timed region "
+                                "(the two ensemble members on ONE stream for this pass; the timed region runs them on two)"}
 
     if rank == 0:
         cpu = None
@@ -897,6 +902,7 @@ def main():
                        "bf16_mfma_kernels": (["awseg_gemm_bf16_bias_act", "awseg_conv3x3_winograd_bf16_nhwc", "awseg_attention_d32_bf16"] if bf16 else None),
                        "weights": "random init (no checkpoints offline)",
                        "parallelism": f"batch-sharded x{world}, one counter all-reduce (int64 confusion + ECE bins + AUROC histogram)",
+                       "ensemble_members_on_two_streams": bool(ops.TWO_STREAMS),
                        "dist_backend": backend},
             "rccl_ranks": world if backend == "nccl" else 0,
             "roofline": roofline, "cpu_baseline": cpu, "fp32_mfma": fp32, "resident_frames": resident if ingest else None, "kernels": kernels,

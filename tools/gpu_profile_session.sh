@@ -13,16 +13,19 @@ cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python tools/kernel_bench.py --iters 10 > gpurun_out/${R}_kernel_bench_hip_events.log 2>&1; echo "kernel_bench exit $?"
 timeout -k 10 400 python bench.py > gpurun_out/${R}_bench_line_default.json 2> gpurun_out/${R}_bench_line_default.err; echo "bench exit $?"
 cd /tmp
+export AWSEG_TWO_STREAMS=0      # the profiler passes time / count each kernel with the chip to itself (the bench lines above run the two ensemble members on two streams)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_step -o step -- python3 $GRAFT_REPO_ROOT/bench.py --steps 6 --warmup 3 --no-cpu-baseline --kernel-steps 0 --fp32-steps 0 --no-parity-pass --resident-steps 0 > $O/${R}_prof_step.log 2>&1; echo "prof step exit $?"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_step_fetch -o step -- python3 $B > $O/${R}_prof_step_fetch.log 2>&1; echo "step fetch exit $?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_step_write -o step -- python3 $B > $O/${R}_prof_step_write.log 2>&1; echo "step write exit $?"
 timeout -k 10 400 rocprofv3 --kernel-trace --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $O/${R}_prof_step_busy -o step -- python3 $B > $O/${R}_prof_step_busy.log 2>&1; echo "step busy exit $?"
 rm -f $O/${R}_prof_step_busy/*/*kernel_trace* 2>/dev/null
+unset AWSEG_TWO_STREAMS
 fi
 if [ "$PART" != "a" ]; then
 cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python bench.py --model b5_r101 > gpurun_out/${R}_bench_line_b5_r101_bf16.json 2> gpurun_out/${R}_bench_line_b5.err; echo "bench b5 exit $?"
 cd /tmp
+export AWSEG_TWO_STREAMS=0
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R}_prof_kb_trace -o kb -- python3 $K > $O/${R}_prof_kb_trace.log 2>&1; echo "kb trace exit $?"
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_kb_fetch -o kb -- python3 $K > $O/${R}_prof_kb_fetch.log 2>&1; echo "kb fetch exit $?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_kb_write -o kb -- python3 $K > $O/${R}_prof_kb_write.log 2>&1; echo "kb write exit $?"
@@ -34,6 +37,7 @@ timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${R
 TR="$GRAFT_REPO_ROOT/bench.py --mode train --steps 1 --warmup 1 --no-cpu-baseline --kernel-steps 0"
 timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${R}_prof_train_fetch -o train -- python3 $TR > $O/${R}_prof_train_fetch.log 2>&1; echo "train fetch exit $?"
 timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${R}_prof_train_write -o train -- python3 $TR > $O/${R}_prof_train_write.log 2>&1; echo "train write exit $?"
+unset AWSEG_TWO_STREAMS
 cd $GRAFT_REPO_ROOT
 timeout -k 10 500 python bench.py --mode train --steps 3 --warmup 2 > gpurun_out/${R}_bench_line_train_1024x2048_bs8.json 2> gpurun_out/${R}_bench_line_train.err; echo "bench train exit $?"
 fi

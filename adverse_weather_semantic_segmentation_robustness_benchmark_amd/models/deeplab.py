@@ -38,6 +38,7 @@ class Conv2d(nn.Conv2d):
     # residual add behind it run on that layout and the NEXT 1x1 reads it without a copy; only a spatial convolution copies its input
     # back to NCHW (MIOpen's NHWC picks for those are the slow ones).  Halves the layout copies of a bottleneck.
     keep_channels_last = os.environ.get("AWSEG_TRAIN_KEEP_CL", "1") != "0"
+    matmul_nchw = os.environ.get("AWSEG_TRAIN_MATMUL_NCHW", "1") != "0"     # 0: the channels-last F.linear form for every input layout
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         if (Conv2d.linear_in_training and x.is_cuda and torch.is_grad_enabled() and self.kernel_size == (1, 1) and self.groups == 1
@@ -45,6 +46,15 @@ class Conv2d(nn.Conv2d):
             if self.stride != (1, 1):
                 x = x[:, :, ::self.stride[0], ::self.stride[1]]
             b, c, h, w = x.shape
+            if Conv2d.matmul_nchw and not (x.stride(1) == 1 and c > 1):
+                # NCHW (or any non-channels-last) input: out[b] = W [o, c] @ x[b] [c, hw] — a batched GEMM in the tensor's OWN layout,
+                # forward and backward, so no layout copy exists anywhere around the layer (round 3's channels-last F.linear form
+                # copied every NCHW input and every gradient through torch's transposing copy kernel: 0.7 TB/s on the 17 GB head maps,
+                # 0.27 s of a 1.30 s step, profiles/r04_train_step_kernels.csv)
+                x3 = x.reshape(b, c, h * w)                              # (a view for contiguous x; the strided downsample input copies a quarter)
+                w3 = self.weight.view(1, self.out_channels, c).expand(b, -1, -1)
+                y = torch.bmm(w3, x3) if self.bias is None else torch.baddbmm(self.bias.view(1, -1, 1), w3, x3)
+                return y.view(b, self.out_channels, h, w)
             y = F.linear(x.permute(0, 2, 3, 1).reshape(b * h * w, c), self.weight.view(self.out_channels, c), self.bias)
             y = y.view(b, h, w, self.out_channels).permute(0, 3, 1, 2)
             return y if Conv2d.keep_channels_last else y.contiguous()

@@ -99,7 +99,7 @@ SIGNATURES = {
     "awseg_bn_train_workspace": (c_i64, [c_i, c_i, c_i64]),
     "awseg_bn_train_stats": (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p]),
     "awseg_bn_relu_dropout_forward": (c_i, [c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
-    "awseg_bn_relu_dropout_backward": (c_i, [c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "awseg_bn_relu_dropout_backward": (c_i, [c_p, c_p, c_i, c_i, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     "awseg_dwconv3x3_wgrad_workspace": (c_i64, [c_i64, c_i, c_i, c_i]),
     "awseg_dwconv3x3_wgrad_nhwc": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_p]),
     "awseg_mixffn_fused": (c_i, [c_p, c_i, c_i, c_i, c_i, c_p, c_p, c_f, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),

@@ -141,6 +141,52 @@ void bn_relu_drop_bwd_dx_kernel(const float* __restrict__ x, const float* __rest
     }
 }
 
+// backward pass 2 with the result stored CHANNELS-LAST ([batch, hw, C] memory): what the layer in front of the full-resolution heads'
+// BatchNorm wants — awseg_upconv3x3_adjoint reads its gradient as NHWC, and torch's permute + contiguous of the 17 GB map ran at
+// 0.7 TB/s (8 x 6.6 ms + 4 x 3.9 ms per step).  Block = (256 pixels, 32 channels, image): loads along the planes, dx through an LDS tile,
+// stores with 8 lanes per pixel (128 contiguous bytes).  C % 32 == 0, hw % 4 == 0.
+__global__ __launch_bounds__(BN_T)
+void bn_relu_drop_bwd_dx_nhwc_kernel(const float* __restrict__ x, const float* __restrict__ g, int C, int64_t hw, const float* __restrict__ mean,
+                                     const float* __restrict__ invstd, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ noise, const float* __restrict__ dbeta, const float* __restrict__ dgamma, float inv_n,
+                                     float* __restrict__ dx)
+{
+    __shared__ __attribute__((aligned(16))) float tile[256 * 36];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32;
+    const int64_t p0 = (int64_t)blockIdx.x * 256;
+    {
+        const int cl = threadIdx.x >> 3, qg = threadIdx.x & 7;
+        const int c = c0 + cl;
+        const float mu = mean[c], is = invstd[c];
+        const float a = gamma[c] * is, sh = beta[c] - mu * a;
+        const float nz = noise ? noise[(int64_t)b * C + c] : 1.0f;
+        const float mb = dbeta[c] * inv_n, mg = dgamma[c] * inv_n;
+        const int64_t base = ((int64_t)b * C + c) * hw + p0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int px = (qg + 8 * j) * 4;
+            if (p0 + px >= hw) break;                                 // hw % 4 == 0: whole float4s
+            const float4 v = *reinterpret_cast<const float4*>(x + base + px);
+            const float4 gv = *reinterpret_cast<const float4*>(g + base + px);
+            const float xs[4] = {v.x, v.y, v.z, v.w}, gs[4] = {gv.x, gv.y, gv.z, gv.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float gp = fmaf(xs[k], a, sh) > 0.f ? gs[k] * nz : 0.f;
+                const float xh = (xs[k] - mu) * is;
+                tile[(px + k) * 36 + cl] = a * ((gp - mb) - xh * mg);
+            }
+        }
+    }
+    __syncthreads();
+    const int q = threadIdx.x & 7, pl = threadIdx.x >> 3;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int px = it * 32 + pl;
+        if (p0 + px >= hw) break;
+        *reinterpret_cast<float4*>(dx + ((int64_t)b * hw + p0 + px) * C + c0 + 4 * q) = *reinterpret_cast<const float4*>(tile + px * 36 + 4 * q);
+    }
+}
+
 int bn_chunks(int64_t hw) { return (int)((hw + BN_CHUNK - 1) / BN_CHUNK); }
 
 }  // namespace
@@ -187,7 +233,7 @@ AWSEG_API int awseg_bn_relu_dropout_forward(const float* x, int batch, int chann
 
 AWSEG_API int awseg_bn_relu_dropout_backward(const float* x, const float* grad_out, int batch, int channels, int64_t hw, const float* mean,
                                              const float* invstd, const float* gamma, const float* beta, const float* noise, void* workspace,
-                                             float* dgamma, float* dbeta, float* dx, awseg_stream_t stream)
+                                             float* dgamma, float* dbeta, float* dx, int dx_channels_last, awseg_stream_t stream)
 {
     if (int rc = bn_check(x, batch, channels, hw, workspace)) return rc;
     if (!grad_out || !mean || !invstd || !gamma || !beta || !dgamma || !dbeta || !dx) return AWSEG_EINVAL;
@@ -201,6 +247,14 @@ AWSEG_API int awseg_bn_relu_dropout_backward(const float* x, const float* grad_o
     hipLaunchKernelGGL(bn_fold_kernel<1>, dim3((channels + 63) / 64), dim3(64), 0, awseg_s(stream), partial, channels, batch * nch, 1.0, dbeta, dgamma);
     AWSEG_LAUNCH_CHECK();
     const float inv_n = (float)(1.0 / ((double)batch * (double)hw));
+    if (dx_channels_last) {
+        if (channels % 32) return AWSEG_ERANGE;
+        if ((hw + 255) / 256 >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
+        hipLaunchKernelGGL(bn_relu_drop_bwd_dx_nhwc_kernel, dim3((unsigned)((hw + 255) / 256), channels / 32, batch), dim3(BN_T), 0, awseg_s(stream), x,
+                           grad_out, channels, hw, mean, invstd, gamma, beta, noise, dbeta, dgamma, inv_n, dx);
+        AWSEG_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(bn_relu_drop_bwd_dx_kernel, grid, dim3(BN_T), 0, awseg_s(stream), x, grad_out, channels, hw, mean, invstd, gamma, beta, noise,
                        dbeta, dgamma, inv_n, dx);
     AWSEG_LAUNCH_CHECK();

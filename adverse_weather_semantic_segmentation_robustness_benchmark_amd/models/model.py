@@ -286,7 +286,8 @@ class SegFormerModel(nn.Module):
                 nxt = mods[i + 1] if i + 1 < len(mods) else None
                 drop = mods[i + 2] if (i + 2 < len(mods) and isinstance(mods[i + 2], nn.Dropout2d)) else None
                 if isinstance(mods[i], nn.BatchNorm2d) and nxt is not None and ops.bn_relu_dropout2d_train_ok(z, mods[i], nxt, drop):
-                    z = ops.bn_relu_dropout2d_train(z, mods[i], drop)
+                    # (i == 0: the producer is ops._UpConv3x3, whose adjoint kernel reads its gradient as NHWC)
+                    z = ops.bn_relu_dropout2d_train(z, mods[i], drop, dx_channels_last=(i == 0))
                     i += 3 if drop is not None else 2
                 else:
                     z = mods[i](z)

@@ -578,7 +578,8 @@ class _BNReLUDropout2d(torch.autograd.Function):
     device generator), so a seeded run consumes the same random numbers as the module graph."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, p):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, momentum, eps, p, dx_channels_last=False):
+        ctx.dx_cl = bool(dx_channels_last) and x.shape[1] % 32 == 0
         b, c, h, w = x.shape
         hw = h * w
         ws = N.workspace.get(x.device, N.lib().awseg_bn_train_workspace(b, c, hw), tag="bntrain")
@@ -607,10 +608,15 @@ class _BNReLUDropout2d(torch.autograd.Function):
         hw = h * w
         g = g.contiguous()
         ws = N.workspace.get(x.device, N.lib().awseg_bn_train_workspace(b, c, hw), tag="bntrain")
-        dgamma, dbeta, dx = torch.empty_like(mean), torch.empty_like(mean), torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(mean), torch.empty_like(mean)
+        # dx_cl: the gradient leaves as an NCHW tensor over channels-last MEMORY — the layout the producer's backward reads (ops._UpConv3x3)
+        dx = torch.empty(b, h, w, c, dtype=x.dtype, device=x.device) if ctx.dx_cl else torch.empty_like(x)
         N.call("awseg_bn_relu_dropout_backward", N.ptr(x), N.ptr(g), b, c, hw, N.ptr(mean), N.ptr(invstd), N.ptr(gamma.contiguous()),
-               N.ptr(beta.contiguous()), N.ptr(noise.view(b, c) if ctx.has_noise else None), N.ptr(ws), N.ptr(dgamma), N.ptr(dbeta), N.ptr(dx), N.stream())
-        return dx, dgamma, dbeta, None, None, None, None, None
+               N.ptr(beta.contiguous()), N.ptr(noise.view(b, c) if ctx.has_noise else None), N.ptr(ws), N.ptr(dgamma), N.ptr(dbeta), N.ptr(dx),
+               int(ctx.dx_cl), N.stream())
+        if ctx.dx_cl:
+            dx = dx.permute(0, 3, 1, 2)
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
 def bn_relu_dropout2d_train_ok(x: torch.Tensor, bn, relu, drop) -> bool:
@@ -623,10 +629,12 @@ def bn_relu_dropout2d_train_ok(x: torch.Tensor, bn, relu, drop) -> bool:
             and (drop is None or (isinstance(drop, nn.Dropout2d) and drop.training)) and x.shape[0] <= 65535 and x.shape[1] <= 65535)
 
 
-def bn_relu_dropout2d_train(x: torch.Tensor, bn, drop=None) -> torch.Tensor:
+def bn_relu_dropout2d_train(x: torch.Tensor, bn, drop=None, dx_channels_last: bool = False) -> torch.Tensor:
+    """dx_channels_last: hand the input gradient back over channels-last memory (for a producer whose backward reads NHWC)."""
     if bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
-    return _BNReLUDropout2d.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, 0.0 if drop is None else float(drop.p))
+    return _BNReLUDropout2d.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.momentum, bn.eps, 0.0 if drop is None else float(drop.p),
+                                  dx_channels_last)
 
 
 def bias_act_nhwc_(x_nhwc: torch.Tensor, bias: Optional[torch.Tensor], residual: Optional[torch.Tensor] = None,

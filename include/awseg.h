@@ -645,6 +645,7 @@ int awseg_attention_d32_split(const float* q, const float* k, const float* v, fl
  * awseg_bn_relu_dropout_forward: out = max((x - mean) invstd gamma + beta, 0) * noise[b, c] (noise float32 [batch, channels]: the
  * Dropout2d channel mask already divided by 1 - p, or NULL).  awseg_bn_relu_dropout_backward: dgamma, dbeta [channels] and dx from
  * x and grad_out — xhat and the ReLU mask are recomputed from x, so autograd keeps x, two per-channel vectors and the noise only.
+ * dx_channels_last = 1 stores dx as [batch, hw, channels] memory (channels % 32 == 0): the layout awseg_upconv3x3_adjoint reads.
  * hw % 4 == 0; x, grad_out, out, dx 16-byte aligned; workspace of awseg_bn_train_workspace(batch, channels, hw) bytes. */
 int64_t awseg_bn_train_workspace(int batch, int channels, int64_t hw);
 int awseg_bn_train_stats(const float* x, int batch, int channels, int64_t hw, void* workspace, float* mean, float* var, awseg_stream_t stream);
@@ -652,7 +653,7 @@ int awseg_bn_relu_dropout_forward(const float* x, int batch, int channels, int64
                                   const float* gamma, const float* beta, const float* noise, float* out, awseg_stream_t stream);
 int awseg_bn_relu_dropout_backward(const float* x, const float* grad_out, int batch, int channels, int64_t hw, const float* mean,
                                    const float* invstd, const float* gamma, const float* beta, const float* noise, void* workspace,
-                                   float* dgamma, float* dbeta, float* dx, awseg_stream_t stream);
+                                   float* dgamma, float* dbeta, float* dx, int dx_channels_last, awseg_stream_t stream);
 
 /* awseg_dwconv3x3_wgrad_nhwc: weight and bias gradient of a depthwise 3x3 convolution (stride 1, zero padding = dilation) on float32
  * NHWC tensors x, dy [batch, height, width, channels] — the backward of the MiT Mix-FFN's depthwise convolution (transformers'

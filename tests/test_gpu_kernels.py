@@ -1528,6 +1528,20 @@ def test_bn_relu_dropout2d_train_matches_the_module_graph(ops, cfg):
         err = (a.double() - b).abs().max().item()
         assert err < 3e-5 * max(1.0, b.abs().max().item()), (cfg, name, err)
     assert int(bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    if C % 32 == 0:
+        # the same backward with the input gradient handed back over channels-last memory (what ops._UpConv3x3's adjoint reads): same values
+        x2 = x.detach().clone().requires_grad_(True)
+        torch.manual_seed(1234)
+        y2 = ops.bn_relu_dropout2d_train(x2, bn, drop, dx_channels_last=True)
+        y2.backward(gy)
+        assert x2.grad.shape == x.grad.shape and torch.equal(x2.grad.contiguous(), x.grad)     # (autograd lays a leaf's .grad out as the leaf)
+        xi = x.detach().clone().requires_grad_(True)
+        torch.manual_seed(1234)
+        mid = xi * 1.0                                                # a non-leaf in front: its incoming gradient keeps the Function's layout
+        seen = []
+        mid.register_hook(lambda gr: seen.append(gr.permute(0, 2, 3, 1).is_contiguous()))
+        ops.bn_relu_dropout2d_train(mid, bn, drop, dx_channels_last=True).backward(gy)
+        assert seen == [True] and torch.equal(xi.grad.contiguous(), x.grad)
 
 
 # ------------------------------------------------------------------ one launch for a batch of mixed conditions (awseg_weather_batch)

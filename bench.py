@@ -588,7 +588,7 @@ def train_main(args):
             roofline = {"kernel": k0["kernel"], "bound": ("mfma" if k0["bound"].startswith("mfma") else "hbm"), "achieved": k0["achieved"],
                         "peak": k0["peak"], "unit": k0["unit"], "frac": k0["frac"], "traffic": traffic, "traffic_source": tsrc,
                         "measured": "HIP events around each launch on the launching stream, one untimed step after the timed region; dominant HAND-WRITTEN "
-                                    "kernel (the forward / backward convolutions are MIOpen's: profiles/r03_train_step_kernels.csv)"}
+                                    "kernel (the forward / backward convolutions are MIOpen's: profiles/r04_train_step_kernels.csv)"}
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:

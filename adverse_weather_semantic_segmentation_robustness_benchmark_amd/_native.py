@@ -56,6 +56,7 @@ SIGNATURES = {
     "awseg_gemm_bf16_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
     "awseg_conv3x3_winograd_bf16_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "awseg_attention_d32_bf16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "awseg_attention_d32_packed_kv": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "awseg_dwconv3x3_upcat_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_winograd_split_weight_halfs": (c_i64, [c_i, c_i]),
     "awseg_conv3x3_winograd_split_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
@@ -106,6 +107,10 @@ SIGNATURES = {
     "awseg_maxpool3x3s2_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "awseg_maxpool3x3s2_bias_relu_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),
     "awseg_upsample_bilinear": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "awseg_rowdot_sigmoid": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_i, c_p, c_p]),
+    "awseg_aspp_pool_branch_workspace": (c_i64, [c_i, c_i]),
+    "awseg_aspp_pool_branch": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),
+    "awseg_upsample_bilinear_strided": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "awseg_combine_confusion_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_i, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i,
                                            c_p, c_i, c_p, c_i, c_f, c_f, c_p, c_p]),
     "awseg_ece_accumulate": (c_i, [c_p, c_i64, c_i, c_i64, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_p]),
@@ -170,6 +175,13 @@ def ptr(t):
         raise AwsegError("awseg kernels take device (HIP) tensors only; got a CPU tensor — no CPU fallback exists")
     if not t.is_contiguous():
         raise AwsegError("awseg kernels take contiguous tensors")
+    return C.c_void_p(t.data_ptr())
+
+
+def ptr_strided(t):
+    """Device pointer of a CUDA tensor handed over together with its strides (entry points that take them)."""
+    if not t.is_cuda:
+        raise AwsegError("awseg kernels take device (HIP) tensors only; got a CPU tensor — no CPU fallback exists")
     return C.c_void_p(t.data_ptr())
 
 

@@ -40,7 +40,7 @@ __device__ __forceinline__ constexpr int acc_row(int r, int hk) { return (r & 3)
 
 __global__ __launch_bounds__(AT, 2)
 void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                          float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+                          float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e, int kvp)
 {
     __shared__ float sK[2][TK * LDK];       // [key][hk*16 + s]   = K[key][2s + hk]
     __shared__ float sV[2][D * LDK];        // [d][hk*16 + r]     = V[row(r,hk)][d]
@@ -49,8 +49,8 @@ void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__
     const int h = blockIdx.y, b = blockIdx.z;
     const int C = heads * D;
     const int q0 = blockIdx.x * 128 + wave * 32;
-    const float* kb = k + ((size_t)b * nkv * heads + h) * D;
-    const float* vb = v + ((size_t)b * nkv * heads + h) * D;
+    const float* kb = k + (size_t)b * nkv * kvp + h * D;
+    const float* vb = v + (size_t)b * nkv * kvp + h * D;
 
     // Q fragment: B operand of S^T = K Q^T, B[k = d][j = query]: lane (j = li, half hk) holds d = 2s + hk
     float qf[16];
@@ -66,7 +66,7 @@ void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__
     }
     // tile staging role of this thread: key = tid / 8, 4 consecutive d = 4c..4c+3
     const int lkey = tid >> 3, lc = tid & 7;
-    const size_t g_off = (size_t)lkey * C + 4 * lc;
+    const size_t g_off = (size_t)lkey * kvp + 4 * lc;
     const int wk0 = lkey * LDK + 2 * lc;                 // sK: (d = 4c, 4c+2) -> hk 0, s = 2c, 2c+1 ; (4c+1, 4c+3) -> hk 1
     const int vkk = (lkey >> 2) & 1, vr = (lkey & 3) + 4 * (lkey >> 3);             // inverse of acc_row
     const int wv0 = (4 * lc) * LDK + vkk * 16 + vr;      // sV[d = 4c + e][vkk*16 + vr], e = 0..3
@@ -79,8 +79,8 @@ void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__
     float4 kreg = *reinterpret_cast<const float4*>(kb + g_off), vreg = *reinterpret_cast<const float4*>(vb + g_off);
     stage(0, kreg, vreg);
     if (ntiles > 1) {
-        kreg = *reinterpret_cast<const float4*>(kb + (size_t)TK * C + g_off);
-        vreg = *reinterpret_cast<const float4*>(vb + (size_t)TK * C + g_off);
+        kreg = *reinterpret_cast<const float4*>(kb + (size_t)TK * kvp + g_off);
+        vreg = *reinterpret_cast<const float4*>(vb + (size_t)TK * kvp + g_off);
     }
     __syncthreads();
 
@@ -137,8 +137,8 @@ void attention_d32_kernel(const float* __restrict__ q, const float* __restrict__
         if (t + 1 < ntiles) {
             stage(buf ^ 1, kreg, vreg);
             if (t + 2 < ntiles) {
-                kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * C + g_off);
-                vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * C + g_off);
+                kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * kvp + g_off);
+                vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * kvp + g_off);
             }
         }
         __syncthreads();
@@ -255,7 +255,7 @@ __device__ __forceinline__ h8 pack8_bf16(const float* x)
 // BASELINE config 5's bf16 MFMA path; no range guard (bf16 has float32's exponent range).
 template <bool SCALED, bool BF16 = false>
 __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e,
+                                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e, int kvp,
                                                 _Float16 (*sK)[TK * SROW], _Float16 (*sV)[D * SROW], unsigned* sMax, const attn_scales sc)
 {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -263,8 +263,8 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
     const int h = blockIdx.y, b = blockIdx.z;
     const int C = heads * D;
     const int q0 = blockIdx.x * 128 + wave * 32;
-    const float* kb = k + ((size_t)b * nkv * heads + h) * D;
-    const float* vb = v + ((size_t)b * nkv * heads + h) * D;
+    const float* kb = k + (size_t)b * nkv * kvp + h * D;
+    const float* vb = v + (size_t)b * nkv * kvp + h * D;
     float qmax = 0.f, kmax = 0.f, vmax = 0.f;
 
     // Q fragments: B operand of S^T = K Q^T, lane (query li, half hk) holds d = 16 s + 8 hk + j
@@ -288,7 +288,7 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
     }
     // tile staging role of this thread: key = tid / 8, 4 consecutive d = 4c .. 4c+3
     const int lkey = tid >> 3, lc = tid & 7;
-    const size_t g_off = (size_t)lkey * C + 4 * lc;
+    const size_t g_off = (size_t)lkey * kvp + 4 * lc;
     const int wk0 = lkey * SROW + 4 * lc;
     const int wv0 = (4 * lc) * SROW + pv_slot(lkey);
     auto stage = [&](int buf, float4 kk4, float4 vv4) {
@@ -326,8 +326,8 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
     float4 kreg = *reinterpret_cast<const float4*>(kb + g_off), vreg = *reinterpret_cast<const float4*>(vb + g_off);
     stage(0, kreg, vreg);
     if (ntiles > 1) {
-        kreg = *reinterpret_cast<const float4*>(kb + (size_t)TK * C + g_off);
-        vreg = *reinterpret_cast<const float4*>(vb + (size_t)TK * C + g_off);
+        kreg = *reinterpret_cast<const float4*>(kb + (size_t)TK * kvp + g_off);
+        vreg = *reinterpret_cast<const float4*>(vb + (size_t)TK * kvp + g_off);
     }
     __syncthreads();
 
@@ -391,8 +391,8 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
             if (t + 1 < ntiles) {
                 stage(buf ^ 1, kreg, vreg);
                 if (t + 2 < ntiles) {
-                    kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * C + g_off);
-                    vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * C + g_off);
+                    kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * kvp + g_off);
+                    vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * kvp + g_off);
                 }
             }
             __syncthreads();
@@ -410,8 +410,8 @@ __device__ __forceinline__ bool attn_split_pass(const float* __restrict__ q, con
         if (t + 1 < ntiles) {
             stage(buf ^ 1, kreg, vreg);
             if (t + 2 < ntiles) {
-                kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * C + g_off);
-                vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * C + g_off);
+                kreg = *reinterpret_cast<const float4*>(kb + (size_t)(t + 2) * TK * kvp + g_off);
+                vreg = *reinterpret_cast<const float4*>(vb + (size_t)(t + 2) * TK * kvp + g_off);
             }
         }
         __syncthreads();
@@ -450,29 +450,29 @@ __device__ __forceinline__ int guard_exponent(unsigned maxbits)
 
 __global__ __launch_bounds__(AT, AWSEG_ATTN_SPLIT_WAVES)
 void attention_d32_split_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e, int kvp)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sK[2][TK * SROW];      // [key][hi d 0..31 | lo d 0..31]
     __shared__ __attribute__((aligned(16))) _Float16 sV[2][D * SROW];       // [d][hi slot 0..31 | lo slot 0..31]
     __shared__ unsigned sMax[3];                                             // max |q*scale|, |k|, |v| bits, when >= 2^15
     if (threadIdx.x < 3) sMax[threadIdx.x] = 0u;                             // ordered by the pass's first barrier
     const attn_scales one = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    if (!attn_split_pass<false>(q, k, v, out, nq, nkv, heads, scale_log2e, sK, sV, sMax, one)) return;
+    if (!attn_split_pass<false>(q, k, v, out, nq, nkv, heads, scale_log2e, kvp, sK, sV, sMax, one)) return;
     const int eq = guard_exponent(sMax[0]), ek = guard_exponent(sMax[1]), ev = guard_exponent(sMax[2]);
     auto p2 = [](int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); };            // |e| <= 114
     const attn_scales sc = {p2(-eq), p2(-ek), p2(-ev), p2(eq), p2(ek), p2(ev)};
-    attn_split_pass<true>(q, k, v, out, nq, nkv, heads, scale_log2e, sK, sV, sMax, sc);
+    attn_split_pass<true>(q, k, v, out, nq, nkv, heads, scale_log2e, kvp, sK, sV, sMax, sc);
 }
 
 __global__ __launch_bounds__(AT, 2)
 void attention_d32_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
-                               float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+                               float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e, int kvp)
 {
     __shared__ __attribute__((aligned(16))) _Float16 sK[2][TK * SROW];
     __shared__ __attribute__((aligned(16))) _Float16 sV[2][D * SROW];
     __shared__ unsigned sMax[3];
     const attn_scales one = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-    attn_split_pass<false, true>(q, k, v, out, nq, nkv, heads, scale_log2e, sK, sV, sMax, one);
+    attn_split_pass<false, true>(q, k, v, out, nq, nkv, heads, scale_log2e, kvp, sK, sV, sMax, one);
 }
 
 }  // namespace
@@ -480,16 +480,18 @@ void attention_d32_bf16_kernel(const float* __restrict__ q, const float* __restr
 namespace {
 template <typename K>
 int launch_attention(K kernel, const float* q, const float* k, const float* v, float* out, int batch, int heads,
-                     int n_queries, int n_keys, float scale, awseg_stream_t stream)
+                     int n_queries, int n_keys, float scale, awseg_stream_t stream, int kv_pitch = 0)
 {
     if (batch == 0 || n_queries == 0) return 0;
     if (!q || !k || !v || !out || batch < 0 || heads < 1 || n_queries < 0 || n_keys < TK) return AWSEG_EINVAL;
     if (n_keys % TK) return AWSEG_ERANGE;                 // whole key tiles only (MiT: the key grid is (H/32) x (W/32) ... x sr^-2)
     if (heads > 65535 || batch > 65535) return AWSEG_ERANGE;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15)) return AWSEG_EALIGN;
+    if (kv_pitch == 0) kv_pitch = heads * D;
+    if (kv_pitch < heads * D || (kv_pitch & 3)) return AWSEG_EINVAL;
     dim3 grid((unsigned)((n_queries + 127) / 128), (unsigned)heads, (unsigned)batch);
     hipLaunchKernelGGL(kernel, grid, dim3(AT), 0, awseg_s(stream), q, k, v, out, n_queries, n_keys, heads,
-                       scale * 1.4426950408889634f);
+                       scale * 1.4426950408889634f, kv_pitch);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -511,4 +513,17 @@ AWSEG_API int awseg_attention_d32_bf16(const float* q, const float* k, const flo
                                        int n_queries, int n_keys, float scale, awseg_stream_t stream)
 {
     return launch_attention(attention_d32_bf16_kernel, q, k, v, out, batch, heads, n_queries, n_keys, scale, stream);
+}
+
+AWSEG_API int awseg_attention_d32_packed_kv(const float* q, const float* kv, float* out, int batch, int heads, int n_queries,
+                                            int n_keys, float scale, int mode, awseg_stream_t stream)
+{
+    if (!kv) return AWSEG_EINVAL;
+    const int c = heads * D;
+    switch (mode) {
+    case 0: return launch_attention(attention_d32_kernel, q, kv, kv + c, out, batch, heads, n_queries, n_keys, scale, stream, 2 * c);
+    case 1: return launch_attention(attention_d32_split_kernel, q, kv, kv + c, out, batch, heads, n_queries, n_keys, scale, stream, 2 * c);
+    case 2: return launch_attention(attention_d32_bf16_kernel, q, kv, kv + c, out, batch, heads, n_queries, n_keys, scale, stream, 2 * c);
+    default: return AWSEG_EINVAL;
+    }
 }

@@ -511,7 +511,7 @@ void upsample_bilinear_kernel(const float* __restrict__ low, int h, int w, int H
 // load -> blend -> store chain per 16 bytes and is latency-bound at 2.9 TB/s).  Same expressions: same values.
 __global__ __launch_bounds__(kThreads)
 void upsample_bilinear_4x4_kernel(const float* __restrict__ low, int h, int w, int H, int W, float sy, float sx, int align,
-                                  float* __restrict__ out, int64_t planes)
+                                  float* __restrict__ out, int64_t planes, int channels, int64_t ls_b, int64_t ls_c, int64_t ls_y, int64_t ls_x)
 {
     const int wq = W / 4, hq = (H + 3) / 4;
     const int64_t total = planes * hq * wq;
@@ -523,12 +523,15 @@ void upsample_bilinear_4x4_kernel(const float* __restrict__ low, int h, int w, i
         auto src = [&](int d, float sc) { float f = align ? sc * (float)d : sc * ((float)d + 0.5f) - 0.5f; return f < 0.f ? 0.f : f; };
         const int ya = (int)src(yq * 4, sy), xa = (int)src(xq * 4, sx);
         float c[3][3];
+        // the low-resolution map through its strides (floats): planar NCHW, or the NHWC rows a GEMM wrote — it is small and stays in L2
+        const int64_t pb = pl / channels;
+        const float* plane = low + pb * ls_b + (pl - pb * channels) * ls_c;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int yy = ya + r < h ? ya + r : h - 1;
-            const float* row = low + (pl * h + yy) * (int64_t)w;
+            const float* row = plane + yy * ls_y;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) c[r][q] = row[xa + q < w ? xa + q : w - 1];
+            for (int q = 0; q < 3; ++q) c[r][q] = row[(xa + q < w ? xa + q : w - 1) * ls_x];
         }
         float lx0[4], lx1[4]; bool fx_first[4];
 #pragma unroll
@@ -862,11 +865,16 @@ AWSEG_API int awseg_maxpool3x3s2_bias_relu_nhwc(const float* x, int64_t batch, i
     return 0;
 }
 
-AWSEG_API int awseg_upsample_bilinear(const float* low, int64_t planes, int low_height, int low_width, int height, int width,
-                                      int align_corners, float* out, awseg_stream_t stream)
+AWSEG_API int awseg_upsample_bilinear_strided(const float* low, int64_t batch, int channels, int low_height, int low_width,
+                                              int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x,
+                                              int height, int width, int align_corners, float* out, awseg_stream_t stream)
 {
+    const int64_t planes = batch * channels;
     if (planes == 0) return 0;
-    if (!low || !out || planes < 0 || low_height < 1 || low_width < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (!low || !out || batch < 0 || channels < 1 || low_height < 1 || low_width < 1 || height < 1 || width < 1) return AWSEG_EINVAL;
+    if (stride_b < 0 || stride_c < 0 || stride_y < 0 || stride_x < 0) return AWSEG_EINVAL;
+    const bool planar = stride_x == 1 && stride_y == low_width && stride_c == (int64_t)low_height * low_width &&
+                        stride_b == stride_c * channels;
     if ((width & 3) == 0 && ((uintptr_t)out & 15)) return AWSEG_EALIGN;
     // torch area_pixel_compute_scale: align_corners ? (out > 1 ? (in - 1) / (out - 1) : 0) : in / out, in float
     const float sy = align_corners ? (height > 1 ? (float)(low_height - 1) / (float)(height - 1) : 0.f) : (float)low_height / (float)height;
@@ -874,15 +882,24 @@ AWSEG_API int awseg_upsample_bilinear(const float* low, int64_t planes, int low_
     if ((width & 3) == 0 && sx * 3.0f < 1.0f && sy * 3.0f < 1.0f) {
         const int64_t blocks4 = planes * ((height + 3) / 4) * (width / 4);
         hipLaunchKernelGGL(upsample_bilinear_4x4_kernel, dim3(awseg_grid_1d(blocks4, kThreads)), dim3(kThreads), 0, awseg_s(stream), low,
-                           low_height, low_width, height, width, sy, sx, align_corners ? 1 : 0, out, planes);
+                           low_height, low_width, height, width, sy, sx, align_corners ? 1 : 0, out, planes, channels, stride_b, stride_c,
+                           stride_y, stride_x);
         AWSEG_LAUNCH_CHECK();
         return 0;
     }
+    if (!planar) return AWSEG_ERANGE;                             // the row-at-a-time kernel reads planar maps only
     const int64_t total = planes * height * ((width + 3) / 4);
     hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(awseg_grid_1d(total, kThreads)), dim3(kThreads), 0, awseg_s(stream), low,
                        low_height, low_width, height, width, sy, sx, align_corners ? 1 : 0, out, planes);
     AWSEG_LAUNCH_CHECK();
     return 0;
+}
+
+AWSEG_API int awseg_upsample_bilinear(const float* low, int64_t planes, int low_height, int low_width, int height, int width,
+                                      int align_corners, float* out, awseg_stream_t stream)
+{
+    const int64_t hw = (int64_t)low_height * low_width;
+    return awseg_upsample_bilinear_strided(low, planes, 1, low_height, low_width, hw, hw, low_width, 1, height, width, align_corners, out, stream);
 }
 
 AWSEG_API int awseg_depth_upsample_combine(const float* d1, const float* d2_low, int batch, int low_height, int low_width,

@@ -17,7 +17,7 @@ from pathlib import Path
 CSRC = Path(__file__).resolve().parent
 PKG = CSRC.parent
 LIB = PKG / "libawseg_hip.so"
-SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "backbone.hip", "depth.hip", "wino.hip", "gemm.hip", "attn.hip", "gemm_split.hip", "gemm_split3.hip", "wino_split.hip", "depthfuse.hip", "mixffn.hip", "dwtrain.hip", "bntrain.hip"]
+SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "backbone.hip", "depth.hip", "wino.hip", "gemm.hip", "attn.hip", "gemm_split.hip", "gemm_split3.hip", "wino_split.hip", "depthfuse.hip", "mixffn.hip", "dwtrain.hip", "bntrain.hip", "smallops.hip"]
 ARCH = "gfx950"
 # per-file extras.  wino.hip: the SLP vectoriser packs the scalar inverse transform of the fused-head epilogue into
 # v_pk_add_f32 fed by ~220 v_mov (and spills); the kernel packs by hand where adjacent registers make it free.

@@ -1,0 +1,141 @@
+// smallops.hip — the two tails of the DeepLabV3+ member that are too small for a GEMM kernel and used to run as library calls
+// (hipBLASLt GEMMs of 8 rows, an addmm with one output column, separate add / sigmoid passes):
+//   * awseg_rowdot_sigmoid   : out[r] = sigmoid(x[r, :] . w + b) — the 1x1 convolution to ONE channel + Sigmoid that ends
+//                              DepthEstimationHead (PKG/models/model.py:49-51) on the stride-16 map of the DeepLab member (:368);
+//   * awseg_aspp_pool_branch : smp's ASPPPooling branch after its global mean — 1x1 conv + BatchNorm + ReLU on one row per image —
+//                              followed by that branch's slice of the ASPP projection (the smp model built at model.py:262-268):
+//                              out[b, :] = relu(mean[b, :] W1^T + b1) W2^T + b2, one launch ("last block finishes" pattern).
+// Both are a few hundred KB of weights against a few rows: bound by latency, not by any pipe.
+#include "awseg_common.h"
+
+namespace {
+
+constexpr int SO_T = 256;
+
+__global__ __launch_bounds__(SO_T)
+void rowdot_sigmoid_kernel(const float* __restrict__ x, int64_t rows, int k, const float* __restrict__ w, const float* __restrict__ bias,
+                           int sigmoid, float* __restrict__ out)
+{
+    // 16 lanes per row, float4 per lane per step: a 128-wide row is two steps
+    const int sub = threadIdx.x & 15;
+    const int64_t r = ((int64_t)blockIdx.x * SO_T + threadIdx.x) >> 4;
+    float acc = 0.f;
+    if (r < rows) {
+        const float4* xr = reinterpret_cast<const float4*>(x + r * k);
+        const float4* w4 = reinterpret_cast<const float4*>(w);
+        for (int j = sub; j < k / 4; j += 16) {
+            const float4 a = xr[j], b = w4[j];
+            acc = fmaf(a.x, b.x, acc); acc = fmaf(a.y, b.y, acc); acc = fmaf(a.z, b.z, acc); acc = fmaf(a.w, b.w, acc);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 16);
+    if (r < rows && sub == 0) {
+        const float v = acc + (bias ? bias[0] : 0.f);
+        out[r] = sigmoid ? 1.0f / (1.0f + expf(-v)) : v;
+    }
+}
+
+constexpr int PB_MC = 4;        // mid channels per block
+constexpr int PB_B = 8;         // images per pass
+
+__global__ __launch_bounds__(SO_T)
+void aspp_pool_branch_kernel(const float* __restrict__ mean, int batch, int cin, const float* __restrict__ w1, const float* __restrict__ b1,
+                             int cmid, const float* __restrict__ w2, const float* __restrict__ b2, int cout, float* g_ws,
+                             unsigned* counter, float* __restrict__ out)
+{
+    __shared__ float sRed[SO_T / 64][PB_MC * PB_B];
+    __shared__ unsigned sLast;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = blockIdx.x * PB_MC;
+    for (int bb = 0; bb < batch; bb += PB_B) {
+        float acc[PB_MC][PB_B];
+#pragma unroll
+        for (int c = 0; c < PB_MC; ++c)
+#pragma unroll
+            for (int b = 0; b < PB_B; ++b) acc[c][b] = 0.f;
+        for (int j = tid; j < cin; j += SO_T) {
+            float wv[PB_MC];
+#pragma unroll
+            for (int c = 0; c < PB_MC; ++c) wv[c] = c0 + c < cmid ? w1[(int64_t)(c0 + c) * cin + j] : 0.f;
+#pragma unroll
+            for (int b = 0; b < PB_B; ++b) {
+                const float m = bb + b < batch ? mean[(int64_t)(bb + b) * cin + j] : 0.f;
+#pragma unroll
+                for (int c = 0; c < PB_MC; ++c) acc[c][b] = fmaf(wv[c], m, acc[c][b]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PB_MC; ++c)
+#pragma unroll
+            for (int b = 0; b < PB_B; ++b) {
+                float v = acc[c][b];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+                if (lane == 0) sRed[wave][c * PB_B + b] = v;
+            }
+        __syncthreads();
+        if (tid < PB_MC * PB_B) {
+            const int c = tid / PB_B, b = tid - c * PB_B;
+            if (c0 + c < cmid && bb + b < batch) {
+                float v = b1[c0 + c];
+#pragma unroll
+                for (int wv = 0; wv < SO_T / 64; ++wv) v += sRed[wv][tid];
+                g_ws[(int64_t)(bb + b) * cmid + c0 + c] = v > 0.f ? v : 0.f;
+            }
+        }
+        __syncthreads();
+    }
+    // the block that takes the last ticket sees every other block's rows of g (fence before the ticket, fence after it)
+    __threadfence();
+    if (tid == 0) sLast = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (!sLast) return;
+    __threadfence();
+    const volatile float* g = g_ws;
+    for (int o = wave; o < cout; o += SO_T / 64) {
+        for (int b = 0; b < batch; ++b) {
+            float v = 0.f;
+            for (int c = lane; c < cmid; c += 64) v = fmaf(g[(int64_t)b * cmid + c], w2[(int64_t)o * cmid + c], v);
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+            if (lane == 0) out[(int64_t)b * cout + o] = v + (b2 ? b2[o] : 0.f);
+        }
+    }
+    if (tid == 0) *counter = 0u;                                  // ready for the next launch on this workspace
+}
+
+}  // namespace
+
+AWSEG_API int awseg_rowdot_sigmoid(const float* x, int64_t rows, int k, const float* w, const float* bias, int sigmoid, float* out,
+                                   awseg_stream_t stream)
+{
+    if (rows == 0) return 0;
+    if (!x || !w || !out || rows < 0 || k < 4) return AWSEG_EINVAL;
+    if (k % 4) return AWSEG_ERANGE;
+    if (((uintptr_t)x & 15) || ((uintptr_t)w & 15)) return AWSEG_EALIGN;
+    const int64_t blocks = (rows * 16 + SO_T - 1) / SO_T;
+    if (blocks > 0x7fffffff) return AWSEG_ERANGE;
+    hipLaunchKernelGGL(rowdot_sigmoid_kernel, dim3((unsigned)blocks), dim3(SO_T), 0, awseg_s(stream), x, rows, k, w, bias, sigmoid ? 1 : 0, out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int64_t awseg_aspp_pool_branch_workspace(int batch, int cmid)
+{
+    return batch < 0 || cmid < 0 ? 0 : ((int64_t)batch * cmid + 4) * 4;
+}
+
+AWSEG_API int awseg_aspp_pool_branch(const float* mean, int batch, int cin, const float* w1, const float* b1, int cmid, const float* w2,
+                                     const float* b2, int cout, void* workspace, float* out, awseg_stream_t stream)
+{
+    if (batch == 0 || cout == 0) return 0;
+    if (!mean || !w1 || !b1 || !w2 || !workspace || !out || batch < 0 || cin < 1 || cmid < 1 || cout < 0) return AWSEG_EINVAL;
+    // workspace: [counter (16 bytes, ZERO at the first launch; the kernel leaves it zero) | g float32 [batch][cmid]]
+    unsigned* counter = reinterpret_cast<unsigned*>(workspace);
+    float* g = reinterpret_cast<float*>(workspace) + 4;
+    hipLaunchKernelGGL(aspp_pool_branch_kernel, dim3((unsigned)((cmid + PB_MC - 1) / PB_MC)), dim3(SO_T), 0, awseg_s(stream), mean, batch, cin,
+                       w1, b1, cmid, w2, b2, cout, g, counter, out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}

@@ -244,7 +244,6 @@ class DeepLabV3PlusDecoder(nn.Module):
         flat = xl.view(B * h * w, Cin)
         Cout = self.out_channels
         P = aspp.project[0].weight.view(Cout, 5 * Cout)              # [out, 5*in]
-        ps, pb = _bn_fold(aspp.project[1])
 
         def branch(inp, wmat, bn):
             from . import fused
@@ -263,22 +262,32 @@ class DeepLabV3PlusDecoder(nn.Module):
         pbn = aspp.project[1]
 
         def fold_proj():
+            ps, pb = _bn_fold(pbn)
             Pf = (P * ps[:, None]).contiguous()
             parts = [Pf[:, i * Cout:(i + 1) * Cout].contiguous() for i in range(5)]
             want = ops.gemm_wants_split(B * h * w, Cout, Cout)
-            return parts, [ops.gemm_split_weights(pp) if want else None for pp in parts[:4]], torch.zeros(Cout, device=P.device)
+            return parts, [ops.gemm_split_weights(pp) if want else None for pp in parts[:4]], torch.zeros(Cout, device=P.device), pb.contiguous()
         from . import fused
-        parts, psplit, zero_bias = fused.cached(aspp.project[0], "proj_fold%d" % int(ops.gemm_wants_split(B * h * w, Cout, Cout)),
+        parts, psplit, zero_bias, pb = fused.cached(aspp.project[0], "proj_fold%d" % int(ops.gemm_wants_split(B * h * w, Cout, Cout)),
                                                 (aspp.project[0].weight, pbn.weight, pbn.bias, pbn.running_mean, pbn.running_var), fold_proj)
         # pooling branch: global mean -> 1x1 -> BN -> ReLU; bilinear upsample of a 1x1 map is a broadcast
         pool = aspp.convs[4]
-        g = branch(xl.mean(dim=(1, 2)), pool[1].weight.view(Cout, Cin), pool[2])       # [B,256]
-        acc = (g @ parts[4].t() + pb)[:, None, :].expand(B, h * w, Cout).contiguous().view(B * h * w, Cout)
+        pw_, pbn_ = pool[1].weight.view(Cout, Cin), pool[2]
+        if xl.is_cuda and xl.dtype == torch.float32:
+            def fold_pool():
+                s_, b_ = _bn_fold(pbn_)
+                return (pw_ * s_[:, None]).contiguous(), b_.contiguous()
+            w1f, b1f = fused.cached(pbn_, "aspp_pool_fold", (pw_, pbn_.weight, pbn_.bias, pbn_.running_mean, pbn_.running_var), fold_pool)
+            g2 = ops.aspp_pool_branch(xl.mean(dim=(1, 2)), w1f, b1f, parts[4], pb)          # [B,256]: conv + BN + ReLU + projection slice
+        else:
+            g2 = branch(xl.mean(dim=(1, 2)), pw_, pbn_) @ parts[4].t() + pb
+        acc = g2[:, None, :].expand(B, h * w, Cout).contiguous().view(B * h * w, Cout)
         # branch 0: 1x1
         y = branch(flat, aspp.convs[0][0].weight.view(Cout, Cin), aspp.convs[0][1])
         ops.gemm_bias_act(y, parts[0], zero_bias, 0, residual=acc, out=acc, w_split=psplit[0])
         # branches 1-3: depthwise (HIP, all three rates at once) then pointwise GEMM
-        wdw = torch.stack([aspp.convs[1 + r][0][0].weight.view(Cin, 9).t() for r in range(3)]).contiguous()  # [3,9,C]
+        dws = [aspp.convs[1 + r][0][0].weight for r in range(3)]
+        wdw = fused.cached(aspp, "dw3taps", dws, lambda: torch.stack([t_.view(Cin, 9).t() for t_ in dws]).contiguous())  # [3,9,C]
         dw = ops.aspp_depthwise3(xl, wdw, aspp.rates).view(3, B * h * w, Cin)
         for r in range(3):
             mod = aspp.convs[1 + r]
@@ -350,7 +359,7 @@ class DeepLabV3Plus(nn.Module):
             # bound by reading the decoder map once; smaller problems stay on the library's float32 kernel)
             y2 = ops.gemm_bias_act(dl.reshape(Bq * H4 * W4, Cd), head.weight.view(head.out_channels, Cd), head.bias, 0,
                                    w_split=fused.split_weights(head, head.weight.view(head.out_channels, Cd), Bq * H4 * W4))
-            low = y2.view(Bq, H4, W4, -1).permute(0, 3, 1, 2).contiguous()  # [B,C,H/4,W/4] NCHW (small)
+            low = y2.view(Bq, H4, W4, -1).permute(0, 3, 1, 2)               # [B,C,H/4,W/4] view of the NHWC rows (ops.upsample_bilinear reads strides)
         else:
             low = head(dec).contiguous()
         up = self.segmentation_head[1]

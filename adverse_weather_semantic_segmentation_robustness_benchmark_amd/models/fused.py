@@ -182,7 +182,13 @@ def conv_gemm_nhwc(x_nhwc: torch.Tensor, conv: nn.Conv2d, w2: torch.Tensor, bias
     if ops.CONV_GATHER and c % 32 == 0 and w2.shape[1] == kh * kw * c and x_nhwc.dtype == torch.float32:
         # the A operand gathered inside the GEMM: no im2col matrix (written once, read once: 0.9 ms per step at 8 x 1024 x 2048)
         m = b * ((h + 2 * pd - kh) // st + 1) * ((w + 2 * pd - kw) // st + 1)
-        ws = split_weights(owner if owner is not None else conv, w2, m)
+        own = owner if owner is not None else conv
+        ws = split_weights(own, w2, m)
+        if ws is None and ops.SMALL_CONV_SPLIT and ops.PRECISION != "bf16" and ops.GEMM_SPLIT and m >= 128 and w2.shape[0] >= 8:
+            # MiT's sequence-reduction convolutions at stages 1 / 2 (16 384 output tokens x 32 / 64 channels): too few rows for the
+            # dispatcher's rule, but the gathered form still beats an im2col pass + a library GEMM (two launches, the matrix written
+            # and read back)
+            ws = cached(own, "wsplit_small", (w2,), lambda: ops.gemm_split_weights(w2))
         if ws is not None and not getattr(ws, "_awseg_bf16", False):
             return ops.conv_gemm_split(x_nhwc, ws, bias, act, kh, kw, st, pd)
     cols, ho, wo = ops.im2col_nhwc(x_nhwc, kh, kw, st, pd, 1, w2.shape[1])
@@ -400,6 +406,23 @@ def _linear_residual(x2: torch.Tensor, lin: nn.Linear, tok: torch.Tensor) -> tor
     return tok
 
 
+def _kv_packed(kv: torch.Tensor, a) -> torch.Tensor:
+    """[key | value] projections of the (reduced) tokens kv [...,C] -> [...,2C]: one GEMM with k_proj's and v_proj's weights stacked.
+    The handful of reduced tokens (16 384 rows at the bench shape) is below the sizes gemm_wants_split() sends to this repo's kernel
+    on its own; it goes there all the same — one launch of ~10 us either way, and the step keeps to one GEMM implementation."""
+    kp, vp = a.k_proj, a.v_proj
+    wkv, bkv = cached(a, "kvpack", [kp.weight, kp.bias, vp.weight, vp.bias],
+                      lambda: (torch.cat([kp.weight, vp.weight]).contiguous(), torch.cat([kp.bias, vp.bias]).contiguous()))
+    c = kv.shape[-1]
+    m = kv.numel() // c
+    if ops.gemm_wants_bf16(m, 2 * c, c) or ops.gemm_wants_split(m, 2 * c, c):
+        y = ops.gemm_bias_act(kv.view(m, c), wkv, bkv, N.ACT_NONE, w_split=split_weights(a, wkv, m))
+    else:
+        ws = cached(a, "kvsplit", (wkv,), lambda: ops.gemm_split_weights(wkv))
+        y = ops.gemm_bias_act(kv.view(m, c), wkv, bkv, N.ACT_NONE, w_split=ws, split=True)
+    return y.view(*kv.shape[:-1], 2 * c)
+
+
 @torch.no_grad()
 def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
     """Last-stage hidden state of transformers.SegformerModel as [B,h,w,C] (NHWC).  Same arithmetic
@@ -437,15 +460,19 @@ def mit_features_nhwc(seg, x: torch.Tensor) -> torch.Tensor:
                 kv = _ln(kv, sr.layer_norm)
             else:
                 kv = hcur
-            k = _linear(kv, a.k_proj)
-            v = _linear(kv, a.v_proj)
             nh, d = a.num_attention_heads, a.head_dim
             nkv = kv.shape[1] * kv.shape[2]
-            if d == 32 and nkv % 32 == 0:
-                # exact-fp32 flash attention on the matrix cores, token-major in and out (no head transposes)
+            if (d == 32 and nkv % 32 == 0 and ops.KV_PACKED and kv.is_cuda and kv.dtype == torch.float32 and C % 8 == 0
+                    and a.k_proj.bias is not None and a.v_proj.bias is not None and kv.is_contiguous()):
+                # the key and the value projection as ONE GEMM over the stacked weights; the attention kernel (exact-fp32-grade flash
+                # attention on the matrix cores, token-major in and out) reads a token's key and value from the two halves of its row
+                o = ops.attention_d32_packed_kv(q.view(B, H * W, C), _kv_packed(kv, a).view(B, nkv, 2 * C), nh, a.scaling).view(B * H * W, C)
+            elif d == 32 and nkv % 32 == 0:
+                k, v = _linear(kv, a.k_proj), _linear(kv, a.v_proj)
                 o = ops.attention_d32(q.view(B, H * W, C), k.reshape(B, nkv, C), v.reshape(B, nkv, C), nh, a.scaling).view(B * H * W, C)
             else:
                 # other head widths (MiT-B1..B5: 64): torch's fused attention; in bf16 mode on bf16 operands (bf16 MFMA path)
+                k, v = _linear(kv, a.k_proj), _linear(kv, a.v_proj)
                 qq, kk, vv = (t_.view(B, -1, nh, d).transpose(1, 2) for t_ in (q.view(B, H * W, C), k.reshape(B, -1, C), v.reshape(B, -1, C)))
                 if ops.PRECISION == "bf16":
                     o = F.scaled_dot_product_attention(qq.bfloat16(), kk.bfloat16(), vv.bfloat16(), scale=a.scaling).float()

@@ -168,6 +168,9 @@ class DepthEstimationHead(nn.Module):
         if h[7].kernel_size == (1, 1):
             yl = fused.nhwc_view(y)
             Bq, hh, ww, Cc = yl.shape
+            if h[7].out_channels == 1 and Cc % 4 == 0 and yl.is_cuda and yl.dtype == torch.float32:
+                d = ops.rowdot_sigmoid(yl.reshape(Bq * hh * ww, Cc), h[7].weight.view(Cc), h[7].bias)     # 1x1 to one channel + Sigmoid
+                return d.view(Bq, 1, hh, ww)
             d = torch.addmm(h[7].bias, yl.reshape(Bq * hh * ww, Cc), h[7].weight.view(h[7].out_channels, Cc).t())
             return torch.sigmoid(d).view(Bq, hh, ww, -1).permute(0, 3, 1, 2).contiguous()
         return torch.sigmoid(h[7](y))
@@ -419,7 +422,10 @@ class EnsembleModel(nn.Module):
         finally:
             self.deeplabv3plus._defer_depth_upsample = False
         mode = _STRATEGY.get(self.ensemble_strategy, N.COMBINE_MEAN)
-        w = F.softmax(self.ensemble_weights, dim=0) if mode == N.COMBINE_WEIGHTED else None
+        # (softmax of the two ensemble weights: once per value of the parameter, not once per use — the combine and the depth combine
+        # of every eval step read the same two floats)
+        w = fused.cached(self, "ens_softmax", [self.ensemble_weights], lambda: F.softmax(self.ensemble_weights, dim=0)) \
+            if mode == N.COMBINE_WEIGHTED else None
         T = self.temperature if self.temperature_scaling else None
         if (stats is not None and not want_logits and not want_pred and labels is not None and counts is not None
                 and mode in (N.COMBINE_WEIGHTED, N.COMBINE_MEAN) and o1["segmentation"].shape[1] == 19
@@ -440,7 +446,8 @@ class EnsembleModel(nn.Module):
             res["prediction"] = pred
         if self.include_depth:
             if "depth_low" in o2:
-                wd = F.softmax(self.ensemble_weights, dim=0) if self.ensemble_strategy == "weighted_average" else None
+                wd = fused.cached(self, "ens_softmax", [self.ensemble_weights], lambda: F.softmax(self.ensemble_weights, dim=0)) \
+                    if self.ensemble_strategy == "weighted_average" else None
                 d2, d = ops.depth_upsample_combine(o1["depth"], o2["depth_low"], wd)
                 res.update({"depth": d, "segformer_depth": o1["depth"], "deeplabv3plus_depth": d2})
             else:

@@ -845,6 +845,8 @@ GEMM_SPLIT_N64 = os.environ.get("AWSEG_GEMM_SPLIT_N64", "1") != "0"
 
 
 GEMM_SPLIT_NARROW = os.environ.get("AWSEG_GEMM_SPLIT_NARROW", "1") != "0"
+KV_PACKED = os.environ.get("AWSEG_KV_PACKED", "1") != "0"              # key + value projections as one GEMM, packed rows into attention
+SMALL_CONV_SPLIT = os.environ.get("AWSEG_SMALL_CONV_SPLIT", "1") != "0"  # gathered-operand GEMM for the small patch convolutions too
 
 
 def gemm_wants_split(m: int, n: int, k: int) -> bool:
@@ -992,6 +994,18 @@ def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
     return out
 
 
+def attention_d32_packed_kv(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float, split: Optional[bool] = None) -> torch.Tensor:
+    """attention_d32 with keys and values packed per token: kv [B,Nkv,2*heads*32] = [key | value], as one GEMM over the stacked key /
+    value projection weights writes them.  Same kernels, same values."""
+    q, kv = q.contiguous(), kv.contiguous()
+    b, nq, c = q.shape
+    assert kv.shape[-1] == 2 * c
+    out = torch.empty_like(q)
+    mode = 2 if (split is None and PRECISION == "bf16") else (1 if (ATTENTION_SPLIT if split is None else split) else 0)
+    N.call("awseg_attention_d32_packed_kv", N.ptr(q), N.ptr(kv), N.ptr(out), b, heads, nq, kv.shape[1], float(scale), mode, N.stream())
+    return out
+
+
 # Compute precision of the dense contractions (1x1 convolutions / Linear layers, 3x3 Winograd convolutions, attention):
 # "f32" = float32-grade results (split-operand f16 MFMA or float32-input MFMA, see set_split), "bf16" = one bf16 MFMA per
 # product tile with float32 accumulation (BASELINE config 5).  Models switch it for the duration of their forward.
@@ -1091,11 +1105,41 @@ def maxpool3x3s2_nhwc(x_nhwc: torch.Tensor, shift: Optional[torch.Tensor] = None
 def upsample_bilinear(x: torch.Tensor, size, align_corners: bool) -> torch.Tensor:
     """F.interpolate(x, size, mode="bilinear", align_corners=...) / nn.UpsamplingBilinear2d on an NCHW float32 tensor, torch's
     arithmetic (bit-identical), 4 output pixels per lane."""
-    x = x.contiguous()
     b, c, h, w = x.shape
     H, W = int(size[0]), int(size[1])
+    # upsampling by more than 3 (the 4 x 4-pixels-per-lane kernel) reads the small map through its strides: an NCHW view of NHWC rows
+    # — what the 19-class head's GEMM writes — needs no planar copy
+    if not (x.is_contiguous() or (W % 4 == 0 and 3 * w < W and 3 * h < H and all(s_ >= 0 for s_ in x.stride()))):
+        x = x.contiguous()
     out = torch.empty(b, c, H, W, dtype=torch.float32, device=x.device)
-    N.call("awseg_upsample_bilinear", N.ptr(x), b * c, h, w, H, W, int(bool(align_corners)), N.ptr(out), N.stream())
+    sb, sc, sy, sx = x.stride()
+    N.call("awseg_upsample_bilinear_strided", N.ptr_strided(x), b, c, h, w, sb, sc, sy, sx, H, W, int(bool(align_corners)), N.ptr(out), N.stream())
+    return out
+
+
+def rowdot_sigmoid(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], sigmoid: bool = True) -> torch.Tensor:
+    """sigmoid(x @ w + bias) for x [rows,k], w [k] -> [rows]: a 1x1 convolution to one channel (+ Sigmoid) on NHWC rows."""
+    x, w = x.contiguous(), w.contiguous().view(-1)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    N.call("awseg_rowdot_sigmoid", N.ptr(x), x.shape[0], x.shape[1], N.ptr(w), N.ptr(bias), int(bool(sigmoid)), N.ptr(out), N.stream())
+    return out
+
+
+_pool_branch_ws = {}
+
+
+def aspp_pool_branch(mean: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: Optional[torch.Tensor]) -> torch.Tensor:
+    """relu(mean @ w1^T + b1) @ w2^T + b2 for one row per image (the ASPP pooling branch and its slice of the projection), one launch."""
+    mean, w1, b1, w2 = mean.contiguous(), w1.contiguous(), b1.contiguous(), w2.contiguous()
+    b, cin = mean.shape
+    cmid, cout = w1.shape[0], w2.shape[0]
+    key = (str(mean.device), b, cmid)
+    ws = _pool_branch_ws.get(key)
+    if ws is None:                                                # zeroed once: the kernel leaves its ticket counter at zero
+        ws = _pool_branch_ws[key] = torch.zeros(int(N.lib().awseg_aspp_pool_branch_workspace(b, cmid)), dtype=torch.uint8, device=mean.device)
+    out = torch.empty(b, cout, dtype=torch.float32, device=mean.device)
+    N.call("awseg_aspp_pool_branch", N.ptr(mean), b, cin, N.ptr(w1), N.ptr(b1), cmid, N.ptr(w2), N.ptr(None if b2 is None else b2.contiguous()),
+           cout, N.ptr(ws), N.ptr(out), N.stream())
     return out
 
 

@@ -592,6 +592,13 @@ int awseg_conv3x3_winograd_bf16_nhwc(const float* x, int batch, int height, int 
                                      const float* w2, const float* b2, float* out, awseg_stream_t stream);
 int awseg_attention_d32_bf16(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                              int n_queries, int n_keys, float scale, awseg_stream_t stream);
+/* The same three attention kernels on PACKED keys and values: kv float32 [B, n_keys, 2*heads*32] holds a token's key in its first
+ * heads*32 floats and its value in the last — what ONE GEMM with the key and value projections' weights stacked ([2C, C]) writes,
+ * so that SegformerEfficientSelfAttention's two projections of the reduced tokens (transformers modeling_segformer.py, behind
+ * PKG/models/model.py:186-200) are one launch.  mode 0: float32 MFMA, 1: split operands, 2: bf16.  Same results as the unpacked
+ * entry points on the same numbers (the kernels only differ in the row pitch they read keys and values with). */
+int awseg_attention_d32_packed_kv(const float* q, const float* kv, float* out, int batch, int heads, int n_queries,
+                                  int n_keys, float scale, int mode, awseg_stream_t stream);
 
 /* awseg_upconv3x3_linear / awseg_upconv3x3_adjoint: the TRAINING form of the upsample-free head stage (BASELINE config 4).
  * PKG/models/model.py:209-214 runs conv3x3(F.interpolate(f, (H,W), bilinear, align_corners=False)) at full resolution (2.47
@@ -696,6 +703,29 @@ int awseg_maxpool3x3s2_bias_relu_nhwc(const float* x, int64_t batch, int height,
  * builds at PKG/models/model.py:262-268) and F.interpolate(..., mode="bilinear") calls on logit / depth planes. */
 int awseg_upsample_bilinear(const float* low, int64_t planes, int low_height, int low_width,
                             int height, int width, int align_corners, float* out, awseg_stream_t stream);
+/* The same upsampling of a low-resolution map that is NOT planar: element (b, c, y, x) at low[b*stride_b + c*stride_c +
+ * y*stride_y + x*stride_x] (strides in floats, >= 0) — e.g. the NHWC rows [B*h*w, C] the 19-class head's GEMM wrote
+ * (stride_b = h*w*C, stride_c = 1, stride_y = w*C, stride_x = C), so that no NCHW copy of them is made.  out is planar
+ * [batch, channels, height, width].  Upsampling by more than 3 in both directions with width % 4 == 0 takes any strides; other
+ * scales take planar maps only (AWSEG_ERANGE otherwise).  Same arithmetic, same values. */
+int awseg_upsample_bilinear_strided(const float* low, int64_t batch, int channels, int low_height, int low_width,
+                                    int64_t stride_b, int64_t stride_c, int64_t stride_y, int64_t stride_x,
+                                    int height, int width, int align_corners, float* out, awseg_stream_t stream);
+
+/* out[r] = sigmoid(x[r, :] . w + bias[0]) (sigmoid = 0: the plain sum) for x float32 [rows, k], k % 4 == 0: the 1x1 convolution to
+ * one channel + nn.Sigmoid that ends DepthEstimationHead (PKG/models/model.py:49-51) on NHWC rows, for hidden widths the fused
+ * Winograd epilogue (64) does not take — the DeepLab member's stride-16 depth map (model.py:368).  float32 FMAs, 1 / (1 + expf(-v)). */
+int awseg_rowdot_sigmoid(const float* x, int64_t rows, int k, const float* w, const float* bias, int sigmoid, float* out,
+                         awseg_stream_t stream);
+
+/* smp's ASPPPooling branch behind its global mean, and that branch's slice of the ASPP projection (the model built at
+ * PKG/models/model.py:262-268), for one row per image: out[b, :] = relu(mean[b, :] w1^T + b1) w2^T + b2 with mean [batch, cin],
+ * w1 [cmid, cin] and b1 [cmid] (BatchNorm folded), w2 [cout, cmid], b2 [cout] or NULL.  One launch; workspace =
+ * awseg_aspp_pool_branch_workspace(batch, cmid) bytes whose first 16 are ZERO at the first launch (the kernel leaves them zero);
+ * one launch at a time per workspace. */
+int64_t awseg_aspp_pool_branch_workspace(int batch, int cmid);
+int awseg_aspp_pool_branch(const float* mean, int batch, int cin, const float* w1, const float* b1, int cmid, const float* w2,
+                           const float* b2, int cout, void* workspace, float* out, awseg_stream_t stream);
 
 /* awseg_depth_upsample_combine: the depth tail of the ensemble in one pass — d2_full = bilinear upsample
  * (align_corners=False) of the stride-16 DeepLab depth map d2_low [B,h,w] to [B,H,W] (PKG/models/model.py:368-371) and

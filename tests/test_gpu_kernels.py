@@ -1570,3 +1570,57 @@ def test_weather_batch_one_launch_equals_the_per_kind_launchers(ops, shape, monk
     assert np.array_equal(res[True][0], res[False][0])
     assert np.array_equal(res[True][1], res[False][1])
     assert not np.array_equal(res[True][0], imgs.cpu().numpy())          # something was corrupted at all
+
+
+def test_upsample_bilinear_reads_nhwc_rows_through_strides(ops):
+    """The 19-class head's GEMM writes NHWC rows; the x4 upsampling reads them through the strides of the NCHW view — same
+    values, bit for bit, as on a planar copy (and a non-x4 scale, which takes planar maps only, makes that copy itself)."""
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rows = torch.randn(2, 24, 40, 19, device="cuda", generator=g)              # [B,h,w,C]
+    view = rows.permute(0, 3, 1, 2)
+    assert not view.is_contiguous()
+    for size, align in (((96, 160), True), ((96, 160), False), ((48, 80), True)):
+        ref = ops.upsample_bilinear(view.contiguous(), size, align)
+        got = ops.upsample_bilinear(view, size, align)
+        assert torch.equal(got, ref)
+    assert ops.N.lib().awseg_upsample_bilinear_strided(ops.N.ptr(rows), 2, 19, 24, 40, 24 * 40 * 19, 1, 40 * 19, 19, 48, 80, 1,
+                                                      ops.N.ptr(torch.empty(2, 19, 48, 80, device="cuda")), None) == -2     # AWSEG_ERANGE
+
+
+@pytest.mark.parametrize("shape", [(2, 1, 200, 64), (1, 2, 128, 32), (2, 5, 300, 2048)])
+def test_attention_d32_packed_keys_and_values(ops, shape):
+    """Keys and values packed per token ([key | value] rows, as one GEMM over the stacked projection weights writes them): the
+    three kernels read them with the doubled row pitch and return what they return on separate tensors."""
+    B, nh, nq, nkv = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape) + 3)
+    C = nh * 32
+    q = torch.randn(B, nq, C, device="cuda", generator=g)
+    kv = torch.randn(B, nkv, 2 * C, device="cuda", generator=g)
+    k, v = kv[..., :C].contiguous(), kv[..., C:].contiguous()
+    for split in (False, True):
+        assert torch.equal(ops.attention_d32_packed_kv(q, kv, nh, 32 ** -0.5, split=split), ops.attention_d32(q, k, v, nh, 32 ** -0.5, split=split))
+    with ops.precision("bf16"):
+        assert torch.equal(ops.attention_d32_packed_kv(q, kv, nh, 32 ** -0.5), ops.attention_d32(q, k, v, nh, 32 ** -0.5))
+
+
+def test_rowdot_sigmoid_and_aspp_pool_branch_vs_float64(ops):
+    """The two small tails of the DeepLab member: 1x1 convolution to one channel + Sigmoid on NHWC rows, and the ASPP pooling
+    branch (1x1 + folded BatchNorm + ReLU on one row per image, then its slice of the projection) — against float64; the pooled
+    branch twice on the same workspace (its ticket counter must be back at zero) and with a batch above one pass of the kernel."""
+    g = torch.Generator(device="cuda").manual_seed(17)
+    x = torch.randn(1000, 128, device="cuda", generator=g)
+    w = torch.randn(128, device="cuda", generator=g) * 0.1
+    b = torch.randn(1, device="cuda", generator=g)
+    ref = torch.sigmoid(x.double() @ w.double() + b.double())
+    assert (ops.rowdot_sigmoid(x, w, b).double() - ref).abs().max().item() < 1e-6
+    assert (ops.rowdot_sigmoid(x, w, None, sigmoid=False).double() - x.double() @ w.double()).abs().max().item() < 1e-5
+    for batch, cin, cmid, cout in ((8, 2048, 256, 256), (11, 520, 30, 19)):
+        mean = torch.randn(batch, cin, device="cuda", generator=g)
+        w1 = torch.randn(cmid, cin, device="cuda", generator=g) / cin ** 0.5
+        b1 = torch.randn(cmid, device="cuda", generator=g)
+        w2 = torch.randn(cout, cmid, device="cuda", generator=g) / cmid ** 0.5
+        b2 = torch.randn(cout, device="cuda", generator=g)
+        ref = torch.relu(mean.double() @ w1.double().t() + b1.double()) @ w2.double().t() + b2.double()
+        for _ in range(2):
+            got = ops.aspp_pool_branch(mean, w1, b1, w2, b2)
+            assert (got.double() - ref).abs().max().item() < 2e-5

@@ -606,6 +606,37 @@ AWSEG_API int awseg_gemm_split_bias_act(const float* x, const uint16_t* w_split,
     return gemm_launch(false, x, w_split, bias, residual, act, out, m, n, k, stream);
 }
 
+AWSEG_API int awseg_gemm_split_dual_bias_act(const float* x, int k1, const float* x2, int k2, int64_t batch, int x2_height, int x2_width,
+                                             int x2_stride, const uint16_t* w_split, const float* bias, const float* residual, int act,
+                                             float* out, int64_t m, int n, awseg_stream_t stream)
+{
+    if (m == 0 || n == 0) return 0;
+    if (!x || !x2 || !w_split || !out || m < 0 || n < 0 || k1 < 32 || k2 < 32 || act < 0 || act > 1 || x2_stride < 0) return AWSEG_EINVAL;
+    if (k1 % 32 || k2 % 32) return AWSEG_ERANGE;                  // whole 32-deep K tiles from either source
+    if (((uintptr_t)x & 15) || ((uintptr_t)x2 & 15) || ((uintptr_t)w_split & 15)) return AWSEG_EALIGN;
+    const int k = k1 + k2;
+    if (!awseg_gemm_split3_eligible(m, n, k, x, out, residual, bias)) return AWSEG_ERANGE;
+    awseg_g3_dual d;
+    d.x2 = x2; d.k1 = k1; d.stride = x2_stride; d.h = d.w = d.ho = d.wo = 1;
+    if (x2_stride > 0) {
+        if (batch < 1 || x2_height < 1 || x2_width < 1) return AWSEG_EINVAL;
+        d.h = x2_height; d.w = x2_width; d.ho = (x2_height - 1) / x2_stride + 1; d.wo = (x2_width - 1) / x2_stride + 1;
+        if (batch * d.ho * d.wo != m) return AWSEG_EINVAL;
+        d.bytes = batch * (int64_t)x2_height * x2_width * k2 * 4;
+    } else {
+        d.bytes = m * (int64_t)k2 * 4;
+    }
+    if (d.bytes > 0x7fffffff) return AWSEG_ERANGE;                // 32-bit offsets into the second source
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
+        cus = n_cu;
+    }
+    return awseg_gemm_split3_launch(x, w_split + 2 * (int64_t)n * k + 8, reinterpret_cast<const unsigned*>(w_split + 2 * (int64_t)n * k), bias, residual,
+                                    act, out, m, n, k, cus, awseg_s(stream), nullptr, false, &d);
+}
+
 AWSEG_API int awseg_conv_gemm_split_bias_act(const float* x, int64_t batch, int height, int width, int channels, int kernel_h,
                                              int kernel_w, int stride, int pad, int dilation, const uint16_t* w_split,
                                              const float* bias, const float* residual, int act, float* out, int n,

@@ -94,6 +94,11 @@ struct g3_args {
     // ox * cs - cpx, one tap per kernel row (ckw = 1); the image is zero-padded on the left / right so that a run never leaves its row
     int cpitch, cpx;
     int64_t x_bytes;
+    // DUAL: the A operand is [x | x2] along K — columns k < K1 from x (rows of K1 floats), the other K - K1 from x2: rows of
+    // K - K1 floats (x2s == 0), or the pixels (b, oy * x2s, ox * x2s) of an NHWC image [B, x2H, x2W, K - K1] for output row
+    // m = (b, oy, ox) of an x2Ho x x2Wo grid — a 1x1 convolution of stride x2s on the block's input (awseg_gemm_split_dual_bias_act)
+    const float* x2; int K1, x2H, x2W, x2s, x2Ho, x2Wo;
+    int64_t x2_bytes;
 };
 
 // ABL != 0: ablation builds for measurements (wrong results, valid times; AWSEG_G3_ABL): 1 no LDS-DMA in the K loop, 2 no MFMAs,
@@ -112,11 +117,12 @@ __device__ __forceinline__ unsigned pack_bf16_3(float x, float y) { return __bui
 // 64 KB — TWO blocks per CU, so that one block's epilogue (its stores leave a CU at ~15 B/clk: 17 k cycles for a 256 x 256 tile,
 // a third of a K = 256 tile's time) runs beside the other block's K loop; the price is NT <= 4 (every activation
 // fragment is split once per 128 columns instead of 256) and twice the weight traffic from L2 per product.
-template <bool CONV, int ABL = 0, bool BF16 = false, int NT = 8, int WV = 8>
+template <bool CONV, int ABL = 0, bool BF16 = false, int NT = 8, int WV = 8, bool DUAL = false>
 __global__ __launch_bounds__(64 * WV, 2)
 void gemm_split3_kernel(g3_args a)
 {
     static_assert(NT <= WV, "a weight stage must fit an activation stage");
+    static_assert(!DUAL || (!CONV && !BF16), "two A sources: the plain split-operand form only");
     constexpr int G3M = 32 * WV, G3_STAGE = G3M * 128, G3_A0 = 0, G3_B0 = 2 * G3_STAGE;    // A stage s at s * G3_STAGE, B stage s at 2 G3_STAGE + s * G3_BSTAGE
     constexpr int G3_BSTAGE = WV == 8 ? G3_STAGE : 32 * NT * 128;                          // (eight waves: the round's layout; four: the tile's own width)
     constexpr int BN = 32 * NT;
@@ -142,15 +148,19 @@ void gemm_split3_kernel(g3_args a)
     // each operand's 256-row stage.  Lane l -> row 8 q + (l >> 3), slot l & 7, which holds source chunk slot ^ ((row >> 1) & 7).
     const int rl = lane >> 3, sl = lane & 7;
     uint32_t a_voff[4], a_voff_last[4], b_voff[4];
+    uint32_t a_voff2[4];                                           // DUAL: this lane's rows in the second source
+    const int KA = DUAL ? a.K1 : a.K;                              // row length of x
+    const int kt1 = KA / G3K;                                      // DUAL: K tiles kt >= kt1 come from x2
     int cby[4], cy0[4], cx0[4];                                    // CONV: image row base b * cH, first tap's input row / column of this lane's A rows (< 0: row past M)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr3(smem));
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar register: the LDS-DMA base goes through m0
-    __amdgpu_buffer_rsrc_t x_rsrc, w_rsrc;
+    __amdgpu_buffer_rsrc_t x_rsrc, w_rsrc, x2_rsrc;
     auto point = [&](int64_t m0, int n0) {
         const int64_t rows_left = a.M - m0;                      // rows past M: out-of-range source -> zeros, never stored
-        const int64_t xbytes = rows_left * (int64_t)K * 4;
+        const int64_t xbytes = rows_left * (int64_t)KA * 4;
         if (CONV) x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
-        else x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * K), 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
+        else x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * KA), 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
+        if (DUAL) x2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, (int)a.x2_bytes, 0x00020000);
         // the weight image is [n-tile of IB rows][kb K tiles][IB rows][ROWB bytes]; this block's BN rows start at row n0 % IB of n-tile n0 / IB
         const int IB = a.img_bn, nr = n0 % IB;
         w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + ((int64_t)(n0 - nr) * kb + nr) * (ROWB / 2)), 0, (IB * kb - nr) * ROWB, 0x00020000);
@@ -158,8 +168,20 @@ void gemm_split3_kernel(g3_args a)
         for (int j = 0; j < 4; ++j) {
             const int row = 8 * (4 * wave + j) + rl;
             const int c = sl ^ ((row >> 1) & 7);
-            a_voff[j] = (uint32_t)(row * K * 4 + c * 16);
+            a_voff[j] = (uint32_t)(row * KA * 4 + c * 16);
             a_voff_last[j] = (ktail == 0 || c * 4 < ktail) ? a_voff[j] : 0x80000000u;     // chunks past K read zeros (the weight image is zero there too)
+            if (DUAL) {
+                const int64_t m = m0 + row;
+                const int k2 = a.K - a.K1;
+                int64_t pix = m;                                   // plain rows
+                if (a.x2s > 0) {
+                    const int b = (int)(m / ((int64_t)a.x2Ho * a.x2Wo));
+                    const int rem = (int)(m - (int64_t)b * a.x2Ho * a.x2Wo);
+                    const int oy = rem / a.x2Wo, ox = rem - oy * a.x2Wo;
+                    pix = ((int64_t)b * a.x2H + oy * a.x2s) * a.x2W + ox * a.x2s;
+                }
+                a_voff2[j] = m < a.M ? (uint32_t)(pix * k2 * 4 + c * 16) : 0x80000000u;
+            }
             {   // weights: instruction wave * NBI + j covers 1 KB = 8 (split: 128-byte rows) or 16 (bf16: 64-byte rows) rows of the K tile
                 const int qi = wave * NBI + j;
                 if (BF16) {
@@ -193,8 +215,13 @@ void gemm_split3_kernel(g3_args a)
                 dma16(x_rsrc, vo, 0u, la + (uint32_t)(j * 1024));
             }
         } else {
+        if (DUAL && kt >= kt1) {                                   // (block-uniform)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(x_rsrc, kt == nkt - 1 ? a_voff_last[j] : a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
+            for (int j = 0; j < 4; ++j) dma16(x2_rsrc, a_voff2[j], (uint32_t)((kt - kt1) * 128), la + (uint32_t)(j * 1024));
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dma16(x_rsrc, kt == nkt - 1 ? a_voff_last[j] : a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
+        }
         }
         {
             const uint32_t lbw = lds0 + (uint32_t)(G3_B0 + stage * G3_BSTAGE) + wave_u * (uint32_t)(NBI * 1024);
@@ -573,9 +600,16 @@ bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const vo
 }
 
 int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned* trailer, const float* bias, const float* residual,
-                             int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv, bool bf16)
+                             int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv, bool bf16,
+                             const awseg_g3_dual* dual)
 {
     g3_args a;
+    a.x2 = nullptr; a.K1 = k; a.x2H = a.x2W = a.x2Ho = a.x2Wo = 1; a.x2s = 0; a.x2_bytes = 0;
+    if (dual) {
+        if (conv || bf16 || dual->k1 % G3K || (k - dual->k1) % G3K || dual->k1 < G3K || k - dual->k1 < G3K || dual->bytes > 0x7fffffff) return AWSEG_ERANGE;
+        a.x2 = dual->x2; a.K1 = dual->k1; a.x2H = dual->h; a.x2W = dual->w; a.x2s = dual->stride; a.x2Ho = dual->ho; a.x2Wo = dual->wo;
+        a.x2_bytes = dual->bytes;
+    }
     a.cH = a.cW = a.cC = a.cHo = a.cWo = a.ckw = a.cs = 1; a.cp = 0; a.cd = 1; a.x_bytes = 0; a.cpitch = 1; a.cpx = 0;
     if (conv) {                                                   // {H, W, C, Ho, Wo, kw, stride, pad, dil, batch, pixel pitch (0: C), pad x (-1: pad)}
         a.cH = conv[0]; a.cW = conv[1]; a.cC = conv[2]; a.cHo = conv[3]; a.cWo = conv[4]; a.ckw = conv[5]; a.cs = conv[6]; a.cp = conv[7]; a.cd = conv[8];
@@ -623,7 +657,7 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     if (blocks > slots) blocks = slots;
     static int abl = -1;
     if (abl < 0) { const char* e = getenv("AWSEG_G3_ABL"); abl = e ? atoi(e) : 0; }
-    if (abl && !conv && !bf16 && bn == 256) {
+    if (abl && !conv && !bf16 && !dual && bn == 256) {
 #define G3_ABL(n) case n: { auto kf = gemm_split3_kernel<false, n>; (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds(8, 8)); hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(512), g3_lds(8, 8), stream, a); break; }
         switch (abl) { G3_ABL(1) G3_ABL(2) G3_ABL(3) G3_ABL(4) G3_ABL(5) default: break; }
 #undef G3_ABL
@@ -643,11 +677,27 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
     } while (0)
 #define G3_BY_NT(CONV_, BF_) do { if (bn == 256) G3_GO(CONV_, BF_, 8, 8); else if (bn == 128) G3_GO(CONV_, BF_, 4, 8); else G3_GO(CONV_, BF_, 2, 8); } while (0)
 #define G3_HALF(CONV_) do { if (bn == 128) G3_GO(CONV_, false, 4, 4); else G3_GO(CONV_, false, 2, 4); } while (0)
-    if (bf16) G3_BY_NT(false, true);
+#define G3_GO_DUAL(NT_, WV_)                                                                                                            \
+    do {                                                                                                                              \
+        auto kf = gemm_split3_kernel<false, 0, false, NT_, WV_, true>;                                                                \
+        static bool attr = false;                                                                                                     \
+        if (!attr) {                                                                                                                  \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, g3_lds(WV_, NT_)); \
+            if (e != hipSuccess) return (int)e;                                                                                       \
+            attr = true;                                                                                                              \
+        }                                                                                                                             \
+        hipLaunchKernelGGL(kf, dim3((unsigned)blocks), dim3(64 * WV_), g3_lds(WV_, NT_), stream, a);                                       \
+    } while (0)
+    if (dual) {
+        if (half) { if (bn == 128) G3_GO_DUAL(4, 4); else G3_GO_DUAL(2, 4); }
+        else if (bn == 256) G3_GO_DUAL(8, 8); else if (bn == 128) G3_GO_DUAL(4, 8); else G3_GO_DUAL(2, 8);
+    }
+    else if (bf16) G3_BY_NT(false, true);
     else if (half && conv) G3_HALF(true);
     else if (half) G3_HALF(false);
     else if (conv) G3_BY_NT(true, false);
     else G3_BY_NT(false, false);
+#undef G3_GO_DUAL
 #undef G3_HALF
 #undef G3_BY_NT
 #undef G3_GO

@@ -318,6 +318,34 @@ def _stem_rows(x: torch.Tensor, conv: nn.Conv2d, w: torch.Tensor, bias: torch.Te
 
 
 # --------------------------------------------------------------------------- ResNet encoder
+def _bottleneck_tail_dual(out: torch.Tensor, y: torch.Tensor, blk):
+    """relu(bn3(conv3(out)) + bn_d(downsample(y))) for a bottleneck whose two branches end in 1x1 convolutions, as one split-operand
+    GEMM over [out | y] (ops.gemm_split_dual); None where that form does not apply (bf16 mode, other layouts, shapes the kernel
+    declines) — the caller then runs the branches one after the other."""
+    c3, cd, bn3, bnd = blk.conv3, blk.downsample[0], blk.bn3, blk.downsample[1]
+    if not (ops.DUAL_TAIL and ops.GEMM_SPLIT and ops.PRECISION != "bf16" and out.is_cuda and out.dtype == torch.float32
+            and c3.kernel_size == (1, 1) and cd.kernel_size == (1, 1) and c3.stride == (1, 1) and c3.groups == 1 and cd.groups == 1
+            and cd.stride[0] == cd.stride[1] and cd.padding == (0, 0) and c3.padding == (0, 0)
+            and c3.in_channels % 32 == 0 and cd.in_channels % 32 == 0 and isinstance(bnd, nn.BatchNorm2d)):
+        return None
+    ol, yl = nhwc_view(out), nhwc_view(y)
+    B, Ho, Wo, k1 = ol.shape
+    _, H, W, k2 = yl.shape
+    st = cd.stride[0]
+    if (H - 1) // st + 1 != Ho or (W - 1) // st + 1 != Wo:
+        return None
+    n = c3.out_channels
+
+    def build():
+        w3, b3 = folded_conv_bn(c3, bn3)
+        wd, bd = folded_conv_bn(cd, bnd)
+        return ops.gemm_split_weights(torch.cat([w3.reshape(n, k1), wd.reshape(n, k2)], dim=1).contiguous()), (b3 + bd).contiguous()
+    ws, bias = cached(blk, "dualtail", [c3.weight, bn3.weight, bn3.bias, bn3.running_mean, bn3.running_var,
+                                        cd.weight, bnd.weight, bnd.bias, bnd.running_mean, bnd.running_var], build)
+    y2 = ops.gemm_split_dual(ol.view(B * Ho * Wo, k1), yl if st > 1 else yl.view(B * H * W, k2), ws, bias, N.ACT_RELU, stride=st if st > 1 else 0)
+    return None if y2 is None else y2.view(B, Ho, Wo, n).permute(0, 3, 1, 2)
+
+
 @torch.no_grad()
 def resnet_features(enc, x: torch.Tensor, stem_feature: bool = False) -> List[torch.Tensor]:
     """smp feature list [x, stem, layer1..layer4] of `deeplab.ResNetEncoder`, fused eval execution.
@@ -353,6 +381,13 @@ def resnet_features(enc, x: torch.Tensor, stem_feature: bool = False) -> List[to
         for blk in layer:
             out = conv_bn_act(y, blk.conv1, blk.bn1, N.ACT_RELU)
             out = conv_bn_act(out, blk.conv2, blk.bn2, N.ACT_RELU)
+            if blk.downsample is not None:
+                # first block of a stage: relu(bn3(conv3(out)) + bn_d(downsample(y))) is ONE product over [out | y at the stride] — the
+                # downsample branch's map (as wide as the block's output) is neither written nor read back as a residual
+                y2 = _bottleneck_tail_dual(out, y, blk)
+                if y2 is not None:
+                    y = y2
+                    continue
             idn = y if blk.downsample is None else conv_bn_act(y, blk.downsample[0], blk.downsample[1], N.ACT_NONE)
             # the identity is dead after this block unless it is a tensor handed out in `feats`
             scratch = not any(idn is f for f in feats)

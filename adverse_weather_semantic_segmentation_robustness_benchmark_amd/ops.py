@@ -929,6 +929,35 @@ def conv_rows_gemm_split(x_padded: torch.Tensor, w_split: torch.Tensor, bias: Op
 CONV_GATHER = os.environ.get("AWSEG_CONV_GATHER", "1") != "0"
 
 
+DUAL_TAIL = os.environ.get("AWSEG_DUAL_TAIL", "1") != "0"             # first bottleneck of a ResNet stage: conv3 + downsample branch as one GEMM
+
+
+def gemm_split_dual(x: torch.Tensor, x2: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0, stride: int = 0,
+                    residual: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """act([x | x2] @ w^T + bias (+ residual)) with the A operand in two pieces along K: x [M,k1] rows; x2 [M,k2] rows (stride 0) or an
+    NHWC image [B,H,W,k2] whose pixels (b, oy*stride, ox*stride) are the rows (a strided 1x1 convolution folded into the product).
+    w_split = gemm_split_weights(w [N,k1+k2]).  Returns None when the LDS-DMA kernel does not take the shape (the caller then runs
+    the two products separately)."""
+    x, x2 = x.contiguous(), x2.contiguous()
+    m, k1 = x.shape
+    k2 = x2.shape[-1]
+    n = w_split.shape[1]
+    if w_split.shape[2] != k1 + k2:
+        raise N.AwsegError(f"gemm_split_dual: weights have K = {w_split.shape[2]}, the operands {k1} + {k2}")
+    if not _split_weights_intact(w_split, n, k1 + k2):
+        raise N.AwsegError("w_split lost its 16-byte trailer (weight exponent): pass the tensor gemm_split_weights returned, not a copy")
+    if stride > 0:
+        b, h, w = x2.shape[0], x2.shape[1], x2.shape[2]
+    else:
+        b, h, w = 1, 1, 1
+        if x2.numel() != m * k2:
+            raise N.AwsegError("gemm_split_dual: x2 has a different row count than x")
+    out = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    rc = N.try_call("awseg_gemm_split_dual_bias_act", N.ptr(x), k1, N.ptr(x2), k2, b, h, w, int(stride), N.ptr(w_split), N.ptr(bias),
+                    N.ptr(residual), act, N.ptr(out), m, n, N.stream())
+    return out if rc == 0 else None
+
+
 def conv_gemm_split(x: torch.Tensor, w_split: torch.Tensor, bias: Optional[torch.Tensor], act: int, kh: int, kw: int, stride: int,
                     pad: int, dilation: int = 1, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """conv2d on a float32 NHWC tensor [B,H,W,C] (C % 32 == 0) as one split-operand GEMM whose A operand is gathered from x

@@ -540,6 +540,19 @@ int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int
                                       const uint16_t* u_split, const float* shift, const float* residual, int act,
                                       const float* w2, const float* b2, float* out, awseg_stream_t stream);
 
+/* awseg_gemm_split_dual_bias_act: the split-operand GEMM with its A operand in TWO pieces along K —
+ *     out[M,N] = act([x | x2] . w^T + bias (+ residual)),  x float32 [M,k1],  w_split = awseg_gemm_split_weights of w [N, k1+k2]
+ * where x2 is either float32 rows [M,k2] (x2_stride == 0) or an NHWC image [batch, x2_height, x2_width, k2] whose pixels
+ * (b, oy*x2_stride, ox*x2_stride) are the rows m = (b, oy, ox) — a 1x1 convolution of that stride folded into the product.  It is
+ * the tail of the FIRST bottleneck of a ResNet stage (the smp encoder behind PKG/models/model.py:259-265, :349):
+ *     relu(bn3(conv3(z)) + bn_d(downsample(block input)))  =  relu([z | input_s] . [W3' | Wd']^T + (b3' + bd'))
+ * in one launch: the downsample branch's map is neither written nor read back as a residual.  k1 % 32 == k2 % 32 == 0, N >= 8;
+ * LDS-DMA kernel of csrc/gemm_split3.hip only (AWSEG_ERANGE for shapes it does not take: the caller runs the two GEMMs).  Range
+ * guard, epilogue and error codes as awseg_gemm_split_bias_act. */
+int awseg_gemm_split_dual_bias_act(const float* x, int k1, const float* x2, int k2, int64_t batch, int x2_height, int x2_width,
+                                   int x2_stride, const uint16_t* w_split, const float* bias, const float* residual, int act,
+                                   float* out, int64_t m, int n, awseg_stream_t stream);
+
 /* A convolution as ONE split-operand GEMM without the im2col matrix: x float32 NHWC [batch, height, width, channels]
  * (channels % 32 == 0), weights in im2col column order (ky, kx, c) split by awseg_gemm_split_weights
  * ([n, kernel_h * kernel_w * channels]); row (b, oy, ox) of the A operand is gathered from x while the K tiles are staged

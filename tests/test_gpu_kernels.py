@@ -1624,3 +1624,37 @@ def test_rowdot_sigmoid_and_aspp_pool_branch_vs_float64(ops):
         for _ in range(2):
             got = ops.aspp_pool_branch(mean, w1, b1, w2, b2)
             assert (got.double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("case", [(5000, 64, 64, 256, 0), (300, 512, 1024, 2048, 0), (1, 128, 256, 512, 2), (40000, 64, 64, 256, 0), (3, 256, 512, 1024, 2),
+                                  (2, 32, 96, 64, 2)])
+def test_gemm_split_dual_operand_vs_float64(ops, case):
+    """The split-operand GEMM with its A operand in two pieces along K (conv3 + downsample branch of a stage's first bottleneck as one
+    product): plain second rows and a stride-2 gather from an NHWC image (odd sizes: the last row / column of the grid), ragged M,
+    bias + ReLU, against float64 and next to the two separate split GEMMs it replaces."""
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    mb, k1, k2, n, st = case
+    if st == 0:
+        m = mb
+        x2 = torch.randn(m, k2, device="cuda", generator=g)
+        rows2 = x2
+    else:
+        B, H, W = mb, 21, 27
+        x2 = torch.randn(B, H, W, k2, device="cuda", generator=g)
+        rows2 = x2[:, ::st, ::st].reshape(-1, k2)
+        m = rows2.shape[0]
+    x = torch.randn(m, k1, device="cuda", generator=g)
+    w = torch.randn(n, k1 + k2, device="cuda", generator=g) / (k1 + k2) ** 0.5
+    b = torch.randn(n, device="cuda", generator=g)
+    ref = torch.relu(torch.cat([x, rows2], dim=1).double() @ w.double().t() + b.double())
+    got = ops.gemm_split_dual(x, x2, ops.gemm_split_weights(w), b, 1, stride=st)
+    assert got is not None
+    err = (got.double() - ref).abs().max().item()
+    two = ops.gemm_bias_act(x, w[:, :k1].contiguous(), b, 1, residual=ops.gemm_bias_act(rows2.contiguous(), w[:, k1:].contiguous(), torch.zeros_like(b), 0, split=True), split=True)
+    err2 = (two.double() - ref).abs().max().item()
+    print(f"dual {case}: |err| {err:.2e} (two launches {err2:.2e})")
+    assert err < 2e-5 and err < 4 * err2 + 1e-6
+    # large activations in the second source only: the range guard must see them
+    got = ops.gemm_split_dual(x, x2 * 3e4, ops.gemm_split_weights(w), b, 1, stride=st)
+    ref = torch.relu(torch.cat([x, rows2 * 3e4], dim=1).double() @ w.double().t() + b.double())
+    assert (got.double() - ref).abs().max().item() < 2e-5 * 3e4

@@ -90,6 +90,7 @@ SIGNATURES = {
     "awseg_upconv3x3_linear": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p]),
     "awseg_upconv3x3_adjoint": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
     "awseg_aspp_depthwise3": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p]),
+    "awseg_aspp_depthwise3_mean": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     "awseg_dwconv3x3_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_p, c_p, c_i, c_p, c_p]),
     "awseg_bias_act_nhwc": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_i, c_p]),
     "awseg_layernorm_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_f, c_p, c_p]),
@@ -108,6 +109,7 @@ SIGNATURES = {
     "awseg_maxpool3x3s2_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p]),
     "awseg_maxpool3x3s2_bias_relu_nhwc": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_p, c_p, c_p]),
     "awseg_upsample_bilinear": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_p, c_p]),
+    "awseg_stem_image": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i64, c_i64, c_i64, c_p, c_i, c_p]),
     "awseg_rowdot_sigmoid": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_i, c_p, c_p]),
     "awseg_aspp_pool_branch_workspace": (c_i64, [c_i, c_i]),
     "awseg_aspp_pool_branch": (c_i, [c_p, c_i, c_i, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_p, c_p]),

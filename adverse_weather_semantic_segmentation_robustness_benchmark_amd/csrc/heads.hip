@@ -1211,10 +1211,14 @@ void aspp_dw3_rows_kernel(const float* __restrict__ x, int64_t batch, int h, int
 // NHWC layout forces on a channel-sliced kernel: 128 contiguous bytes per pixel, 8 KB apart (slice widths of 32-256 channels all
 // land within 5 % of each other; the 512-byte-per-pixel writes of awseg_upconv3x3_bn_relu reach 5.7 TB/s).
 constexpr int kAsppLdsQuads = 8;                                     // quads per slice: 128 bytes per pixel
-template <int AHEAD, bool NT>
+// MEAN: the blocks of rate 0 also leave the per-channel mean of their slice over the image in mean_out [batch, C] — every thread of such
+// a block meets each row of its column exactly once, so ASPPPooling's global average (a 0.5 GB pass of its own otherwise) is a
+// running sum beside the walk and one reduction over the columns through the row buffer at the end (fixed order: deterministic).
+template <int AHEAD, bool NT, bool MEAN = false>
 __global__ __launch_bounds__(1024)
 void aspp_dw3_lds_kernel(const float* __restrict__ x, int64_t batch, int h, int w, int C,
-                         const float* __restrict__ wdw, int r0, int r1, int r2, float* __restrict__ out, int n_units)
+                         const float* __restrict__ wdw, int r0, int r1, int r2, float* __restrict__ out, int n_units,
+                         float* __restrict__ mean_out = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) float4 srow[];    // [2][w][8]
     const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
@@ -1256,11 +1260,13 @@ void aspp_dw3_lds_kernel(const float* __restrict__ x, int64_t batch, int h, int 
     }
     int j = 0, s = 0, buf = 0;
     float4 accA = zero, accB = zero;
+    float4 msum = zero;
     while (j < ncl) {
 #pragma unroll
         for (int i = 0; i < AHEAD; ++i) {                         // (unrolled so that the ring stays in registers)
             if (j >= ncl) break;
             const float4 cur = ring[i];
+            if (MEAN && r == 0) { msum.x += cur.x; msum.y += cur.y; msum.z += cur.z; msum.w += cur.w; }
             ring[i] = lj < ncl ? *reinterpret_cast<const float4*>(xb + (int64_t)ls * w * C) : zero;
             step(ls, lj);
             srow[buf * rowq + threadIdx.x] = cur;
@@ -1275,6 +1281,20 @@ void aspp_dw3_lds_kernel(const float* __restrict__ x, int64_t batch, int h, int 
             if (s + d >= h) { put(ob + (int64_t)s * w * C, accA); accA = zero; accB = zero; }
             step(s, j);
             buf ^= 1;
+        }
+    }
+    if (MEAN && r == 0) {
+        __syncthreads();                                          // the last row's neighbours have been read
+        srow[threadIdx.x] = msum;
+        __syncthreads();
+        if (threadIdx.x < kAsppLdsQuads) {
+            float4 t = zero;
+            for (int col = 0; col < w; ++col) {
+                const float4 v = srow[col * kAsppLdsQuads + threadIdx.x];
+                t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+            }
+            const float inv = 1.0f / (float)((int64_t)h * w);
+            *reinterpret_cast<float4*>(mean_out + (int64_t)b * C + (sl * kAsppLdsQuads + threadIdx.x) * 4) = make_float4(t.x * inv, t.y * inv, t.z * inv, t.w * inv);
         }
     }
 }
@@ -1292,6 +1312,25 @@ AWSEG_API int awseg_upconv3x3_adjoint(const float* dz, int64_t batch, int cmid, 
     if (e != hipSuccess) return (int)e;
     dim3 grid((width + 31) / 32, (height + 31) / 32, (unsigned)batch);
     hipLaunchKernelGGL(upconv3x3_adjoint_kernel, grid, dim3(cmid), 0, awseg_s(stream), dz, h, w, height, width, cmid, dg9);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_aspp_depthwise3_mean(const float* x, int64_t batch, int h, int w, int channels, const float* wdw,
+                                         int rate0, int rate1, int rate2, float* out, float* mean_out, awseg_stream_t stream)
+{
+    if (!x || !wdw || !out || !mean_out || batch < 1 || h < 1 || w < 1 || channels < 4 || (channels & 3)) return AWSEG_EINVAL;
+    if (((uintptr_t)x & 15) || ((uintptr_t)wdw & 15) || ((uintptr_t)out & 15) || ((uintptr_t)mean_out & 15)) return AWSEG_EALIGN;
+    if (rate0 < 1 || rate1 < 1 || rate2 < 1) return AWSEG_EINVAL;
+    // the LDS-staged walk only: its rate-0 blocks see every pixel of their channel slice once
+    if ((channels / 4) % kAsppLdsQuads || w * kAsppLdsQuads > 1024 || w * kAsppLdsQuads < 64) return AWSEG_ERANGE;
+    const int n_units = (int)batch * ((channels / 4) / kAsppLdsQuads);
+    const int64_t grid = (int64_t)((n_units + 7) / 8) * 3 * 8;
+    if (grid >= ((int64_t)1 << 31)) return AWSEG_ERANGE;
+    const size_t lds_bytes = (size_t)2 * w * kAsppLdsQuads * sizeof(float4);
+    auto kern = aspp_dw3_lds_kernel<4, true, true>;
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)(w * kAsppLdsQuads)), lds_bytes, awseg_s(stream), x, batch, h, w,
+                       channels, wdw, rate0, rate1, rate2, out, n_units, mean_out);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -1316,7 +1355,7 @@ AWSEG_API int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w,
             // (measured: 4 rows of loads ahead 0.68 ms, 1 row 0.78, 8 rows 0.84, 12 rows 1.26; plain instead of non-temporal stores +2 %)
             auto kern = aspp_dw3_lds_kernel<4, true>;
             hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3((unsigned)(w * kAsppLdsQuads)), lds_bytes, awseg_s(stream), x, batch, h, w,
-                               channels, wdw, rate0, rate1, rate2, out, n_units);
+                               channels, wdw, rate0, rate1, rate2, out, n_units, (float*)nullptr);
             AWSEG_LAUNCH_CHECK();
             return 0;
         }

@@ -1,11 +1,13 @@
-// smallops.hip — the two tails of the DeepLabV3+ member that are too small for a GEMM kernel and used to run as library calls
-// (hipBLASLt GEMMs of 8 rows, an addmm with one output column, separate add / sigmoid passes):
+// smallops.hip — small passes of the eval step that used to run as library calls (hipBLASLt GEMMs of 8 rows, an addmm with one
+// output column, separate add / sigmoid passes, a strided torch copy):
 //   * awseg_rowdot_sigmoid   : out[r] = sigmoid(x[r, :] . w + b) — the 1x1 convolution to ONE channel + Sigmoid that ends
 //                              DepthEstimationHead (PKG/models/model.py:49-51) on the stride-16 map of the DeepLab member (:368);
 //   * awseg_aspp_pool_branch : smp's ASPPPooling branch after its global mean — 1x1 conv + BatchNorm + ReLU on one row per image —
 //                              followed by that branch's slice of the ASPP projection (the smp model built at model.py:262-268):
-//                              out[b, :] = relu(mean[b, :] W1^T + b1) W2^T + b2, one launch ("last block finishes" pattern).
-// Both are a few hundred KB of weights against a few rows: bound by latency, not by any pipe.
+//                              out[b, :] = relu(mean[b, :] W1^T + b1) W2^T + b2, one launch ("last block finishes" pattern);
+//   * awseg_stem_image       : the planar frames into the zero-padded 4-channel NHWC image both 7x7 stems gather their rows from.
+// The first two are a few hundred KB of weights against a few rows: bound by latency, not by any pipe; the third is one pass at the
+// HBM rate (torch's strided copy ran at a third of it).
 #include "awseg_common.h"
 
 namespace {
@@ -33,6 +35,39 @@ void rowdot_sigmoid_kernel(const float* __restrict__ x, int64_t rows, int k, con
     if (r < rows && sub == 0) {
         const float v = acc + (bias ? bias[0] : 0.f);
         out[r] = sigmoid ? 1.0f / (1.0f + expf(-v)) : v;
+    }
+}
+
+// planar frames [B, C <= 4, H, W] (any strides whose innermost is 1) -> the interior columns 3 .. 3 + W - 1 of the zero-padded
+// 4-channel NHWC image [B, H, Wp, 4] both 7x7 stems gather their rows from; channels >= C and the padding columns are not touched
+// (zero since the buffer was made).  A lane = 4 consecutive pixels: up to three 16-byte plane reads, four 16-byte pixel writes.
+__global__ __launch_bounds__(SO_T)
+void stem_image_kernel(const float* __restrict__ x, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sy, float* __restrict__ img, int Wp)
+{
+    const int wq = (W + 3) / 4;
+    const int64_t total = (int64_t)B * H * wq;
+    for (int64_t i = (int64_t)blockIdx.x * SO_T + threadIdx.x; i < total; i += (int64_t)gridDim.x * SO_T) {
+        const int xq = (int)(i % wq);
+        const int64_t t = i / wq;
+        const int y = (int)(t % H), b = (int)(t / H);
+        const float* src = x + b * sb + y * sy + 4 * xq;
+        float v[4][4];
+        const bool full = 4 * xq + 4 <= W && (((uintptr_t)src | (uintptr_t)(sc * 4)) & 15) == 0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < C) {
+                if (full) { const float4 p = *reinterpret_cast<const float4*>(src + c * sc); v[c][0] = p.x; v[c][1] = p.y; v[c][2] = p.z; v[c][3] = p.w; }
+                else
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) v[c][k] = 4 * xq + k < W ? src[c * sc + k] : 0.f;
+            } else
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[c][k] = 0.f;
+        }
+        float* dst = img + (((int64_t)b * H + y) * Wp + 3 + 4 * xq) * 4;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (4 * xq + k < W) *reinterpret_cast<float4*>(dst + 4 * k) = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
     }
 }
 
@@ -136,6 +171,20 @@ AWSEG_API int awseg_aspp_pool_branch(const float* mean, int batch, int cin, cons
     float* g = reinterpret_cast<float*>(workspace) + 4;
     hipLaunchKernelGGL(aspp_pool_branch_kernel, dim3((unsigned)((cmid + PB_MC - 1) / PB_MC)), dim3(SO_T), 0, awseg_s(stream), mean, batch, cin,
                        w1, b1, cmid, w2, b2, cout, g, counter, out);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
+}
+
+AWSEG_API int awseg_stem_image(const float* x, int batch, int channels, int height, int width, int64_t stride_b, int64_t stride_c,
+                               int64_t stride_y, float* image, int padded_width, awseg_stream_t stream)
+{
+    if (batch == 0) return 0;
+    if (!x || !image || batch < 0 || channels < 1 || channels > 4 || height < 1 || width < 1 || padded_width < width + 3) return AWSEG_EINVAL;
+    if (stride_b < 0 || stride_c < 0 || stride_y < width) return AWSEG_EINVAL;
+    if ((uintptr_t)image & 15) return AWSEG_EALIGN;
+    const int64_t total = (int64_t)batch * height * ((width + 3) / 4);
+    hipLaunchKernelGGL(stem_image_kernel, dim3(awseg_grid_1d(total, SO_T)), dim3(SO_T), 0, awseg_s(stream), x, batch, channels, height, width,
+                       stride_b, stride_c, stride_y, image, padded_width);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }

@@ -270,6 +270,17 @@ class DeepLabV3PlusDecoder(nn.Module):
         from . import fused
         parts, psplit, zero_bias, pb = fused.cached(aspp.project[0], "proj_fold%d" % int(ops.gemm_wants_split(B * h * w, Cout, Cout)),
                                                 (aspp.project[0].weight, pbn.weight, pbn.bias, pbn.running_mean, pbn.running_var), fold_proj)
+        # the depthwise halves of branches 1-3 (HIP, all three rates in one pass) — the same pass leaves the pooling branch's global
+        # average (its rate-0 blocks meet every pixel of their channels once)
+        dws = [aspp.convs[1 + r][0][0].weight for r in range(3)]
+        wdw = fused.cached(aspp, "dw3taps", dws, lambda: torch.stack([t_.view(Cin, 9).t() for t_ in dws]).contiguous())  # [3,9,C]
+        if xl.is_cuda and xl.dtype == torch.float32:
+            dw, gmean = ops.aspp_depthwise3_mean(xl, wdw, aspp.rates)
+        else:
+            dw, gmean = ops.aspp_depthwise3(xl, wdw, aspp.rates), None
+        dw = dw.view(3, B * h * w, Cin)
+        if gmean is None:
+            gmean = xl.mean(dim=(1, 2))
         # pooling branch: global mean -> 1x1 -> BN -> ReLU; bilinear upsample of a 1x1 map is a broadcast
         pool = aspp.convs[4]
         pw_, pbn_ = pool[1].weight.view(Cout, Cin), pool[2]
@@ -278,17 +289,14 @@ class DeepLabV3PlusDecoder(nn.Module):
                 s_, b_ = _bn_fold(pbn_)
                 return (pw_ * s_[:, None]).contiguous(), b_.contiguous()
             w1f, b1f = fused.cached(pbn_, "aspp_pool_fold", (pw_, pbn_.weight, pbn_.bias, pbn_.running_mean, pbn_.running_var), fold_pool)
-            g2 = ops.aspp_pool_branch(xl.mean(dim=(1, 2)), w1f, b1f, parts[4], pb)          # [B,256]: conv + BN + ReLU + projection slice
+            g2 = ops.aspp_pool_branch(gmean, w1f, b1f, parts[4], pb)                         # [B,256]: conv + BN + ReLU + projection slice
         else:
-            g2 = branch(xl.mean(dim=(1, 2)), pw_, pbn_) @ parts[4].t() + pb
+            g2 = branch(gmean, pw_, pbn_) @ parts[4].t() + pb
         acc = g2[:, None, :].expand(B, h * w, Cout).contiguous().view(B * h * w, Cout)
         # branch 0: 1x1
         y = branch(flat, aspp.convs[0][0].weight.view(Cout, Cin), aspp.convs[0][1])
         ops.gemm_bias_act(y, parts[0], zero_bias, 0, residual=acc, out=acc, w_split=psplit[0])
-        # branches 1-3: depthwise (HIP, all three rates at once) then pointwise GEMM
-        dws = [aspp.convs[1 + r][0][0].weight for r in range(3)]
-        wdw = fused.cached(aspp, "dw3taps", dws, lambda: torch.stack([t_.view(Cin, 9).t() for t_ in dws]).contiguous())  # [3,9,C]
-        dw = ops.aspp_depthwise3(xl, wdw, aspp.rates).view(3, B * h * w, Cin)
+        # branches 1-3: their pointwise GEMMs
         for r in range(3):
             mod = aspp.convs[1 + r]
             y = branch(dw[r], mod[0][1].weight.view(Cout, Cin), mod[1])

@@ -292,7 +292,10 @@ def stem_image(x: torch.Tensor) -> torch.Tensor:
         if xp is None:
             _stem_pad.clear()                                  # one shape at a time: 270 MB at 8 x 1024 x 2048
             xp = _stem_pad[key] = torch.zeros(B, H, wp_any, 4, dtype=torch.float32, device=x.device)
-        xp[:, :, 3:3 + W, :C] = x.permute(0, 2, 3, 1)      # the padding columns / channel stay zero
+        if x.stride(3) == 1 and x.stride(2) >= W and min(x.stride()) >= 0:
+            ops.stem_image_fill(x, xp)                     # the padding columns / channel stay zero
+        else:
+            xp[:, :, 3:3 + W, :C] = x.permute(0, 2, 3, 1)
         if _stem_scope is not None:
             _stem_scope[skey] = xp
     return xp

@@ -504,6 +504,20 @@ def aspp_depthwise3(x_nhwc: torch.Tensor, wdw: torch.Tensor, rates) -> torch.Ten
     return out
 
 
+def aspp_depthwise3_mean(x_nhwc: torch.Tensor, wdw: torch.Tensor, rates):
+    """aspp_depthwise3 that also returns the per-image channel means [B,C] of x (ASPPPooling's global average) from the same pass;
+    the mean is None where the kernel that can do it does not take the shape (the caller then reduces x itself)."""
+    x = x_nhwc.contiguous()
+    b, h, w, c = x.shape
+    out = torch.empty(3, b, h, w, c, dtype=torch.float32, device=x.device)
+    mean = torch.empty(b, c, dtype=torch.float32, device=x.device)
+    rc = N.try_call("awseg_aspp_depthwise3_mean", N.ptr(x), b, h, w, c, N.ptr(wdw.contiguous()), int(rates[0]), int(rates[1]), int(rates[2]),
+                    N.ptr(out), N.ptr(mean), N.stream())
+    if rc != 0:
+        return aspp_depthwise3(x, wdw, rates), None
+    return out, mean
+
+
 # ----------------------------------------------------------------------------- backbone helpers
 def dwconv3x3_nhwc(x: torch.Tensor, w9: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = 0,
                    dilation: int = 1) -> torch.Tensor:
@@ -1144,6 +1158,14 @@ def upsample_bilinear(x: torch.Tensor, size, align_corners: bool) -> torch.Tenso
     sb, sc, sy, sx = x.stride()
     N.call("awseg_upsample_bilinear_strided", N.ptr_strided(x), b, c, h, w, sb, sc, sy, sx, H, W, int(bool(align_corners)), N.ptr(out), N.stream())
     return out
+
+
+def stem_image_fill(x: torch.Tensor, image: torch.Tensor) -> None:
+    """x [B,C<=4,H,W] (innermost stride 1) -> columns 3.. of the zero-padded NHWC image [B,H,Wp,4] of the 7x7 stems, one pass."""
+    b, c, h, w = x.shape
+    if x.stride(3) != 1:
+        x = x.contiguous()
+    N.call("awseg_stem_image", N.ptr_strided(x), b, c, h, w, x.stride(0), x.stride(1), x.stride(2), N.ptr(image), image.shape[2], N.stream())
 
 
 def rowdot_sigmoid(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], sigmoid: bool = True) -> torch.Tensor:

@@ -428,6 +428,12 @@ int awseg_upconv3x3_bn_relu(const float* g9, int64_t batch, int cmid, int h, int
 int awseg_aspp_depthwise3(const float* x, int64_t batch, int h, int w, int channels,
                           const float* wdw, int rate0, int rate1, int rate2,
                           float* out, awseg_stream_t stream);
+/* The same pass that also leaves ASPPPooling's global average in mean_out float32 [batch, channels] (nn.AdaptiveAvgPool2d(1) of
+ * the smp ASPP's pooling branch): the rate-0 blocks of the LDS-staged walk meet every pixel of their channel slice once, so the mean
+ * is a running sum beside the stencil instead of a pass over the 2048-channel map of its own.  AWSEG_ERANGE where that walk does not
+ * apply (channels % 32 != 0, or width * 8 outside 64 .. 1024): the caller takes awseg_aspp_depthwise3 and a mean of its own. */
+int awseg_aspp_depthwise3_mean(const float* x, int64_t batch, int h, int w, int channels, const float* wdw,
+                               int rate0, int rate1, int rate2, float* out, float* mean_out, awseg_stream_t stream);
 
 /* ------------------------------------------------------------------------- *
  *  channel-last helpers around the torch-ROCm backbones (callers of A8 / A9)
@@ -739,6 +745,14 @@ int awseg_rowdot_sigmoid(const float* x, int64_t rows, int k, const float* w, co
 int64_t awseg_aspp_pool_branch_workspace(int batch, int cmid);
 int awseg_aspp_pool_branch(const float* mean, int batch, int cin, const float* w1, const float* b1, int cmid, const float* w2,
                            const float* b2, int cout, void* workspace, float* out, awseg_stream_t stream);
+
+/* The frames as both 7x7 stems read them: planar float32 [batch, channels <= 4, height, width] (element (b, c, y, x) at
+ * x[b*stride_b + c*stride_c + y*stride_y + x], strides in floats) into columns 3 .. 3 + width - 1 of a 4-channel NHWC image
+ * [batch, height, padded_width, 4] whose other columns / channels the caller zeroed once (the operand of
+ * awseg_conv_rows_gemm_split_bias_act: ResNet conv1 and MiT's first patch embedding behind PKG/models/model.py:186-200, :349).
+ * One pass, 16-byte accesses on both sides. */
+int awseg_stem_image(const float* x, int batch, int channels, int height, int width, int64_t stride_b, int64_t stride_c,
+                     int64_t stride_y, float* image, int padded_width, awseg_stream_t stream);
 
 /* awseg_depth_upsample_combine: the depth tail of the ensemble in one pass — d2_full = bilinear upsample
  * (align_corners=False) of the stride-16 DeepLab depth map d2_low [B,h,w] to [B,H,W] (PKG/models/model.py:368-371) and

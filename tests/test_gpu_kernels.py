@@ -1658,3 +1658,41 @@ def test_gemm_split_dual_operand_vs_float64(ops, case):
     got = ops.gemm_split_dual(x, x2 * 3e4, ops.gemm_split_weights(w), b, 1, stride=st)
     ref = torch.relu(torch.cat([x, rows2 * 3e4], dim=1).double() @ w.double().t() + b.double())
     assert (got.double() - ref).abs().max().item() < 2e-5 * 3e4
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 24, 64, (3, 5, 7)), (1, 64, 128, 2048, (12, 24, 36)), (3, 9, 8, 32, (12, 24, 36))])
+def test_aspp_depthwise3_with_mean_output(ops, shape):
+    """The ASPP depthwise pass that also leaves the pooling branch's global average: same three maps as awseg_aspp_depthwise3 bit for
+    bit, mean against float64 (and twice: the reduction order is fixed, so the bits are)."""
+    B, h, w, C, rates = shape
+    g = torch.Generator(device="cuda").manual_seed(sum(shape[:4]))
+    x = torch.randn(B, h, w, C, device="cuda", generator=g)
+    wdw = torch.randn(3, 9, C, device="cuda", generator=g)
+    ref = ops.aspp_depthwise3(x, wdw, rates)
+    got, mean = ops.aspp_depthwise3_mean(x, wdw, rates)
+    assert mean is not None
+    assert torch.equal(got, ref)
+    assert (mean.double() - x.double().mean(dim=(1, 2))).abs().max().item() < 1e-6
+    assert torch.equal(ops.aspp_depthwise3_mean(x, wdw, rates)[1], mean)
+    # a width the LDS-staged walk does not take: the maps still come, the mean is left to the caller
+    xs = torch.randn(1, 5, 4, 32, device="cuda", generator=g)
+    got, mean = ops.aspp_depthwise3_mean(xs, wdw[:, :, :32].contiguous(), rates)
+    assert mean is None and torch.equal(got, ops.aspp_depthwise3(xs, wdw[:, :, :32].contiguous(), rates))
+
+
+def test_stem_image_fill_matches_strided_copy(ops):
+    """awseg_stem_image against the torch expression it replaces (planar frames -> columns 3.. of the zero-padded NHWC image), for a
+    ragged width, a channels-last input and a 4-channel input; untouched cells keep what the buffer held."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for B, C, H, W, cl in ((2, 3, 9, 37, False), (1, 3, 8, 64, True), (2, 4, 5, 16, False)):
+        x = torch.randn(B, C, H, W, device="cuda", generator=g)
+        if cl:
+            x = x.contiguous(memory_format=torch.channels_last)
+        wp = W + 11
+        ref = torch.full((B, H, wp, 4), 7.0, device="cuda")
+        got = ref.clone()
+        ref[:, :, 3:3 + W, :C] = x.permute(0, 2, 3, 1)
+        if C < 4:
+            ref[:, :, 3:3 + W, C:] = 0.0                      # channels past C of the interior are written as zeros
+        ops.stem_image_fill(x, got)
+        assert torch.equal(got, ref)

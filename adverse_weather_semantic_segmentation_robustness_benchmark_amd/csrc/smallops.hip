@@ -4,7 +4,7 @@
 //                              DepthEstimationHead (PKG/models/model.py:49-51) on the stride-16 map of the DeepLab member (:368);
 //   * awseg_aspp_pool_branch : smp's ASPPPooling branch after its global mean — 1x1 conv + BatchNorm + ReLU on one row per image —
 //                              followed by that branch's slice of the ASPP projection (the smp model built at model.py:262-268):
-//                              out[b, :] = relu(mean[b, :] W1^T + b1) W2^T + b2, one launch ("last block finishes" pattern);
+//                              out[b, :] = relu(mean[b, :] W1^T + b1) W2^T + b2: two small launches (64 blocks each);
 //   * awseg_stem_image       : the planar frames into the zero-padded 4-channel NHWC image both 7x7 stems gather their rows from.
 // The first two are a few hundred KB of weights against a few rows: bound by latency, not by any pipe; the third is one pass at the
 // HBM rate (torch's strided copy ran at a third of it).
@@ -39,35 +39,30 @@ void rowdot_sigmoid_kernel(const float* __restrict__ x, int64_t rows, int k, con
 }
 
 // planar frames [B, C <= 4, H, W] (any strides whose innermost is 1) -> the interior columns 3 .. 3 + W - 1 of the zero-padded
-// 4-channel NHWC image [B, H, Wp, 4] both 7x7 stems gather their rows from; channels >= C and the padding columns are not touched
-// (zero since the buffer was made).  A lane = 4 consecutive pixels: up to three 16-byte plane reads, four 16-byte pixel writes.
+// 4-channel NHWC image [B, H, Wp, 4] both 7x7 stems gather their rows from; channels >= C of the interior are written as zeros, the
+// padding columns are not touched (zero since the buffer was made).  A wave takes 256 consecutive pixels of a row, lane i the pixels
+// i, 64 + i, 128 + i, 192 + i: every load instruction reads 256 contiguous bytes of a plane and every store instruction writes 1 KB of
+// contiguous pixels (4 consecutive pixels per lane would make each store touch 64 lines a quarter full).
 __global__ __launch_bounds__(SO_T)
 void stem_image_kernel(const float* __restrict__ x, int B, int C, int H, int W, int64_t sb, int64_t sc, int64_t sy, float* __restrict__ img, int Wp)
 {
-    const int wq = (W + 3) / 4;
-    const int64_t total = (int64_t)B * H * wq;
-    for (int64_t i = (int64_t)blockIdx.x * SO_T + threadIdx.x; i < total; i += (int64_t)gridDim.x * SO_T) {
-        const int xq = (int)(i % wq);
-        const int64_t t = i / wq;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int spans = (W + 255) / 256;                             // 256-pixel spans per row
+    const int64_t total = (int64_t)B * H * spans;
+    for (int64_t u = (int64_t)blockIdx.x * (SO_T / 64) + wave; u < total; u += (int64_t)gridDim.x * (SO_T / 64)) {
+        const int sp = (int)(u % spans);
+        const int64_t t = u / spans;
         const int y = (int)(t % H), b = (int)(t / H);
-        const float* src = x + b * sb + y * sy + 4 * xq;
+        const float* src = x + b * sb + y * sy + sp * 256 + lane;
         float v[4][4];
-        const bool full = 4 * xq + 4 <= W && (((uintptr_t)src | (uintptr_t)(sc * 4)) & 15) == 0;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (c < C) {
-                if (full) { const float4 p = *reinterpret_cast<const float4*>(src + c * sc); v[c][0] = p.x; v[c][1] = p.y; v[c][2] = p.z; v[c][3] = p.w; }
-                else
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) v[c][k] = 4 * xq + k < W ? src[c * sc + k] : 0.f;
-            } else
-#pragma unroll
-                for (int k = 0; k < 4; ++k) v[c][k] = 0.f;
-        }
-        float* dst = img + (((int64_t)b * H + y) * Wp + 3 + 4 * xq) * 4;
+            for (int k = 0; k < 4; ++k) v[c][k] = (c < C && sp * 256 + 64 * k + lane < W) ? src[c * sc + 64 * k] : 0.f;
+        float* dst = img + (((int64_t)b * H + y) * Wp + 3 + sp * 256 + lane) * 4;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (4 * xq + k < W) *reinterpret_cast<float4*>(dst + 4 * k) = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
+            if (sp * 256 + 64 * k + lane < W) *reinterpret_cast<float4*>(dst + 256 * k) = make_float4(v[0][k], v[1][k], v[2][k], v[3][k]);
     }
 }
 
@@ -76,11 +71,9 @@ constexpr int PB_B = 8;         // images per pass
 
 __global__ __launch_bounds__(SO_T)
 void aspp_pool_branch_kernel(const float* __restrict__ mean, int batch, int cin, const float* __restrict__ w1, const float* __restrict__ b1,
-                             int cmid, const float* __restrict__ w2, const float* __restrict__ b2, int cout, float* g_ws,
-                             unsigned* counter, float* __restrict__ out)
+                             int cmid, float* __restrict__ g_ws)
 {
     __shared__ float sRed[SO_T / 64][PB_MC * PB_B];
-    __shared__ unsigned sLast;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = blockIdx.x * PB_MC;
     for (int bb = 0; bb < batch; bb += PB_B) {
@@ -121,23 +114,37 @@ void aspp_pool_branch_kernel(const float* __restrict__ mean, int batch, int cin,
         }
         __syncthreads();
     }
-    // the block that takes the last ticket sees every other block's rows of g (fence before the ticket, fence after it)
-    __threadfence();
-    if (tid == 0) sLast = atomicAdd(counter, 1u) == gridDim.x - 1 ? 1u : 0u;
-    __syncthreads();
-    if (!sLast) return;
-    __threadfence();
-    const volatile float* g = g_ws;
-    for (int o = wave; o < cout; o += SO_T / 64) {
-        for (int b = 0; b < batch; ++b) {
-            float v = 0.f;
-            for (int c = lane; c < cmid; c += 64) v = fmaf(g[(int64_t)b * cmid + c], w2[(int64_t)o * cmid + c], v);
+}
+
+// second half: out[b, o] = g[b, :] . w2[o, :] + b2[o] — a block per PB_MC output channels (one per wave), g through LDS
+__global__ __launch_bounds__(SO_T)
+void aspp_pool_proj_kernel(const float* __restrict__ g, int batch, int cmid, const float* __restrict__ w2, const float* __restrict__ b2,
+                           int cout, float* __restrict__ out)
+{
+    extern __shared__ float sG[];                                  // [PB_B][cmid]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o = blockIdx.x * (SO_T / 64) + wave;
+    for (int bb = 0; bb < batch; bb += PB_B) {
+        const int nb = batch - bb < PB_B ? batch - bb : PB_B;
+        __syncthreads();
+        for (int i = tid; i < nb * cmid; i += SO_T) sG[i] = g[(int64_t)bb * cmid + i];
+        __syncthreads();
+        if (o >= cout) continue;
+        float v[PB_B];
 #pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
-            if (lane == 0) out[(int64_t)b * cout + o] = v + (b2 ? b2[o] : 0.f);
+        for (int b = 0; b < PB_B; ++b) v[b] = 0.f;
+        for (int c = lane; c < cmid; c += 64) {
+            const float wv = w2[(int64_t)o * cmid + c];
+#pragma unroll
+            for (int b = 0; b < PB_B; ++b) if (b < nb) v[b] = fmaf(sG[b * cmid + c], wv, v[b]);
+        }
+#pragma unroll
+        for (int b = 0; b < PB_B; ++b) {
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) v[b] += __shfl_xor(v[b], s, 64);
+            if (lane == 0 && b < nb) out[(int64_t)(bb + b) * cout + o] = v[b] + (b2 ? b2[o] : 0.f);
         }
     }
-    if (tid == 0) *counter = 0u;                                  // ready for the next launch on this workspace
 }
 
 }  // namespace
@@ -158,7 +165,7 @@ AWSEG_API int awseg_rowdot_sigmoid(const float* x, int64_t rows, int k, const fl
 
 AWSEG_API int64_t awseg_aspp_pool_branch_workspace(int batch, int cmid)
 {
-    return batch < 0 || cmid < 0 ? 0 : ((int64_t)batch * cmid + 4) * 4;
+    return batch < 0 || cmid < 0 ? 0 : (int64_t)batch * cmid * 4;
 }
 
 AWSEG_API int awseg_aspp_pool_branch(const float* mean, int batch, int cin, const float* w1, const float* b1, int cmid, const float* w2,
@@ -166,11 +173,13 @@ AWSEG_API int awseg_aspp_pool_branch(const float* mean, int batch, int cin, cons
 {
     if (batch == 0 || cout == 0) return 0;
     if (!mean || !w1 || !b1 || !w2 || !workspace || !out || batch < 0 || cin < 1 || cmid < 1 || cout < 0) return AWSEG_EINVAL;
-    // workspace: [counter (16 bytes, ZERO at the first launch; the kernel leaves it zero) | g float32 [batch][cmid]]
-    unsigned* counter = reinterpret_cast<unsigned*>(workspace);
-    float* g = reinterpret_cast<float*>(workspace) + 4;
+    if ((size_t)PB_B * cmid * sizeof(float) > 48 * 1024) return AWSEG_ERANGE;
+    float* g = reinterpret_cast<float*>(workspace);               // relu(mean w1^T + b1), float32 [batch][cmid]
     hipLaunchKernelGGL(aspp_pool_branch_kernel, dim3((unsigned)((cmid + PB_MC - 1) / PB_MC)), dim3(SO_T), 0, awseg_s(stream), mean, batch, cin,
-                       w1, b1, cmid, w2, b2, cout, g, counter, out);
+                       w1, b1, cmid, g);
+    AWSEG_LAUNCH_CHECK();
+    hipLaunchKernelGGL(aspp_pool_proj_kernel, dim3((unsigned)((cout + SO_T / 64 - 1) / (SO_T / 64))), dim3(SO_T), (size_t)PB_B * cmid * sizeof(float),
+                       awseg_s(stream), g, batch, cmid, w2, b2, cout, out);
     AWSEG_LAUNCH_CHECK();
     return 0;
 }
@@ -182,7 +191,7 @@ AWSEG_API int awseg_stem_image(const float* x, int batch, int channels, int heig
     if (!x || !image || batch < 0 || channels < 1 || channels > 4 || height < 1 || width < 1 || padded_width < width + 3) return AWSEG_EINVAL;
     if (stride_b < 0 || stride_c < 0 || stride_y < width) return AWSEG_EINVAL;
     if ((uintptr_t)image & 15) return AWSEG_EALIGN;
-    const int64_t total = (int64_t)batch * height * ((width + 3) / 4);
+    const int64_t total = (int64_t)batch * height * ((width + 255) / 256) * 64;      // a wave per 256-pixel span
     hipLaunchKernelGGL(stem_image_kernel, dim3(awseg_grid_1d(total, SO_T)), dim3(SO_T), 0, awseg_s(stream), x, batch, channels, height, width,
                        stride_b, stride_c, stride_y, image, padded_width);
     AWSEG_LAUNCH_CHECK();

@@ -859,6 +859,7 @@ GEMM_SPLIT_N64 = os.environ.get("AWSEG_GEMM_SPLIT_N64", "1") != "0"
 
 
 GEMM_SPLIT_NARROW = os.environ.get("AWSEG_GEMM_SPLIT_NARROW", "1") != "0"
+STRIDED_UPSAMPLE = os.environ.get("AWSEG_STRIDED_UPSAMPLE", "0") != "0"   # off: see upsample_bilinear
 KV_PACKED = os.environ.get("AWSEG_KV_PACKED", "1") != "0"              # key + value projections as one GEMM, packed rows into attention
 SMALL_CONV_SPLIT = os.environ.get("AWSEG_SMALL_CONV_SPLIT", "1") != "0"  # gathered-operand GEMM for the small patch convolutions too
 
@@ -1150,9 +1151,10 @@ def upsample_bilinear(x: torch.Tensor, size, align_corners: bool) -> torch.Tenso
     arithmetic (bit-identical), 4 output pixels per lane."""
     b, c, h, w = x.shape
     H, W = int(size[0]), int(size[1])
-    # upsampling by more than 3 (the 4 x 4-pixels-per-lane kernel) reads the small map through its strides: an NCHW view of NHWC rows
-    # — what the 19-class head's GEMM writes — needs no planar copy
-    if not (x.is_contiguous() or (W % 4 == 0 and 3 * w < W and 3 * h < H and all(s_ >= 0 for s_ in x.stride()))):
+    # (the 4 x 4-pixels-per-lane kernel can read the small map through its strides — awseg_upsample_bilinear_strided — but lanes that
+    # walk NHWC rows 76 bytes apart keep the texture addresser busy for 0.73 ms where the planar map takes 0.32: a planar copy of
+    # the small map (57 us at the bench shape) is the cheaper way, measured)
+    if not (x.is_contiguous() or (STRIDED_UPSAMPLE and W % 4 == 0 and 3 * w < W and 3 * h < H and all(s_ >= 0 for s_ in x.stride()))):
         x = x.contiguous()
     out = torch.empty(b, c, H, W, dtype=torch.float32, device=x.device)
     sb, sc, sy, sx = x.stride()
@@ -1176,18 +1178,12 @@ def rowdot_sigmoid(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
-_pool_branch_ws = {}
-
-
 def aspp_pool_branch(mean: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: Optional[torch.Tensor]) -> torch.Tensor:
-    """relu(mean @ w1^T + b1) @ w2^T + b2 for one row per image (the ASPP pooling branch and its slice of the projection), one launch."""
+    """relu(mean @ w1^T + b1) @ w2^T + b2 for one row per image (the ASPP pooling branch and its slice of the projection)."""
     mean, w1, b1, w2 = mean.contiguous(), w1.contiguous(), b1.contiguous(), w2.contiguous()
     b, cin = mean.shape
     cmid, cout = w1.shape[0], w2.shape[0]
-    key = (str(mean.device), b, cmid)
-    ws = _pool_branch_ws.get(key)
-    if ws is None:                                                # zeroed once: the kernel leaves its ticket counter at zero
-        ws = _pool_branch_ws[key] = torch.zeros(int(N.lib().awseg_aspp_pool_branch_workspace(b, cmid)), dtype=torch.uint8, device=mean.device)
+    ws = torch.empty(int(N.lib().awseg_aspp_pool_branch_workspace(b, cmid)), dtype=torch.uint8, device=mean.device)
     out = torch.empty(b, cout, dtype=torch.float32, device=mean.device)
     N.call("awseg_aspp_pool_branch", N.ptr(mean), b, cin, N.ptr(w1), N.ptr(b1), cmid, N.ptr(w2), N.ptr(None if b2 is None else b2.contiguous()),
            cout, N.ptr(ws), N.ptr(out), N.stream())

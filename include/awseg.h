@@ -739,9 +739,8 @@ int awseg_rowdot_sigmoid(const float* x, int64_t rows, int k, const float* w, co
 
 /* smp's ASPPPooling branch behind its global mean, and that branch's slice of the ASPP projection (the model built at
  * PKG/models/model.py:262-268), for one row per image: out[b, :] = relu(mean[b, :] w1^T + b1) w2^T + b2 with mean [batch, cin],
- * w1 [cmid, cin] and b1 [cmid] (BatchNorm folded), w2 [cout, cmid], b2 [cout] or NULL.  One launch; workspace =
- * awseg_aspp_pool_branch_workspace(batch, cmid) bytes whose first 16 are ZERO at the first launch (the kernel leaves them zero);
- * one launch at a time per workspace. */
+ * w1 [cmid, cin] and b1 [cmid] (BatchNorm folded), w2 [cout, cmid], b2 [cout] or NULL.  Two small kernels (a block per four
+ * channels each) with the hidden row in workspace = awseg_aspp_pool_branch_workspace(batch, cmid) bytes. */
 int64_t awseg_aspp_pool_branch_workspace(int batch, int cmid);
 int awseg_aspp_pool_branch(const float* mean, int batch, int cin, const float* w1, const float* b1, int cmid, const float* w2,
                            const float* b2, int cout, void* workspace, float* out, awseg_stream_t stream);

@@ -1606,7 +1606,7 @@ def test_attention_d32_packed_keys_and_values(ops, shape):
 def test_rowdot_sigmoid_and_aspp_pool_branch_vs_float64(ops):
     """The two small tails of the DeepLab member: 1x1 convolution to one channel + Sigmoid on NHWC rows, and the ASPP pooling
     branch (1x1 + folded BatchNorm + ReLU on one row per image, then its slice of the projection) — against float64; the pooled
-    branch twice on the same workspace (its ticket counter must be back at zero) and with a batch above one pass of the kernel."""
+    branch twice and with a batch above one pass of the kernel."""
     g = torch.Generator(device="cuda").manual_seed(17)
     x = torch.randn(1000, 128, device="cuda", generator=g)
     w = torch.randn(128, device="cuda", generator=g) * 0.1

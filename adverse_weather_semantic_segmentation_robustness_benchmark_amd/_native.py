@@ -56,6 +56,8 @@ SIGNATURES = {
     "awseg_gemm_bf16_bias_act": (c_i, [c_p, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_i, c_p]),
     "awseg_conv3x3_winograd_bf16_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_p, c_p]),
     "awseg_attention_d32_bf16": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_p]),
+    "awseg_attention_d32_split_workspace": (c_i64, [c_i, c_i, c_i]),
+    "awseg_attention_d32_split_ws": (c_i, [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     "awseg_attention_d32_packed_kv": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "awseg_dwconv3x3_upcat_nhwc": (c_i, [c_p, c_i, c_i, c_i, c_p, c_i, c_i64, c_i, c_i, c_p, c_p, c_p]),
     "awseg_winograd_split_weight_halfs": (c_i64, [c_i, c_i]),

@@ -464,6 +464,219 @@ void attention_d32_split_kernel(const float* __restrict__ q, const float* __rest
     attn_split_pass<true>(q, k, v, out, nq, nkv, heads, scale_log2e, kvp, sK, sV, sMax, sc);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The split-operand kernel reading a PREPARED key / value image.  attention_d32_split_kernel splits every key tile again in every
+// query block — 1 024 blocks per image in MiT stage 1, each spending ~36 of its ~150 vector instructions and 10 of its 19 LDS
+// instructions per tile on the same 2 048 keys, in a loop that is bound by its vector instruction count (a software-pipelined
+// variant that ran every MFMA beside vector work of another tile was 6 % SLOWER: DESIGN.md 11).  Here one small kernel per launch
+// writes, for every (image, head), the tiles exactly as the query blocks want them in LDS — [32 keys][32 hi | 32 lo | pad] then
+// V^T [32 d][32 hi | 32 lo | pad] in the PV slot order, f16, scaled low parts, 9 216 bytes a tile — and the query blocks fetch a
+// tile with nine LDS-DMA instructions per block (global -> LDS, no registers, no vector work), one tile ahead.
+// Operand range: the image kernel sees every key / value of its (image, head) and settles their exponents itself (2^-ek, 2^-ev
+// from the maxima when they reach 2^15, exponents left in a table); the query blocks keep the optimistic pass / scaled second pass
+// for q alone.  Same arithmetic per element as attention_d32_split_kernel: same values.
+constexpr int IMG_TILE_HALFS = (TK + D) * SROW;                    // 4 608 halfs
+
+__device__ __forceinline__ uint32_t at_lds_addr(const void* p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)p; }
+__device__ __forceinline__ void at_dma16(__amdgpu_buffer_rsrc_t rsrc, uint32_t voff, uint32_t soff, uint32_t lds_base)
+{
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds" : : "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "m0", "memory");
+}
+
+__global__ __launch_bounds__(AT)
+void attn_kv_image_kernel(const float* __restrict__ k, const float* __restrict__ v, int kvp, int nkv, int heads,
+                          _Float16* __restrict__ img, int* __restrict__ exps)
+{
+    __shared__ unsigned sM[2];
+    const int tid = threadIdx.x, h = blockIdx.x, b = blockIdx.y;
+    const float* kb = k + (size_t)b * nkv * kvp + h * D;
+    const float* vb = v + (size_t)b * nkv * kvp + h * D;
+    const int lkey = tid >> 3, lc = tid & 7;
+    const size_t g_off = (size_t)lkey * kvp + 4 * lc;
+    const int wk0 = lkey * SROW + 4 * lc;
+    const int wv0 = TK * SROW + (4 * lc) * SROW + pv_slot(lkey);
+    const int ntiles = nkv / TK;
+    if (tid < 2) sM[tid] = 0u;
+    __syncthreads();
+    float kmax = 0.f, vmax = 0.f;
+    for (int t = 0; t < ntiles; ++t) {
+        kmax = amax4(kmax, *reinterpret_cast<const float4*>(kb + (size_t)t * TK * kvp + g_off));
+        vmax = amax4(vmax, *reinterpret_cast<const float4*>(vb + (size_t)t * TK * kvp + g_off));
+    }
+    if (kmax >= kSplitLimit) atomicMax(&sM[0], __builtin_bit_cast(unsigned, kmax));
+    if (vmax >= kSplitLimit) atomicMax(&sM[1], __builtin_bit_cast(unsigned, vmax));
+    __syncthreads();
+    const int ek = guard_exponent(sM[0]), ev = guard_exponent(sM[1]);
+    auto p2 = [](int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); };
+    const float sk = p2(-ek), sv = p2(-ev);
+    if (tid == 0) { exps[((size_t)b * heads + h) * 2] = ek; exps[((size_t)b * heads + h) * 2 + 1] = ev; }
+    _Float16* base = img + ((size_t)b * heads + h) * ntiles * IMG_TILE_HALFS;
+    for (int t = 0; t < ntiles; ++t) {
+        float4 kk4 = *reinterpret_cast<const float4*>(kb + (size_t)t * TK * kvp + g_off);
+        float4 vv4 = *reinterpret_cast<const float4*>(vb + (size_t)t * TK * kvp + g_off);
+        kk4.x *= sk; kk4.y *= sk; kk4.z *= sk; kk4.w *= sk;        // (x 1.0 when in range: exact)
+        vv4.x *= sv; vv4.y *= sv; vv4.z *= sv; vv4.w *= sv;
+        _Float16* T = base + (size_t)t * IMG_TILE_HALFS;
+        u32x2 H, L; unsigned hh, ll;
+        split_pair(kk4.x, kk4.y, hh, ll); H[0] = hh; L[0] = ll;
+        split_pair(kk4.z, kk4.w, hh, ll); H[1] = hh; L[1] = ll;
+        *reinterpret_cast<u32x2*>(&T[wk0]) = H;
+        *reinterpret_cast<u32x2*>(&T[wk0 + 32]) = L;
+        unsigned vh01, vl01, vh23, vl23;
+        split_pair(vv4.x, vv4.y, vh01, vl01);
+        split_pair(vv4.z, vv4.w, vh23, vl23);
+        unsigned short* sv16 = reinterpret_cast<unsigned short*>(&T[wv0]);
+        sv16[0] = (unsigned short)vh01;            sv16[32] = (unsigned short)vl01;
+        sv16[SROW] = (unsigned short)(vh01 >> 16); sv16[SROW + 32] = (unsigned short)(vl01 >> 16);
+        sv16[2 * SROW] = (unsigned short)vh23;     sv16[2 * SROW + 32] = (unsigned short)vl23;
+        sv16[3 * SROW] = (unsigned short)(vh23 >> 16); sv16[3 * SROW + 32] = (unsigned short)(vl23 >> 16);
+    }
+}
+
+// SCALED: some operand carries a power-of-two scale (sc); QGUARD: track max|q| and report a block whose q left the range
+template <bool SCALED, bool QGUARD>
+__device__ __forceinline__ bool attn_split_pass_img(const float* __restrict__ q, const _Float16* __restrict__ img_bh, float* __restrict__ out,
+                                                    int nq, int nkv, int heads, float scale_log2e, _Float16 (*sKV)[IMG_TILE_HALFS],
+                                                    unsigned* sMax, const attn_scales sc)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hk = lane >> 5, li = lane & 31;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int C = heads * D;
+    const int q0 = blockIdx.x * 128 + wave * 32;
+    float qmax = 0.f;
+    h8 qh[2], ql[2];
+    {
+        const int qi = q0 + li;
+        const float* qp = q + ((size_t)b * nq + (qi < nq ? qi : nq - 1)) * C + h * D;
+        const float qs = SCALED ? scale_log2e * sc.sq : scale_log2e;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const float4 a4 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * hk);
+            const float4 b4 = *reinterpret_cast<const float4*>(qp + 16 * s + 8 * hk + 4);
+            const float x[8] = { a4.x * qs, a4.y * qs, a4.z * qs, a4.w * qs, b4.x * qs, b4.y * qs, b4.z * qs, b4.w * qs };
+            if (QGUARD) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) qmax = __builtin_fmaxf(qmax, __builtin_fabsf(x[i]));
+            }
+            split8(x, qh[s], ql[s]);
+        }
+    }
+    const int ntiles = nkv / TK;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)img_bh, 0, ntiles * IMG_TILE_HALFS * 2, 0x00020000);
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane(at_lds_addr(&sKV[0][0]));
+    const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // a tile = nine 1 KB LDS-DMA instructions: wave w issues chunks w and w + 4, wave 0 the ninth
+    auto dma_tile = [&](int t, int buf) {
+        const uint32_t so = (uint32_t)t * (uint32_t)(IMG_TILE_HALFS * 2), lb = lds0 + (uint32_t)buf * (uint32_t)(IMG_TILE_HALFS * 2);
+        at_dma16(rsrc, (uint32_t)(lane * 16) + wave_u * 1024u, so, lb + wave_u * 1024u);
+        at_dma16(rsrc, (uint32_t)(lane * 16) + (wave_u + 4u) * 1024u, so, lb + (wave_u + 4u) * 1024u);
+        if (wave_u == 0) at_dma16(rsrc, (uint32_t)(lane * 16) + 8192u, so, lb + 8192u);
+    };
+    dma_tile(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    f32x16 om, oc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { om[r] = 0.f; oc[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+    const int a_off = li * SROW + 8 * hk;
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) dma_tile(t + 1, buf ^ 1);              // (that buffer's readers passed the barrier behind tile t - 1)
+        const h8* kr = reinterpret_cast<const h8*>(&sKV[buf][a_off]);
+        const h8 kh0 = kr[0], kh1 = kr[2], kl0 = kr[4], kl1 = kr[6];
+        f32x16 sm, scx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sm[r] = 0.f; scx[r] = 0.f; }
+        sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], sm, 0, 0, 0);
+        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], scx, 0, 0, 0);
+        sm = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], sm, 0, 0, 0);
+        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], scx, 0, 0, 0);
+        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], scx, 0, 0, 0);
+        scx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], scx, 0, 0, 0);
+        const h8* vr = reinterpret_cast<const h8*>(&sKV[buf][TK * SROW + a_off]);
+        const h8 vh0 = vr[0], vh1 = vr[2], vl0 = vr[4], vl1 = vr[6];
+        float s[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s[r] = fmaf(scx[r], kLoInv, sm[r]);
+            if (SCALED) s[r] = s[r] * sc.bq * sc.bk;
+        }
+        float mt = fmaxf(fmaxf(s[0], s[1]), fmaxf(s[2], s[3]));
+#pragma unroll
+        for (int r = 4; r < 16; r += 4) mt = fmaxf(mt, fmaxf(fmaxf(s[r], s[r + 1]), fmaxf(s[r + 2], s[r + 3])));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        const float m_sh = m_new - 15.0f;
+        float p[16], ls = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { p[r] = __builtin_amdgcn_exp2f(s[r] - m_sh); ls += p[r]; }
+        ls += __shfl_xor(ls, 32, 64);
+        l_run = l_run * alpha + ls;
+        m_run = m_new;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { om[r] *= alpha; oc[r] *= alpha; }
+        }
+        h8 ph0, pl0, ph1, pl1;
+        split8_unscaled(p, ph0, pl0);
+        split8_unscaled(p + 8, ph1, pl1);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, ph0, om, 0, 0, 0);
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl0, ph0, oc, 0, 0, 0);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, ph1, om, 0, 0, 0);
+        oc = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl1, ph1, oc, 0, 0, 0);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh0, pl0, om, 0, 0, 0);
+        om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh1, pl1, om, 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's share of tile t + 1 has landed
+        __syncthreads();
+    }
+
+    if (QGUARD) {
+        if (qmax >= kSplitLimit) atomicMax(&sMax[0], __builtin_bit_cast(unsigned, qmax));
+        __syncthreads();
+        if (sMax[0] != 0u) return true;
+    }
+    const int qi = q0 + li;
+    if (qi < nq) {
+        const float inv = 1.0f / l_run;
+        float* op = out + ((size_t)b * nq + qi) * C + h * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 o4 = make_float4(fmaf(oc[4 * g], kLoInv, om[4 * g]) * inv, fmaf(oc[4 * g + 1], kLoInv, om[4 * g + 1]) * inv,
+                                    fmaf(oc[4 * g + 2], kLoInv, om[4 * g + 2]) * inv, fmaf(oc[4 * g + 3], kLoInv, om[4 * g + 3]) * inv);
+            if (SCALED) { o4.x *= sc.bv; o4.y *= sc.bv; o4.z *= sc.bv; o4.w *= sc.bv; }
+            *reinterpret_cast<float4*>(op + 8 * g + 4 * hk) = o4;
+        }
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(AT, AWSEG_ATTN_SPLIT_WAVES)
+void attention_d32_split_img_kernel(const float* __restrict__ q, const _Float16* __restrict__ img, const int* __restrict__ exps,
+                                    float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e)
+{
+    __shared__ __attribute__((aligned(16))) _Float16 sKV[2][IMG_TILE_HALFS];
+    __shared__ unsigned sMax[1];
+    const int h = blockIdx.y, b = blockIdx.z;
+    if (threadIdx.x == 0) sMax[0] = 0u;                              // ordered by the pass's first barrier
+    const _Float16* img_bh = img + ((size_t)b * heads + h) * (size_t)(nkv / TK) * IMG_TILE_HALFS;
+    const int ek = exps[((size_t)b * heads + h) * 2], ev = exps[((size_t)b * heads + h) * 2 + 1];
+    auto p2 = [](int e) { return __builtin_bit_cast(float, (unsigned)(127 + e) << 23); };
+    attn_scales sc = {1.f, p2(-ek), p2(-ev), 1.f, p2(ek), p2(ev)};
+    bool redo;
+    if ((ek | ev) == 0) redo = attn_split_pass_img<false, true>(q, img_bh, out, nq, nkv, heads, scale_log2e, sKV, sMax, sc);
+    else redo = attn_split_pass_img<true, true>(q, img_bh, out, nq, nkv, heads, scale_log2e, sKV, sMax, sc);
+    if (!redo) return;
+    const int eq = guard_exponent(sMax[0]);
+    sc.sq = p2(-eq); sc.bq = p2(eq);
+    __syncthreads();
+    attn_split_pass_img<true, false>(q, img_bh, out, nq, nkv, heads, scale_log2e, sKV, sMax, sc);
+}
+
 __global__ __launch_bounds__(AT, 2)
 void attention_d32_bf16_kernel(const float* __restrict__ q, const float* __restrict__ k, const float* __restrict__ v,
                                float* __restrict__ out, int nq, int nkv, int heads, float scale_log2e, int kvp)
@@ -513,6 +726,37 @@ AWSEG_API int awseg_attention_d32_bf16(const float* q, const float* k, const flo
                                        int n_queries, int n_keys, float scale, awseg_stream_t stream)
 {
     return launch_attention(attention_d32_bf16_kernel, q, k, v, out, batch, heads, n_queries, n_keys, scale, stream);
+}
+
+// workspace of the image form: [exponent table: 2 ints per (image, head), padded to 256 bytes][tiles: 9 216 bytes each]
+AWSEG_API int64_t awseg_attention_d32_split_workspace(int batch, int heads, int n_keys)
+{
+    if (batch < 0 || heads < 0 || n_keys < 0) return 0;
+    const int64_t tab = ((int64_t)batch * heads * 2 * 4 + 255) / 256 * 256;
+    return tab + (int64_t)batch * heads * (n_keys / TK) * IMG_TILE_HALFS * 2;
+}
+
+AWSEG_API int awseg_attention_d32_split_ws(const float* q, const float* k, const float* v, int kv_pitch, float* out, int batch, int heads,
+                                           int n_queries, int n_keys, float scale, void* workspace, awseg_stream_t stream)
+{
+    if (batch == 0 || n_queries == 0) return 0;
+    if (!q || !k || !v || !out || !workspace || batch < 0 || heads < 1 || n_queries < 0 || n_keys < TK) return AWSEG_EINVAL;
+    if (n_keys % TK) return AWSEG_ERANGE;
+    if (heads > 65535 || batch > 65535) return AWSEG_ERANGE;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)out & 15) || ((uintptr_t)workspace & 255)) return AWSEG_EALIGN;
+    if (kv_pitch == 0) kv_pitch = heads * D;
+    if (kv_pitch < heads * D || (kv_pitch & 3)) return AWSEG_EINVAL;
+    if ((int64_t)(n_keys / TK) * IMG_TILE_HALFS * 2 > 0x7fffffff) return AWSEG_ERANGE;     // one (image, head)'s tiles behind a 32-bit descriptor
+    int* exps = reinterpret_cast<int*>(workspace);
+    const int64_t tab = ((int64_t)batch * heads * 2 * 4 + 255) / 256 * 256;
+    _Float16* img = reinterpret_cast<_Float16*>(reinterpret_cast<char*>(workspace) + tab);
+    hipLaunchKernelGGL(attn_kv_image_kernel, dim3((unsigned)heads, (unsigned)batch), dim3(AT), 0, awseg_s(stream), k, v, kv_pitch, n_keys, heads, img, exps);
+    AWSEG_LAUNCH_CHECK();
+    dim3 grid((unsigned)((n_queries + 127) / 128), (unsigned)heads, (unsigned)batch);
+    hipLaunchKernelGGL(attention_d32_split_img_kernel, grid, dim3(AT), 0, awseg_s(stream), q, img, exps, out, n_queries, n_keys, heads,
+                       scale * 1.4426950408889634f);
+    AWSEG_LAUNCH_CHECK();
+    return 0;
 }
 
 AWSEG_API int awseg_attention_d32_packed_kv(const float* q, const float* kv, float* out, int batch, int heads, int n_queries,

@@ -1034,8 +1034,28 @@ def attention_d32(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int,
         sym = "awseg_attention_d32_bf16"
     else:
         sym = "awseg_attention_d32_split" if (ATTENTION_SPLIT if split is None else split) else "awseg_attention_d32"
+    if sym == "awseg_attention_d32_split" and _wants_kv_image(nq, k.shape[1]):
+        _attention_split_ws(q, k, v, 0, out, b, heads, nq, k.shape[1], scale)
+        return out
     N.call(sym, N.ptr(q), N.ptr(k), N.ptr(v), N.ptr(out), b, heads, nq, k.shape[1], float(scale), N.stream())
     return out
+
+
+ATTN_KV_IMAGE = os.environ.get("AWSEG_ATTN_KV_IMAGE", "1") != "0"     # split-operand attention: keys / values prepared once per launch
+
+
+def _wants_kv_image(nq: int, nkv: int) -> bool:
+    """The prepared image pays where many query blocks share the keys: MiT stages 1 / 2 at the bench shape (64 / 16 queries per key:
+    1.148 -> 1.053 ms for stage 1); at 4 queries per key (stage 3: 0.372 -> 0.376 ms) the preparing kernel costs what it saves."""
+    return ATTN_KV_IMAGE and nq >= 8 * nkv
+
+
+def _attention_split_ws(q, k, v, pitch, out, b, heads, nq, nkv, scale):
+    """awseg_attention_d32_split_ws on a per-stream scratch workspace (v may be a view into k's rows: packed keys | values)."""
+    nbytes = int(N.lib().awseg_attention_d32_split_workspace(b, heads, nkv))
+    ws = N.workspace.get(q.device, nbytes, tag="attn%d" % torch.cuda.current_stream(q.device).cuda_stream)
+    N.call("awseg_attention_d32_split_ws", N.ptr(q), N.ptr_strided(k), N.ptr_strided(v), int(pitch), N.ptr(out), b, heads, nq, nkv, float(scale),
+           N.ptr(ws), N.stream())
 
 
 def attention_d32_packed_kv(q: torch.Tensor, kv: torch.Tensor, heads: int, scale: float, split: Optional[bool] = None) -> torch.Tensor:
@@ -1046,6 +1066,9 @@ def attention_d32_packed_kv(q: torch.Tensor, kv: torch.Tensor, heads: int, scale
     assert kv.shape[-1] == 2 * c
     out = torch.empty_like(q)
     mode = 2 if (split is None and PRECISION == "bf16") else (1 if (ATTENTION_SPLIT if split is None else split) else 0)
+    if mode == 1 and _wants_kv_image(nq, kv.shape[1]):
+        _attention_split_ws(q, kv, kv[..., c:], 2 * c, out, b, heads, nq, kv.shape[1], scale)
+        return out
     N.call("awseg_attention_d32_packed_kv", N.ptr(q), N.ptr(kv), N.ptr(out), b, heads, nq, kv.shape[1], float(scale), mode, N.stream())
     return out
 

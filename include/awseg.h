@@ -611,6 +611,17 @@ int awseg_conv3x3_winograd_bf16_nhwc(const float* x, int batch, int height, int 
                                      const float* w2, const float* b2, float* out, awseg_stream_t stream);
 int awseg_attention_d32_bf16(const float* q, const float* k, const float* v, float* out, int batch, int heads,
                              int n_queries, int n_keys, float scale, awseg_stream_t stream);
+/* awseg_attention_d32_split with the keys and values PREPARED once per launch: a first small kernel writes every (image, head)'s
+ * key / value tiles as the query blocks want them in LDS (f16 high | scaled low parts, V transposed into the PV operand order,
+ * 9 216 bytes per 32 keys) and settles the key / value operand range there (exponents in a table); the query blocks (1 024 per image
+ * in MiT stage 1) fetch tiles by LDS-DMA instead of each splitting the same 2 048 keys again.  k / v: float32 rows of kv_pitch floats
+ * (0: heads*32; 2*heads*32 with v = k + heads*32 for the packed rows of awseg_attention_d32_packed_kv).  workspace:
+ * awseg_attention_d32_split_workspace(batch, heads, n_keys) bytes, 256-byte aligned, scratch.  Same arithmetic per element as
+ * awseg_attention_d32_split: same values. */
+int64_t awseg_attention_d32_split_workspace(int batch, int heads, int n_keys);
+int awseg_attention_d32_split_ws(const float* q, const float* k, const float* v, int kv_pitch, float* out, int batch, int heads,
+                                 int n_queries, int n_keys, float scale, void* workspace, awseg_stream_t stream);
+
 /* The same three attention kernels on PACKED keys and values: kv float32 [B, n_keys, 2*heads*32] holds a token's key in its first
  * heads*32 floats and its value in the last — what ONE GEMM with the key and value projections' weights stacked ([2C, C]) writes,
  * so that SegformerEfficientSelfAttention's two projections of the reduced tokens (transformers modeling_segformer.py, behind

@@ -1696,3 +1696,28 @@ def test_stem_image_fill_matches_strided_copy(ops):
             ref[:, :, 3:3 + W, C:] = 0.0                      # channels past C of the interior are written as zeros
         ops.stem_image_fill(x, got)
         assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("scales", [(1.0, 1.0, 1.0), (1e5, 1.0, 1.0), (1.0, 3e5, 1.0), (1.0, 1.0, 7e4), (2e5, 1e5, 1e6)])
+def test_attention_d32_prepared_key_value_image_equals_in_block_staging(ops, scales):
+    """The split-operand attention that reads key / value tiles prepared once per launch (awseg_attention_d32_split_ws: LDS-DMA of
+    f16 high | low images) against the kernel whose query blocks split the tiles themselves: the same values bit for bit, in range
+    and with each of q, k, v (and all three) beyond the f16 range — the image kernel settles the key / value exponents, the query
+    blocks the query's."""
+    qs, ks, vs = scales
+    B, nh, nq, nkv = 2, 2, 2100, 256                            # (>= 8 queries per key: the shapes ops routes to the image form)
+    g = torch.Generator(device="cuda").manual_seed(int(qs + ks + vs) % 1000)
+    C = nh * 32
+    q = torch.randn(B, nq, C, device="cuda", generator=g) * qs
+    k = torch.randn(B, nkv, C, device="cuda", generator=g) * ks
+    v = torch.randn(B, nkv, C, device="cuda", generator=g) * vs
+    prev = ops.ATTN_KV_IMAGE
+    try:
+        ops.ATTN_KV_IMAGE = False
+        ref = ops.attention_d32(q, k, v, nh, 32 ** -0.5, split=True)
+        ops.ATTN_KV_IMAGE = True
+        got = ops.attention_d32(q, k, v, nh, 32 ** -0.5, split=True)
+    finally:
+        ops.ATTN_KV_IMAGE = prev
+    assert torch.isfinite(got).all()
+    assert torch.equal(got, ref)

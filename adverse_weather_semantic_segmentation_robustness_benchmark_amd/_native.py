@@ -98,6 +98,7 @@ SIGNATURES = {
     "awseg_layernorm_rows": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_f, c_p, c_p]),
     "awseg_ensemble_eval_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_i, c_p, c_p, c_p, c_i, c_p, c_p, c_i, c_p, c_i, c_p, c_i,
                                        c_f, c_f, c_p, c_p]),
+    "awseg_gemm_split_pieces_bias_act": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_p]),
     "awseg_gemm_split_dual_bias_act": (c_i, [c_p, c_i, c_p, c_i, c_i64, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i64, c_i, c_p]),
     "awseg_conv_gemm_split_bias_act": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),
     "awseg_conv_rows_gemm_split_bias_act": (c_i, [c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p]),

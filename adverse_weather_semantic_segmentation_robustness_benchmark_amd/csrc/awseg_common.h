@@ -101,7 +101,7 @@ __device__ __forceinline__ float awseg_u01(uint32_t a) { return (float)(a >> 8) 
 int awseg_gemm_split3_weights(const float* w, int n, int k, uint16_t* w3, const unsigned* trailer, hipStream_t stream);
 bool awseg_gemm_split3_eligible(int64_t m, int n, int k, const void* x, const void* out, const void* residual, const void* bias);
 // dual: the A operand continues in a second source behind column k1 (gemm_split3.hip g3_args: x2, K1, x2H, x2W, x2s, x2Ho, x2Wo)
-struct awseg_g3_dual { const float* x2; int k1; int h, w, stride, ho, wo; int64_t bytes; };
+struct awseg_g3_dual { const float* x2; int k1; int h, w, stride, ho, wo; int64_t bytes; const float* x3 = nullptr; const float* x4 = nullptr; };   // bytes: of ONE piece
 int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned* trailer, const float* bias, const float* residual,
                              int act, float* out, int64_t m, int n, int k, int cus, hipStream_t stream, const int* conv = nullptr,
                              bool bf16 = false, const awseg_g3_dual* dual = nullptr);

@@ -637,6 +637,34 @@ AWSEG_API int awseg_gemm_split_dual_bias_act(const float* x, int k1, const float
                                     act, out, m, n, k, cus, awseg_s(stream), nullptr, false, &d);
 }
 
+AWSEG_API int awseg_gemm_split_pieces_bias_act(const float* const* pieces, int n_pieces, int k_piece, const uint16_t* w_split, const float* bias,
+                                               const float* residual, int act, float* out, int64_t m, int n, awseg_stream_t stream)
+{
+    if (m == 0 || n == 0) return 0;
+    if (!pieces || n_pieces < 2 || n_pieces > 4 || !w_split || !out || m < 0 || n < 0 || k_piece < 32 || act < 0 || act > 1) return AWSEG_EINVAL;
+    if (k_piece % 32) return AWSEG_ERANGE;
+    for (int i = 0; i < n_pieces; ++i) {
+        if (!pieces[i]) return AWSEG_EINVAL;
+        if ((uintptr_t)pieces[i] & 15) return AWSEG_EALIGN;
+    }
+    if ((uintptr_t)w_split & 15) return AWSEG_EALIGN;
+    const int k = n_pieces * k_piece;
+    if (!awseg_gemm_split3_eligible(m, n, k, pieces[0], out, residual, bias)) return AWSEG_ERANGE;
+    awseg_g3_dual d;
+    d.x2 = pieces[1]; d.k1 = k_piece; d.stride = 0; d.h = d.w = d.ho = d.wo = 1;
+    d.bytes = m * (int64_t)k_piece * 4;
+    d.x3 = n_pieces > 2 ? pieces[2] : nullptr; d.x4 = n_pieces > 3 ? pieces[3] : nullptr;
+    if (d.bytes > 0x7fffffff) return AWSEG_ERANGE;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 1) n_cu = 256;
+        cus = n_cu;
+    }
+    return awseg_gemm_split3_launch(pieces[0], w_split + 2 * (int64_t)n * k + 8, reinterpret_cast<const unsigned*>(w_split + 2 * (int64_t)n * k), bias, residual,
+                                    act, out, m, n, k, cus, awseg_s(stream), nullptr, false, &d);
+}
+
 AWSEG_API int awseg_conv_gemm_split_bias_act(const float* x, int64_t batch, int height, int width, int channels, int kernel_h,
                                              int kernel_w, int stride, int pad, int dilation, const uint16_t* w_split,
                                              const float* bias, const float* residual, int act, float* out, int n,

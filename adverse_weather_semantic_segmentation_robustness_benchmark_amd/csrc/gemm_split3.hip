@@ -99,6 +99,8 @@ struct g3_args {
     // m = (b, oy, ox) of an x2Ho x x2Wo grid — a 1x1 convolution of stride x2s on the block's input (awseg_gemm_split_dual_bias_act)
     const float* x2; int K1, x2H, x2W, x2s, x2Ho, x2Wo;
     int64_t x2_bytes;
+    // ... and, for plain rows, up to two more pieces of the same width as x2 behind it (x3, x4: [x | x2 | x3 | x4], K2 floats each)
+    const float* x3; const float* x4; int K2;
 };
 
 // ABL != 0: ablation builds for measurements (wrong results, valid times; AWSEG_G3_ABL): 1 no LDS-DMA in the K loop, 2 no MFMAs,
@@ -154,13 +156,17 @@ void gemm_split3_kernel(g3_args a)
     int cby[4], cy0[4], cx0[4];                                    // CONV: image row base b * cH, first tap's input row / column of this lane's A rows (< 0: row past M)
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane(lds_addr3(smem));
     const uint32_t wave_u = __builtin_amdgcn_readfirstlane(wave);   // scalar register: the LDS-DMA base goes through m0
-    __amdgpu_buffer_rsrc_t x_rsrc, w_rsrc, x2_rsrc;
+    __amdgpu_buffer_rsrc_t x_rsrc, w_rsrc, x2_rsrc, x3_rsrc, x4_rsrc;
     auto point = [&](int64_t m0, int n0) {
         const int64_t rows_left = a.M - m0;                      // rows past M: out-of-range source -> zeros, never stored
         const int64_t xbytes = rows_left * (int64_t)KA * 4;
         if (CONV) x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)a.x_bytes, 0x00020000);
         else x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + m0 * KA), 0, (int)(xbytes > 0x7fffffff ? 0x7fffffff : xbytes), 0x00020000);
-        if (DUAL) x2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, (int)a.x2_bytes, 0x00020000);
+        if (DUAL) {
+            x2_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x2, 0, (int)a.x2_bytes, 0x00020000);
+            x3_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x3 ? a.x3 : a.x2), 0, (int)a.x2_bytes, 0x00020000);
+            x4_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.x4 ? a.x4 : a.x2), 0, (int)a.x2_bytes, 0x00020000);
+        }
         // the weight image is [n-tile of IB rows][kb K tiles][IB rows][ROWB bytes]; this block's BN rows start at row n0 % IB of n-tile n0 / IB
         const int IB = a.img_bn, nr = n0 % IB;
         w_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.w3 + ((int64_t)(n0 - nr) * kb + nr) * (ROWB / 2)), 0, (IB * kb - nr) * ROWB, 0x00020000);
@@ -172,7 +178,7 @@ void gemm_split3_kernel(g3_args a)
             a_voff_last[j] = (ktail == 0 || c * 4 < ktail) ? a_voff[j] : 0x80000000u;     // chunks past K read zeros (the weight image is zero there too)
             if (DUAL) {
                 const int64_t m = m0 + row;
-                const int k2 = a.K - a.K1;
+                const int k2 = a.K2;
                 int64_t pix = m;                                   // plain rows
                 if (a.x2s > 0) {
                     const int b = (int)(m / ((int64_t)a.x2Ho * a.x2Wo));
@@ -216,8 +222,19 @@ void gemm_split3_kernel(g3_args a)
             }
         } else {
         if (DUAL && kt >= kt1) {                                   // (block-uniform)
+            const int kt2 = a.K2 / G3K;
+            const int piece = __builtin_amdgcn_readfirstlane((kt - kt1) / kt2);
+            const uint32_t ko = (uint32_t)__builtin_amdgcn_readfirstlane(((kt - kt1) - piece * kt2) * 128);
+            if (piece == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) dma16(x2_rsrc, a_voff2[j], (uint32_t)((kt - kt1) * 128), la + (uint32_t)(j * 1024));
+                for (int j = 0; j < 4; ++j) dma16(x2_rsrc, a_voff2[j], ko, la + (uint32_t)(j * 1024));
+            } else if (piece == 1) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dma16(x3_rsrc, a_voff2[j], ko, la + (uint32_t)(j * 1024));
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dma16(x4_rsrc, a_voff2[j], ko, la + (uint32_t)(j * 1024));
+            }
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j) dma16(x_rsrc, kt == nkt - 1 ? a_voff_last[j] : a_voff[j], (uint32_t)(kt * 128), la + (uint32_t)(j * 1024));
@@ -604,11 +621,14 @@ int awseg_gemm_split3_launch(const float* x, const uint16_t* w3, const unsigned*
                              const awseg_g3_dual* dual)
 {
     g3_args a;
-    a.x2 = nullptr; a.K1 = k; a.x2H = a.x2W = a.x2Ho = a.x2Wo = 1; a.x2s = 0; a.x2_bytes = 0;
+    a.x2 = nullptr; a.K1 = k; a.x2H = a.x2W = a.x2Ho = a.x2Wo = 1; a.x2s = 0; a.x2_bytes = 0; a.x3 = a.x4 = nullptr; a.K2 = 0;
     if (dual) {
-        if (conv || bf16 || dual->k1 % G3K || (k - dual->k1) % G3K || dual->k1 < G3K || k - dual->k1 < G3K || dual->bytes > 0x7fffffff) return AWSEG_ERANGE;
+        const int pieces = 1 + (dual->x3 ? 1 : 0) + (dual->x4 ? 1 : 0);
+        if (conv || bf16 || dual->k1 % G3K || dual->k1 < G3K || (k - dual->k1) % pieces || dual->bytes > 0x7fffffff) return AWSEG_ERANGE;
+        const int k2 = (k - dual->k1) / pieces;
+        if (k2 % G3K || k2 < G3K || (pieces > 1 && dual->stride > 0) || (dual->x4 && !dual->x3)) return AWSEG_ERANGE;
         a.x2 = dual->x2; a.K1 = dual->k1; a.x2H = dual->h; a.x2W = dual->w; a.x2s = dual->stride; a.x2Ho = dual->ho; a.x2Wo = dual->wo;
-        a.x2_bytes = dual->bytes;
+        a.x2_bytes = dual->bytes; a.x3 = dual->x3; a.x4 = dual->x4; a.K2 = k2;
     }
     a.cH = a.cW = a.cC = a.cHo = a.cWo = a.ckw = a.cs = 1; a.cp = 0; a.cd = 1; a.x_bytes = 0; a.cpitch = 1; a.cpx = 0;
     if (conv) {                                                   // {H, W, C, Ho, Wo, kw, stride, pad, dil, batch, pixel pitch (0: C), pad x (-1: pad)}

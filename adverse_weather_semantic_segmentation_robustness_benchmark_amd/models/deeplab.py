@@ -293,14 +293,19 @@ class DeepLabV3PlusDecoder(nn.Module):
         else:
             g2 = branch(gmean, pw_, pbn_) @ parts[4].t() + pb
         acc = g2[:, None, :].expand(B, h * w, Cout).contiguous().view(B * h * w, Cout)
-        # branch 0: 1x1
-        y = branch(flat, aspp.convs[0][0].weight.view(Cout, Cin), aspp.convs[0][1])
-        ops.gemm_bias_act(y, parts[0], zero_bias, 0, residual=acc, out=acc, w_split=psplit[0])
-        # branches 1-3: their pointwise GEMMs
-        for r in range(3):
+        ys = [branch(flat, aspp.convs[0][0].weight.view(Cout, Cin), aspp.convs[0][1])]                 # branch 0: 1x1
+        for r in range(3):                                                                            # branches 1-3: their pointwise GEMMs
             mod = aspp.convs[1 + r]
-            y = branch(dw[r], mod[0][1].weight.view(Cout, Cin), mod[1])
-            ops.gemm_bias_act(y, parts[1 + r], zero_bias, 1 if r == 2 else 0, residual=acc, out=acc, w_split=psplit[1 + r])
+            ys.append(branch(dw[r], mod[0][1].weight.view(Cout, Cin), mod[1]))
+        done = None
+        if ops.ASPP_PIECES and ops.GEMM_SPLIT and ops.PRECISION != "bf16" and acc.is_cuda and Cout % 32 == 0:
+            # the projection of the four pixel branches as ONE product over [b0 | b1 | b2 | b3] (the pieces stay where they are)
+            wcat = fused.cached(aspp.project[0], "proj_pieces", (parts[0], parts[1], parts[2], parts[3]),
+                                lambda: ops.gemm_split_weights(torch.cat(parts[:4], dim=1).contiguous()))
+            done = ops.gemm_split_pieces(ys, wcat, zero_bias, 1, residual=acc, out=acc)
+        if done is None:
+            for i, y in enumerate(ys):
+                ops.gemm_bias_act(y, parts[i], zero_bias, 1 if i == 3 else 0, residual=acc, out=acc, w_split=psplit[i])
         out = acc                                                                     # project BN + ReLU done (Dropout: eval)
         return out.view(B, h, w, Cout).permute(0, 3, 1, 2)                            # NCHW view, channels_last memory
 

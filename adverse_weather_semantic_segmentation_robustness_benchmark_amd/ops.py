@@ -944,6 +944,7 @@ def conv_rows_gemm_split(x_padded: torch.Tensor, w_split: torch.Tensor, bias: Op
 CONV_GATHER = os.environ.get("AWSEG_CONV_GATHER", "1") != "0"
 
 
+ASPP_PIECES = os.environ.get("AWSEG_ASPP_PIECES", "1") != "0"          # ASPP projection: one GEMM over the four pixel branches
 DUAL_TAIL = os.environ.get("AWSEG_DUAL_TAIL", "1") != "0"             # first bottleneck of a ResNet stage: conv3 + downsample branch as one GEMM
 
 
@@ -969,6 +970,26 @@ def gemm_split_dual(x: torch.Tensor, x2: torch.Tensor, w_split: torch.Tensor, bi
             raise N.AwsegError("gemm_split_dual: x2 has a different row count than x")
     out = torch.empty(m, n, dtype=torch.float32, device=x.device)
     rc = N.try_call("awseg_gemm_split_dual_bias_act", N.ptr(x), k1, N.ptr(x2), k2, b, h, w, int(stride), N.ptr(w_split), N.ptr(bias),
+                    N.ptr(residual), act, N.ptr(out), m, n, N.stream())
+    return out if rc == 0 else None
+
+
+def gemm_split_pieces(pieces, w_split: torch.Tensor, bias: Optional[torch.Tensor], act: int = 0, residual: Optional[torch.Tensor] = None,
+                      out: Optional[torch.Tensor] = None) -> Optional[torch.Tensor]:
+    """act(cat(pieces, dim=1) @ w^T + bias (+ residual)) for 2 .. 4 equally wide row matrices [M,k] without the concatenation (one GEMM
+    whose A operand is fetched piece by piece); `out` may be `residual`.  None when the LDS-DMA kernel does not take the shape."""
+    import ctypes
+    pieces = [p_.contiguous() for p_ in pieces]
+    m, kp = pieces[0].shape
+    n = w_split.shape[1]
+    if any(p_.shape != (m, kp) for p_ in pieces) or w_split.shape[2] != kp * len(pieces):
+        raise N.AwsegError("gemm_split_pieces: the pieces must be equally shaped and the weights [N, pieces * k]")
+    if not _split_weights_intact(w_split, n, kp * len(pieces)):
+        raise N.AwsegError("w_split lost its 16-byte trailer (weight exponent): pass the tensor gemm_split_weights returned, not a copy")
+    if out is None:
+        out = torch.empty(m, n, dtype=torch.float32, device=pieces[0].device)
+    arr = (ctypes.c_void_p * len(pieces))(*[p_.data_ptr() for p_ in pieces])
+    rc = N.try_call("awseg_gemm_split_pieces_bias_act", ctypes.cast(arr, ctypes.c_void_p), len(pieces), kp, N.ptr(w_split), N.ptr(bias),
                     N.ptr(residual), act, N.ptr(out), m, n, N.stream())
     return out if rc == 0 else None
 

@@ -127,6 +127,39 @@ def launch_work(name, args):
         # the same products, each issued as THREE f16 MFMA products (split operands): priced as issued, against the f16 peak
         b, heads, nq, nkv = args[4:8]
         return "mfma_f16", 3 * 4.0 * b * heads * nq * nkv * 32
+    if name == "awseg_attention_d32_split_ws":
+        # (q, k, v, kv_pitch, out, batch, heads, n_queries, n_keys, ...): the split-operand products (the preparing kernel's pass over the
+        # keys / values is noise beside them)
+        b, heads, nq, nkv = args[5:9]
+        return "mfma_f16", 3 * 4.0 * b * heads * nq * nkv * 32
+    if name == "awseg_attention_d32_packed_kv":
+        # (q, kv, out, batch, heads, n_queries, n_keys, scale, mode, ...)
+        b, heads, nq, nkv = args[3:7]
+        return ("mfma", 4.0 * b * heads * nq * nkv * 32) if args[8] == 0 else ("mfma_f16", (3 if args[8] == 1 else 1) * 4.0 * b * heads * nq * nkv * 32)
+    if name == "awseg_gemm_split_dual_bias_act":
+        # (x, k1, x2, k2, batch, H2, W2, stride, w_split, bias, residual, act, out, m, n): one product over [x | x2]; bytes: both
+        # operand pieces once (the strided piece: the rows it gathers), the output once
+        k1, k2 = args[1], args[3]
+        m, n = args[13], args[14]
+        flops = 3 * 2.0 * m * n * (k1 + k2)
+        nbytes = 4.0 * (m * (k1 + k2) + m * n + n * (k1 + k2))
+        if nbytes / (HBM_PEAK_GBS * 1e9) > flops / (MFMA_F16_PEAK_TFLOPS * 1e12):
+            return "hbm", nbytes, name + " [launches bound by HBM]"
+        return "mfma_f16", flops
+    if name == "awseg_stem_image":
+        # (x, batch, channels, H, W, ...): the planar frames in, the 4-channel image's interior out
+        _, b, c, h, w = args[:5]
+        return "hbm", 4.0 * b * h * w * (c + 4)
+    if name == "awseg_aspp_depthwise3_mean":
+        # (x, batch, h, w, C, ...): x once, the three depthwise maps out
+        _, b, h, w, c = args[:5]
+        return "hbm", 16.0 * b * h * w * c
+    if name == "awseg_rowdot_sigmoid":
+        return "hbm", 4.0 * args[1] * (args[2] + 1)        # (x, rows, k, ...)
+    if name == "awseg_upsample_bilinear_strided":
+        # (low, batch, channels, h, w, strides x4, H, W, ...): the small map in, the full-resolution planes out
+        _, b, c, h, w = args[:5]
+        return "hbm", 4.0 * b * c * (h * w + args[9] * args[10])
     if name == "awseg_gemm_split_bias_act":
         # (x, w_split, bias, residual, act, out, m, n, k): three f16 MFMA products per float32-grade product, priced as issued —
         # where the matrix pipe is the roofline.  A launch whose algorithmic bytes (x once, the output once, the residual once) take
@@ -227,7 +260,10 @@ DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
                  "awseg_conv3x3_winograd_bf16_nhwc": ("wino8p_kernel<0, true>", "wino8p_kernel<1, true>", "wino8s_kernel<0, true>", "wino8s_kernel<1, true>", "wino8_kernel<0, true>", "wino8_kernel<1, true>", "wino_split_kernel<0, true>", "wino_split_kernel<1, true>"),
                  "awseg_gemm_split_bias_act": ("gemm_split3_kernel<false, 0, false", "gemm_split3_kernel<true, 0, false", "gemm_split_kernel<4, 2, 2, 4, false, false", "gemm_split_kernel<4, 2, 2, 4, true, false", "gemm_split_kernel<2, 2, 2, 4, false, false", "gemm_split_kernel<1, 2, 4, 2, false, false", "gemm_split_kernel<2, 2, 2, 4, true, false", "gemm_split_kernel<1, 2, 4, 2, true, false", "gemm_split_kernel<2, 2, 4, 2, false, false, true", "gemm_split_kernel<2, 2, 4, 2, true, false, true"),
                  "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
-                 "awseg_attention_d32_split": "attention_d32_split_kernel", "awseg_depth_head_fused": ("wino8p_kernel<2, false>", "wino8p_kernel<2, true>"),
+                 "awseg_attention_d32_split": "attention_d32_split_kernel", "awseg_attention_d32_split_ws": "attention_d32_split_img_kernel",
+                 "awseg_attention_d32_packed_kv": "attention_d32_split_kernel", "awseg_gemm_split_dual_bias_act": ("gemm_split3_kernel<false, 0, false, 8, 8, true", "gemm_split3_kernel<false, 0, false, 4, 4, true", "gemm_split3_kernel<false, 0, false, 4, 8, true", "gemm_split3_kernel<false, 0, false, 2, 4, true", "gemm_split3_kernel<false, 0, false, 2, 8, true"),
+                 "awseg_aspp_depthwise3_mean": "aspp_dw3_lds_kernel", "awseg_stem_image": "stem_image_kernel",
+                 "awseg_depth_head_fused": ("wino8p_kernel<2, false>", "wino8p_kernel<2, true>"),
                  "awseg_upconv_forms": "upconv_forms_kernel", "awseg_weather_batch": "weather_batch_kernel", "awseg_mixffn_fused": ("mixffn_kernel<32>", "mixffn_kernel<64>"),
                  "awseg_segformer_head_fused": "head_mfma_classify_kernel<8>", "awseg_segformer_head_fused_split": "head_split_classify_kernel<8>", "awseg_combine_argmax_confusion": "combine_argmax_confusion_kernel<0", "awseg_combine_confusion_stats": "ensemble_stats_kernel<",
                  "awseg_upconv3x3_adjoint": "upconv3x3_adjoint_kernel", "awseg_upconv3x3_linear": "head_mfma_kernel<", "awseg_dwconv3x3_wgrad_nhwc": "dwconv3x3_wgrad_partial_kernel",
@@ -240,7 +276,7 @@ TRAFFIC_TABLES = ["r04_bench_step_stats_and_traffic.csv", "r03_bench_step_stats_
                   "r01_kernel_bench_v4_stats_and_traffic.csv"]   # first match wins
 
 
-B5_TRAFFIC_TABLE = "r03_bench_b5_step_stats_and_traffic.csv"     # the same passes of `bench.py --model b5_r101`
+B5_TRAFFIC_TABLE = "r04_bench_b5_step_stats_and_traffic.csv"     # the same passes of `bench.py --model b5_r101`
 
 
 TRAIN_TRAFFIC_TABLE = "r04_train_step_stats_and_traffic.csv"     # the same passes of `bench.py --mode train`

@@ -546,6 +546,15 @@ int awseg_conv3x3_winograd_split_nhwc(const float* x, int batch, int height, int
                                       const uint16_t* u_split, const float* shift, const float* residual, int act,
                                       const float* w2, const float* b2, float* out, awseg_stream_t stream);
 
+/* awseg_gemm_split_pieces_bias_act: the split-operand GEMM over an A operand that lies in 2 .. 4 equally wide pieces along K —
+ *     out[M,N] = act([x_0 | x_1 | ...] . w^T + bias (+ residual)),  x_i float32 [M,k_piece] (pieces: HOST array of device pointers),
+ * w_split = awseg_gemm_split_weights of w [N, n_pieces*k_piece].  The 1x1 projection behind smp's ASPP (the model built at
+ * PKG/models/model.py:262-268) is project(cat(branches)) = sum_i branch_i . P_i^T: with the four pixel branches as pieces the sum is
+ * ONE product instead of four accumulating launches, and the concatenated map still never exists.  k_piece % 32 == 0; LDS-DMA kernel
+ * only (AWSEG_ERANGE otherwise).  Epilogue, range guard and error codes as awseg_gemm_split_bias_act. */
+int awseg_gemm_split_pieces_bias_act(const float* const* pieces, int n_pieces, int k_piece, const uint16_t* w_split, const float* bias,
+                                     const float* residual, int act, float* out, int64_t m, int n, awseg_stream_t stream);
+
 /* awseg_gemm_split_dual_bias_act: the split-operand GEMM with its A operand in TWO pieces along K —
  *     out[M,N] = act([x | x2] . w^T + bias (+ residual)),  x float32 [M,k1],  w_split = awseg_gemm_split_weights of w [N, k1+k2]
  * where x2 is either float32 rows [M,k2] (x2_stride == 0) or an NHWC image [batch, x2_height, x2_width, k2] whose pixels

@@ -1721,3 +1721,20 @@ def test_attention_d32_prepared_key_value_image_equals_in_block_staging(ops, sca
         ops.ATTN_KV_IMAGE = prev
     assert torch.isfinite(got).all()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("case", [(70000, 256, 256, 4), (5000, 256, 64, 3), (300, 512, 128, 2), (65536, 256, 256, 4)])
+def test_gemm_split_pieces_vs_float64(ops, case):
+    """The split-operand GEMM over an A operand in 2 .. 4 equally wide pieces (the ASPP projection over its branches without the
+    concatenated map): against float64 with bias, ReLU and a residual that aliases the output."""
+    m, n, kp, npieces = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    pieces = [torch.randn(m, kp, device="cuda", generator=g) for _ in range(npieces)]
+    w = torch.randn(n, kp * npieces, device="cuda", generator=g) / (kp * npieces) ** 0.5
+    b = torch.randn(n, device="cuda", generator=g)
+    r = torch.randn(m, n, device="cuda", generator=g)
+    ref = torch.relu(torch.cat(pieces, dim=1).double() @ w.double().t() + b.double() + r.double())
+    acc = r.clone()
+    got = ops.gemm_split_pieces(pieces, ops.gemm_split_weights(w), b, 1, residual=acc, out=acc)
+    assert got is not None and got.data_ptr() == acc.data_ptr()
+    assert (got.double() - ref).abs().max().item() < 2e-5

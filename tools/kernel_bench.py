@@ -206,6 +206,18 @@ def main():
     gemm_case("aspp 1x1", px16, 256, 2048, False)
     gemm_case("aspp project", px16, 256, 1280, False)
     gemm_case("decoder pw1", px4, 256, 304, False)
+
+    def dual_case(name, b, ho, wo, k1, k2, n, st):
+        # first bottleneck of a ResNet stage: relu([z | input at the stride] . [W3 | Wd]^T + b) in one launch; bytes: z, the gathered input rows, the output
+        m = b * ho * wo
+        z = torch.randn(m, k1, device=dev)
+        x2 = torch.randn(b, ho * st, wo * st, k2, device=dev) if st > 1 else torch.randn(m, k2, device=dev)
+        wsd = ops.gemm_split_weights(torch.randn(n, k1 + k2, device=dev) * 0.05); bd = torch.randn(n, device=dev)
+        cases[f"gemm dual {name} M={m} N={n} K={k1}+{k2} [split f16x3, issued flops]"] = (lambda: ops.gemm_split_dual(z, x2, wsd, bd, 1, stride=st if st > 1 else 0), "mfma_f16", 3 * 2.0 * m * n * (k1 + k2))
+        cases[f"gemm dual {name} M={m} N={n} K={k1}+{k2} [as HBM bytes]"] = (lambda: ops.gemm_split_dual(z, x2, wsd, bd, 1, stride=st if st > 1 else 0), "hbm", 4.0 * (m * (k1 + k2) + m * n))
+    dual_case("l1 block0 tail", B, H // 4, W // 4, 64, 64, 256, 1)
+    dual_case("l2 block0 tail (stride-2 gather)", B, H // 8, W // 8, 128, 256, 512, 2)
+    dual_case("l4 block0 tail", B, H // 16, W // 16, 512, 1024, 2048, 1)
     gemm_case("decoder pw2", px4, 256, 256, False)
 
     def attn_case(name, nh, nq, nkv):

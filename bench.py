@@ -146,6 +146,15 @@ def launch_work(name, args):
         if nbytes / (HBM_PEAK_GBS * 1e9) > flops / (MFMA_F16_PEAK_TFLOPS * 1e12):
             return "hbm", nbytes, name + " [launches bound by HBM]"
         return "mfma_f16", flops
+    if name == "awseg_gemm_split_pieces_bias_act":
+        # (pieces, n_pieces, k_piece, w_split, bias, residual, act, out, m, n): one product over the pieces; each piece, the residual and the output once
+        npc, kp = args[1], args[2]
+        m, n = args[8], args[9]
+        flops = 3 * 2.0 * m * n * npc * kp
+        nbytes = 4.0 * (m * npc * kp + m * n * (2 if args[5] is not None else 1) + n * npc * kp)
+        if nbytes / (HBM_PEAK_GBS * 1e9) > flops / (MFMA_F16_PEAK_TFLOPS * 1e12):
+            return "hbm", nbytes, name + " [launches bound by HBM]"
+        return "mfma_f16", flops
     if name == "awseg_stem_image":
         # (x, batch, channels, H, W, ...): the planar frames in, the 4-channel image's interior out
         _, b, c, h, w = args[:5]
@@ -262,6 +271,7 @@ DEVICE_KERNEL = {"awseg_conv3x3_winograd_nhwc": "conv3x3_wino_kernel<1>",
                  "awseg_gemm_bf16_bias_act": ("gemm_split3_kernel<false, 0, true", "gemm_split_kernel<2, 2, 2, 4, false, true", "gemm_split_kernel<1, 2, 4, 2, false, true"),
                  "awseg_attention_d32_split": "attention_d32_split_kernel", "awseg_attention_d32_split_ws": "attention_d32_split_img_kernel",
                  "awseg_attention_d32_packed_kv": "attention_d32_split_kernel", "awseg_gemm_split_dual_bias_act": ("gemm_split3_kernel<false, 0, false, 8, 8, true", "gemm_split3_kernel<false, 0, false, 4, 4, true", "gemm_split3_kernel<false, 0, false, 4, 8, true", "gemm_split3_kernel<false, 0, false, 2, 4, true", "gemm_split3_kernel<false, 0, false, 2, 8, true"),
+                 "awseg_gemm_split_pieces_bias_act": ("gemm_split3_kernel<false, 0, false, 8, 8, true", "gemm_split3_kernel<false, 0, false, 4, 4, true"),
                  "awseg_aspp_depthwise3_mean": "aspp_dw3_lds_kernel", "awseg_stem_image": "stem_image_kernel",
                  "awseg_depth_head_fused": ("wino8p_kernel<2, false>", "wino8p_kernel<2, true>"),
                  "awseg_upconv_forms": "upconv_forms_kernel", "awseg_weather_batch": "weather_batch_kernel", "awseg_mixffn_fused": ("mixffn_kernel<32>", "mixffn_kernel<64>"),

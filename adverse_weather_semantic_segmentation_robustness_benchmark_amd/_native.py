@@ -35,6 +35,7 @@ assert FOG_JOB.itemsize == 32 and NIGHT_JOB.itemsize == 32 and PRIM_JOB.itemsize
 # name -> (restype, argtypes); every symbol include/awseg.h declares
 SIGNATURES = {
     "awseg_abi_version": (c_i, []),
+    "awseg_header_hash": (C.c_uint64, []),
     "awseg_error_string": (C.c_char_p, [c_i]),
     "awseg_device_count": (c_i, []),
     "awseg_metrics_workspace": (c_i64, [c_i64, c_i, c_i64]),
@@ -143,6 +144,15 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)          # AttributeError here == header/library drift
             fn.restype, fn.argtypes = res, args
+        # a library built from another state of include/awseg.h takes other arguments than these bindings pass: refuse it
+        # (a stale .so next to newer sources is exactly how that happens; the symbols above may all still exist)
+        header = LIB_PATH.parent.parent / "include" / "awseg.h"
+        built = int(handle.awseg_header_hash())
+        if built and header.exists():
+            from .csrc.build import header_hash
+            if built != header_hash():
+                raise AwsegError(f"{LIB_PATH} was built from another include/awseg.h than the one beside it (ABI drift): rebuild it with "
+                                 "`python -m adverse_weather_semantic_segmentation_robustness_benchmark_amd.csrc.build`")
         _lib = handle
     return _lib
 

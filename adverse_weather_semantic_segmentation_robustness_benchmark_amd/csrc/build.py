@@ -21,7 +21,18 @@ SOURCES = ["core.hip", "metrics.hip", "weather.hip", "loss.hip", "heads.hip", "b
 ARCH = "gfx950"
 # per-file extras.  wino.hip: the SLP vectoriser packs the scalar inverse transform of the fused-head epilogue into
 # v_pk_add_f32 fed by ~220 v_mov (and spills); the kernel packs by hand where adjacent registers make it free.
-EXTRA_FLAGS = {"attn.hip": ["-DAWSEG_ATTN_SPLIT_WAVES=" + os.environ.get("AWSEG_ATTN_SPLIT_WAVES", "2")], "wino.hip": ["-fno-slp-vectorize"], "wino_split.hip": ["-fno-slp-vectorize", "-DAWSEG_WS_ASM_PK"]}
+HEADER = PKG.parent / "include" / "awseg.h"
+
+
+def header_hash() -> int:
+    """60 bits of sha256(include/awseg.h): compiled into the library (awseg_header_hash) and compared by _native.lib() when it loads
+    it, so that a library built from another state of the ABI is refused instead of being called with the wrong arguments."""
+    import hashlib
+    return int(hashlib.sha256(HEADER.read_bytes()).hexdigest()[:15], 16)
+
+
+EXTRA_FLAGS = {"attn.hip": ["-DAWSEG_ATTN_SPLIT_WAVES=" + os.environ.get("AWSEG_ATTN_SPLIT_WAVES", "2")], "wino.hip": ["-fno-slp-vectorize"], "wino_split.hip": ["-fno-slp-vectorize", "-DAWSEG_WS_ASM_PK"],
+               "core.hip": ["-DAWSEG_HEADER_HASH=0x%xULL" % header_hash()]}
 
 
 def hipcc() -> str:
@@ -49,7 +60,7 @@ def needs_build() -> bool:
     if not STAMP.exists() or STAMP.read_text() != _flag_stamp():
         return True
     t = LIB.stat().st_mtime
-    deps = [CSRC / s for s in SOURCES] + [CSRC / "awseg_common.h", PKG.parent / "include" / "awseg.h"]
+    deps = [CSRC / s for s in SOURCES] + [CSRC / "awseg_common.h", HEADER]
     return any(d.stat().st_mtime > t for d in deps)
 
 

@@ -3,6 +3,11 @@
 
 AWSEG_API int awseg_abi_version(void) { return 1; }
 
+#ifndef AWSEG_HEADER_HASH
+#define AWSEG_HEADER_HASH 0ULL
+#endif
+AWSEG_API unsigned long long awseg_header_hash(void) { return AWSEG_HEADER_HASH; }     // csrc/build.py: 60 bits of sha256(include/awseg.h)
+
 AWSEG_API const char* awseg_error_string(int code)
 {
     switch (code) {

@@ -56,6 +56,10 @@ typedef void* awseg_stream_t;
 #define AWSEG_GAUSS_RADIUS 8   /* scipy gaussian_filter(sigma=2, truncate=4) -> 17 taps */
 
 int         awseg_abi_version(void);          /* bumps when a signature changes */
+/* 60 bits of sha256 of THIS file as it was when the library was built (csrc/build.py passes it to the compiler): a binding that
+ * loads the library next to a header with another hash is looking at another ABI and must refuse to call it (the ctypes host side
+ * does: adverse_weather_semantic_segmentation_robustness_benchmark_amd/_native.py).  0: built without the build script. */
+unsigned long long awseg_header_hash(void);
 const char* awseg_error_string(int code);     /* host string for any return code */
 int         awseg_device_count(void);         /* hipGetDeviceCount, 0 when no GPU */
 

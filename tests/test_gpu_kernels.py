@@ -1579,10 +1579,15 @@ def test_upsample_bilinear_reads_nhwc_rows_through_strides(ops):
     rows = torch.randn(2, 24, 40, 19, device="cuda", generator=g)              # [B,h,w,C]
     view = rows.permute(0, 3, 1, 2)
     assert not view.is_contiguous()
-    for size, align in (((96, 160), True), ((96, 160), False), ((48, 80), True)):
-        ref = ops.upsample_bilinear(view.contiguous(), size, align)
-        got = ops.upsample_bilinear(view, size, align)
-        assert torch.equal(got, ref)
+    prev = ops.STRIDED_UPSAMPLE
+    try:
+        ops.STRIDED_UPSAMPLE = True                                # (off by default: the planar copy is the faster way at the bench shape)
+        for size, align in (((96, 160), True), ((96, 160), False), ((48, 80), True)):
+            ref = ops.upsample_bilinear(view.contiguous(), size, align)
+            got = ops.upsample_bilinear(view, size, align)
+            assert torch.equal(got, ref)
+    finally:
+        ops.STRIDED_UPSAMPLE = prev
     assert ops.N.lib().awseg_upsample_bilinear_strided(ops.N.ptr(rows), 2, 19, 24, 40, 24 * 40 * 19, 1, 40 * 19, 19, 48, 80, 1,
                                                       ops.N.ptr(torch.empty(2, 19, 48, 80, device="cuda")), None) == -2     # AWSEG_ERANGE
 
